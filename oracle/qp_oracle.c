@@ -1,0 +1,57 @@
+/*
+ * TEST INFRASTRUCTURE — NOT PRODUCT CODE.  See qp_oracle_impl.h / qp_oracle.h.
+ * Instantiates the restatement for double and float, like src/qp.cpp:385-386.
+ */
+#include "qp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* defaults of QPSolverSettings, qp.hpp:38-53 */
+void qpo_default_settings(qpo_settings *s) {
+    s->rho = 1e-1;
+    s->sigma = 1e-6;
+    s->alpha = 1.0;
+    s->eps_rel = 1e-3;
+    s->eps_abs = 1e-3;
+    s->max_iter = 1000;
+    s->check_termination = 25;
+    s->warm_start = 0;
+    s->adaptive_rho = 0;
+    s->adaptive_rho_tolerance = 5;
+    s->adaptive_rho_interval = 25;
+    s->verbose = 0;
+}
+
+int qpo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+#define SCALAR double
+#define SCALAR_EPS DBL_EPSILON
+#define SCALAR_MIN DBL_MIN
+#define SFX(name) name##_f64
+#include "qp_oracle_impl.h"
+#undef SCALAR
+#undef SCALAR_EPS
+#undef SCALAR_MIN
+#undef SFX
+
+#define SCALAR float
+#define SCALAR_EPS FLT_EPSILON
+#define SCALAR_MIN FLT_MIN
+#define SFX(name) name##_f32
+#include "qp_oracle_impl.h"
+#undef SCALAR
+#undef SCALAR_EPS
+#undef SCALAR_MIN
+#undef SFX
