@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""bench.py — QP-subproblem throughput of the MI355X-native batched ADMM solver.
+
+A "step" = one pass of the hot path over one synthetic batch: `setup(); solve()` (fused, one
+kernel launch) for every QP of this rank's shard, inputs already resident in HBM.  Default
+workload = BASELINE.json configs[2] sharded weakly: 8,192 dense QPs (n=50, m=100, fp64) per GPU,
+i.e. the 65,536-QP batch at 8 GPUs; `--mode fixed` runs exactly `--iters` ADMM iterations per QP
+(check_termination=0), `--mode default` uses the reference's default settings (eps 1e-3, check
+every 25, max_iter 1000).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (HBM, from HIP
+events recorded on the launch stream around every timed launch) and `cpu_baseline` (the CPU oracle,
+a port of the reference's src/qp.cpp, timed on this host's cores on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=50)
+    ap.add_argument("--m", type=int, default=100)
+    ap.add_argument("--batch-per-gpu", type=int, default=8192)
+    ap.add_argument("--mode", choices=["fixed", "default"], default="fixed")
+    ap.add_argument("--iters", type=int, default=200, help="ADMM iterations per QP in --mode fixed")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--force-generic", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL gather of results (N>1)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from sqp_solver_amd import QPSolverBatch
+    from sqp_solver_amd.problems import random_qp_batch_torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n, m, B = args.n, args.m, args.batch_per_gpu
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    ndt = np.float64 if args.dtype == "f64" else np.float32
+
+    # synthetic, device-resident, per-QP column-major (the C-ABI layout); rank-dependent seed
+    P, q, A_cm, l, u = random_qp_batch_torch(B, n, m, seed=20250228 + 3 + 1000 * rank, dtype=tdt, device=dev)
+    torch.cuda.synchronize()
+
+    solver = QPSolverBatch(n, m, B, dtype=ndt, device=local_rank, force_generic=args.force_generic)
+    st = solver.settings
+    if args.mode == "fixed":
+        st.max_iter = args.iters
+        st.check_termination = 0
+    solver.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # device views of the resident results for the gather
+    xp, yp, zp, ip = solver.device_state_ptrs()
+
+    def step():
+        solver.setup_solve(P, q, A_cm, l, u, colmajor=True)
+
+    gather_bufs = None
+    if world > 1 and not args.no_gather:
+        # final collection of (x, y, info) records on rank 0 over xGMI (RCCL gather)
+        from sqp_solver_amd.dist import ResultGather
+
+        gather_bufs = ResultGather(solver, world, rank, dev)
+
+    def full_step():
+        step()
+        if gather_bufs is not None:
+            gather_bufs.gather()
+
+    for _ in range(args.warmup):
+        full_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    solver.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = solver.collect_kernel_ms()
+    solver.enable_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # total ADMM iterations of the last step (info.iter counts max_iter+1 when exhausted, qp.cpp:147-150)
+    info = solver.info()
+    iters_local = int(np.minimum(info.iter, st.max_iter).sum())
+    n_solved = int((info.status == 0).sum())
+    if world > 1:
+        t = torch.tensor([iters_local, n_solved], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        iters_total, solved_total = int(t[0].item()), int(t[1].item())
+    else:
+        iters_total, solved_total = iters_local, n_solved
+
+    total_qps = B * world * args.steps
+    value = total_qps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    admm_iters_per_sec = iters_total * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        bytes_per_qp = solver.algorithmic_bytes_per_qp()
+        avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        achieved = bytes_per_qp * B / (avg_kernel_ms * 1e-3) / 1e9
+        flops_per_iter = 2.0 * (2 * m * n + n * n)  # Schur-ordered iteration
+        iters_per_qp = iters_local / B
+        out = {
+            "metric": "qp_solves_per_sec",
+            "value": value,
+            "unit": "QP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2] shard: %d dense QPs n=%d m=%d per GPU (%d total), %s" % (
+                    B, n, m, B * world,
+                    ("fixed %d ADMM iterations (check_termination=0)" % args.iters) if args.mode == "fixed"
+                    else "reference default settings (eps 1e-3, check 25, max_iter 1000)"),
+                "n": n, "m": m, "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
+                "admm_iters_per_qp": iters_per_qp, "kernel": solver.kernel_name(),
+                "parallelism": "batch-sharded x%d" % world,
+                "gather": bool(gather_bufs is not None),
+            },
+            "admm_iters_per_sec": admm_iters_per_sec,
+            "solved_fraction": solved_total / float(B * world),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_qp": bytes_per_qp,
+                "kernel_ms_avg": avg_kernel_ms,
+                "kernel_launches_timed": len(kernel_ms),
+                "onchip_f64_tflops": flops_per_iter * iters_local / (avg_kernel_ms * 1e-3) / 1e12,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt):
+    """Time the CPU oracle (port of the reference's src/qp.cpp) on a bounded sample of the same
+    batch on this host's cores, and check the GPU results of that sample against it."""
+    import numpy as np
+
+    import oracle
+
+    B, n, m = P.shape[0], args.n, args.m
+    ost = oracle.default_settings(
+        rho=st.rho, sigma=st.sigma, alpha=st.alpha, eps_rel=st.eps_rel, eps_abs=st.eps_abs,
+        max_iter=st.max_iter, check_termination=st.check_termination, warm_start=st.warm_start,
+        adaptive_rho=st.adaptive_rho, adaptive_rho_tolerance=st.adaptive_rho_tolerance,
+        adaptive_rho_interval=st.adaptive_rho_interval)
+    cores = oracle.max_threads()
+
+    def host(k):
+        # oracle.solve_batch takes math-indexed [b,i,j]; the device arrays are column-major per QP
+        return (P[:k].cpu().numpy().transpose(0, 2, 1), q[:k].cpu().numpy(),
+                A_cm[:k].cpu().numpy().transpose(0, 2, 1), l[:k].cpu().numpy(), u[:k].cpu().numpy())
+
+    pilot = min(B, max(cores * 4, 32))
+    hp = host(pilot)
+    t0 = time.perf_counter()
+    oracle.solve_batch(*hp, settings=ost, nthreads=cores, dtype=ndt)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    sample = int(min(B, max(pilot, args.cpu_seconds / dt * pilot)))
+    hs = host(sample)
+    t0 = time.perf_counter()
+    xo, yo, zo, io = oracle.solve_batch(*hs, settings=ost, nthreads=cores, dtype=ndt)
+    dt = time.perf_counter() - t0
+    xg, yg, zg, ig = solver.solution()
+
+    def rel(a, b):
+        den = np.maximum(np.max(np.abs(b), axis=1), 1e-300)
+        return float(np.max(np.max(np.abs(a - b), axis=1) / den))
+
+    return {
+        "value": sample / dt,
+        "unit": "QP/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "first %d QPs of rank 0's batch, same settings, oracle/qp_oracle.c with OpenMP over QPs (%.1f s)" % (sample, dt),
+        "admm_iters_per_sec": float(np.minimum(io["iter"], st.max_iter).sum()) / dt,
+        "parity_max_rel_err_x": rel(xg[:sample], xo),
+        "parity_max_rel_err_y": rel(yg[:sample], yo),
+        "parity_status_equal": bool((ig.status[:sample] == io["status"]).all()),
+        "parity_iter_equal": bool((ig.iter[:sample] == io["iter"]).all()),
+    }
+
+
+if __name__ == "__main__":
+    main()

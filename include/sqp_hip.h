@@ -1,0 +1,173 @@
+/*
+ * sqp_hip.h — C-ABI of libsqp_hip.so: MI355X-native batched ADMM QP-subproblem solver.
+ *
+ * This is the drop-in boundary for the reference's QP hot path.  The reference has no
+ * FFI layer of its own (it is a C++11/Eigen class library), so each entry point below
+ * replaces a *method of qp_solver::QPSolver<Scalar>* applied to a whole batch of
+ * same-(n,m) problems; the C++ facade in include/sqp_hip/qp.hpp re-creates the class on
+ * top of these calls (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ *   reference interface (file:line under /root/reference)      C-ABI entry point
+ *   ---------------------------------------------------------  ---------------------------
+ *   QPSolverSettings<Scalar>      include/solvers/qp.hpp:36-54     sqph_settings
+ *   QPSolverInfo<Scalar>          include/solvers/qp.hpp:72-80     sqph_info
+ *   QPSolverStatus                include/solvers/qp.hpp:70        SQPH_SOLVED ... (same order)
+ *   QuadraticProblem<Scalar>      include/solvers/qp.hpp:19-34     sqph_qp_batch (borrowed ptrs)
+ *   QPSolver::setup(qp)           src/qp.cpp:11-44                 sqph_setup
+ *   QPSolver::update_qp(qp)       src/qp.cpp:46-62                 sqph_update_qp
+ *   QPSolver::solve(qp)           src/qp.cpp:64-157                sqph_solve
+ *   setup(qp); solve(qp)          src/sqp.cpp:221-222 (run_solve_qp) sqph_setup_solve (one launch)
+ *   primal_solution()/dual_solution()/info()  qp.hpp:160-170       sqph_get_solution / sqph_device_state
+ *   settings()                    qp.hpp:166-167                   sqph_set_settings / sqph_get_settings
+ *   static constr_type_init(l,u,type)  src/qp.cpp:283-294          sqph_constr_type_init (host utility)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.  dtype selects Scalar.
+ *   - every QP of a batch has the same (n, m).  Matrices are per-QP COLUMN-MAJOR (Eigen's
+ *     default, qp.hpp:27), QP-major across the batch: problem b starts at base + b*stride
+ *     (strides in elements; stride 0 = the same array is shared by every QP of the batch).
+ *   - problem data is borrowed for the duration of the call only (host memspace: copied to
+ *     the device inside the call; device memspace: must stay valid until the stream reaches
+ *     the end of the enqueued work).
+ *   - all calls are asynchronous on the solver's stream except where noted.
+ *   - return value: 0 = ok, <0 = API misuse or HIP error (message via sqph_last_error).
+ *     Per-QP numerical status is in sqph_info::status, exactly as in the reference.
+ *   - P and A given to sqph_solve must be the ones given to the preceding
+ *     sqph_setup / sqph_update_qp; q, l, u may differ (the reference re-reads them from
+ *     solve()'s argument, src/qp.cpp:89,100,112).
+ */
+#ifndef SQP_HIP_H
+#define SQP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQPH_VERSION 1
+
+/* Scalar type of a solver instance (QPSolver<double> / QPSolver<float>, src/qp.cpp:385-386) */
+enum { SQPH_F64 = 0, SQPH_F32 = 1 };
+/* where caller buffers live */
+enum { SQPH_HOST = 0, SQPH_DEVICE = 1 };
+/* QPSolverStatus, qp.hpp:70 — same numeric order */
+enum { SQPH_SOLVED = 0, SQPH_MAX_ITER_EXCEEDED = 1, SQPH_UNSOLVED = 2, SQPH_NUMERICAL_ISSUES = 3, SQPH_UNINITIALIZED = 4 };
+/* ConstraintType, qp.hpp:134 — same numeric order */
+enum { SQPH_INEQUALITY_CONSTRAINT = 0, SQPH_EQUALITY_CONSTRAINT = 1, SQPH_LOOSE_BOUNDS = 2 };
+/* error codes */
+enum {
+    SQPH_OK = 0,
+    SQPH_ERR_INVALID = -1,     /* bad argument / misuse */
+    SQPH_ERR_HIP = -2,         /* HIP runtime error */
+    SQPH_ERR_UNSUPPORTED = -3, /* shape outside what the kernels cover */
+    SQPH_ERR_NO_DEVICE = -4    /* no HIP device: there is NO CPU fallback */
+};
+
+/* QPSolverSettings<Scalar>, qp.hpp:36-54; values are converted to Scalar on use */
+typedef struct sqph_settings {
+    double rho;                    /* 1e-1 */
+    double sigma;                  /* 1e-6 */
+    double alpha;                  /* 1.0  */
+    double eps_rel;                /* 1e-3 */
+    double eps_abs;                /* 1e-3 */
+    int max_iter;                  /* 1000 */
+    int check_termination;         /* 25, 0 = never */
+    int warm_start;                /* 0 */
+    int adaptive_rho;              /* 0 */
+    double adaptive_rho_tolerance; /* 5 */
+    int adaptive_rho_interval;     /* 25 */
+    int verbose;                   /* 0 (ignored on device) */
+} sqph_settings;
+
+/* QPSolverInfo<Scalar>, qp.hpp:72-80 (40 bytes; Scalar fields widened to double) */
+typedef struct sqph_info {
+    int status;
+    int iter;
+    int rho_updates;
+    int _pad;
+    double rho_estimate;
+    double res_prim;
+    double res_dual;
+} sqph_info;
+
+/* A batch of QuadraticProblem<Scalar> (qp.hpp:19-34): non-owning pointers. */
+typedef struct sqph_qp_batch {
+    int batch;    /* number of QPs, <= capacity given at creation */
+    int memspace; /* SQPH_HOST or SQPH_DEVICE */
+    const void *P; /* n x n, col-major; only its lower triangle enters the factor (LDLT<Lower>) */
+    const void *q; /* n */
+    const void *A; /* m x n, col-major */
+    const void *l; /* m */
+    const void *u; /* m */
+    long long stride_P, stride_q, stride_A, stride_l, stride_u; /* elements; 0 = shared */
+} sqph_qp_batch;
+
+typedef struct sqph_solver sqph_solver;
+
+/* Behaviour flags for sqph_create */
+enum {
+    /* 0: supported-class semantics, src/qp.cpp:78-82 — `warm_start=false` does NOT reset x,z,y
+     *    in solve() (the reference calls the static Zero() factory and drops the result);
+     * 1: legacy-class semantics, include/unsupported/qp_solver.hpp:256-260 — it does reset. */
+    SQPH_FLAG_LEGACY_COLD_START = 1,
+    /* force the generic (global-memory) kernel even where a register-tiled one exists */
+    SQPH_FLAG_FORCE_GENERIC = 2
+};
+
+void sqph_default_settings(sqph_settings *s);
+
+/* Create a batched solver bound to HIP device `device`: `batch_capacity` instances of
+ * QPSolver<Scalar> for n variables and m constraints. Every instance starts UNINITIALIZED. */
+int sqph_create(sqph_solver **out, int device, int n, int m, int batch_capacity, int dtype, int flags);
+void sqph_destroy(sqph_solver *s);
+
+/* Stream the kernels/copies are enqueued on (a hipStream_t; NULL = the null stream). */
+int sqph_set_stream(sqph_solver *s, void *hip_stream);
+
+int sqph_set_settings(sqph_solver *s, const sqph_settings *settings);
+int sqph_get_settings(const sqph_solver *s, sqph_settings *settings);
+
+int sqph_setup(sqph_solver *s, const sqph_qp_batch *qp);       /* QPSolver::setup for each QP     */
+int sqph_update_qp(sqph_solver *s, const sqph_qp_batch *qp);   /* QPSolver::update_qp             */
+int sqph_solve(sqph_solver *s, const sqph_qp_batch *qp);       /* QPSolver::solve                 */
+int sqph_setup_solve(sqph_solver *s, const sqph_qp_batch *qp); /* setup()+solve(), single launch  */
+
+/* Copy out primal x [batch][n], dual y [batch][m], z [batch][m] and info [batch]; any pointer
+ * may be NULL. With SQPH_HOST this call synchronises the stream before returning. */
+int sqph_get_solution(sqph_solver *s, int batch, int memspace, void *x, void *y, void *z, sqph_info *info);
+
+/* Overwrite the iterates (warm-start injection; the reference exposes them through the
+ * non-const primal_solution()/dual_solution() accessors). NULL = leave unchanged. */
+int sqph_set_state(sqph_solver *s, int batch, int memspace, const void *x, const void *z, const void *y);
+
+/* Device-resident state arrays (QP-major, valid until sqph_destroy): no copy. */
+int sqph_device_state(sqph_solver *s, void **x, void **y, void **z, sqph_info **info);
+
+int sqph_synchronize(sqph_solver *s);
+
+/* Name of the kernel variant the last launch used ("generic_w1", "tile_13x7", ...). */
+const char *sqph_kernel_name(const sqph_solver *s);
+/* Last launch duration helpers: records HIP events around every launch when enabled. */
+int sqph_enable_timing(sqph_solver *s, int on);
+/* Milliseconds of the last launched kernel (synchronises on its stop event). */
+int sqph_last_kernel_ms(sqph_solver *s, float *ms);
+/* Durations (ms) of every launch since timing was enabled / last collected; writes up to
+ * `cap` values, returns the number of launches in *count and clears the list. */
+int sqph_collect_kernel_ms(sqph_solver *s, float *ms, int cap, int *count);
+
+const char *sqph_last_error(const sqph_solver *s);
+/* error text for failures where no solver exists yet (sqph_create) */
+const char *sqph_global_error(void);
+
+/* static QPSolver::constr_type_init(l, u, constr_type), src/qp.cpp:283-294 (host, no device) */
+int sqph_constr_type_init(int dtype, int m, const void *l, const void *u, int *constr_type);
+
+/* Algorithmic HBM bytes of one setup+solve of one QP:
+ * sizeof(Scalar)*(n*n + n + m*n + 2m) read + sizeof(Scalar)*(n+m) written + sizeof(sqph_info). */
+long long sqph_algorithmic_bytes(int n, int m, int dtype);
+
+int sqph_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQP_HIP_H */

@@ -1,0 +1,344 @@
+// Generic ADMM kernel: one workgroup (1..4 wavefronts) per QP, runtime (n, m).
+//
+// This is the shape-agnostic fallback: matrices stay in global memory (L1/L2 resident while a
+// QP is being iterated), vectors live in LDS.  The register-tiled kernels in admm_tile.h are
+// the fast path for the shapes they cover.  Algorithm = the reference ADMM
+// (/root/reference/src/qp.cpp:64-157) on the Schur-ordered KKT system: with R = diag(rho_vec)
+//     S = P + sigma I + A' R A            (n x n, SPD)          [replaces the (n+m)^2 LDL^T, qp.cpp:159-259]
+//     x~ = S^-1 ( sigma x - q + A' R (z - R^-1 y) )             [== head(n) of K^-1 rhs, qp.cpp:89-92]
+//     z~ = A x~                                                 [== z_prev + R^-1 (nu - y),  qp.cpp:93]
+// followed by the verbatim x / z / y updates (qp.cpp:96-103), the residual/termination block
+// (qp.cpp:105-123, 316-371) and adaptive rho (qp.cpp:125-144, 296-314, 333-341).
+#pragma once
+#include "block_ops.h"
+#include "kargs.h"
+
+namespace sqph {
+
+template <typename T>
+__host__ __device__ inline size_t generic_lds_elems(int n, int m, int nt) {
+    // n-vectors: x xt b q Px row col ; m-vectors: z y w l u rho rinv zt Ax ; part[nt] ; red[7*nt]
+    return (size_t)7 * n + (size_t)9 * m + (size_t)8 * nt + 8;
+}
+
+// out[r] = sum_k M[k*ld + r] * v[k]   (outputs contiguous in memory => coalesced across lanes).
+// v, out, part in LDS. Ends with a barrier; callers must have synchronised v beforehand.
+template <typename T>
+__device__ __forceinline__ void matvec_cm(const T *__restrict__ M, long ld, int R, int K, const T *v, T *out, T *part) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (R <= 0) return;  // m == 0 (unconstrained QP): block-uniform
+    if (R >= nt) {
+        for (int r = tid; r < R; r += nt) {
+            T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int k = 0;
+            for (; k + 3 < K; k += 4) {
+                a0 += M[(long)k * ld + r] * v[k];
+                a1 += M[(long)(k + 1) * ld + r] * v[k + 1];
+                a2 += M[(long)(k + 2) * ld + r] * v[k + 2];
+                a3 += M[(long)(k + 3) * ld + r] * v[k + 3];
+            }
+            for (; k < K; k++) a0 += M[(long)k * ld + r] * v[k];
+            out[r] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        return;
+    }
+    // fewer outputs than threads: split the reduction range over G lane groups
+    const int G = nt / R;
+    const int g = tid / R;
+    const int r = tid - g * R;
+    T a0 = 0, a1 = 0;
+    if (g < G) {
+        int k = g;
+        for (; k + G < K; k += 2 * G) {
+            a0 += M[(long)k * ld + r] * v[k];
+            a1 += M[(long)(k + G) * ld + r] * v[k + G];
+        }
+        for (; k < K; k += G) a0 += M[(long)k * ld + r] * v[k];
+    }
+    part[tid] = a0 + a1;
+    __syncthreads();
+    if (tid < R) {
+        T s = 0;
+        for (int gg = 0; gg < G; gg++) s += part[gg * R + tid];
+        out[tid] = s;
+    }
+    __syncthreads();
+}
+
+// S = Psym + sigma I + A' diag(rho) A, then in-place Gauss-Jordan inversion (S is SPD: no pivoting).
+// Returns false (block-uniform) on a non-positive / non-finite pivot  => NUMERICAL_ISSUES.
+template <typename T>
+__device__ bool factor_schur_inverse(int n, int m, const T *__restrict__ P, const T *__restrict__ At, const T *rho,
+                                     T sigma, T *__restrict__ Sinv, T *row, T *col) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int nn = n * n;
+    for (int e = tid; e < nn; e += nt) {
+        const int j = e / n, i = e - j * n;
+        const int lo = i > j ? i : j, hi = i > j ? j : i;
+        // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>, qp.hpp:129)
+        T acc = P[(long)hi * n + lo] + (i == j ? sigma : T(0));
+        T s0 = 0, s1 = 0;
+        int k = 0;
+        for (; k + 1 < m; k += 2) {
+            s0 += At[(long)k * n + i] * rho[k] * At[(long)k * n + j];
+            s1 += At[(long)(k + 1) * n + i] * rho[k + 1] * At[(long)(k + 1) * n + j];
+        }
+        if (k < m) s0 += At[(long)k * n + i] * rho[k] * At[(long)k * n + j];
+        Sinv[e] = acc + (s0 + s1);
+    }
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        for (int i = tid; i < n; i += nt) {
+            col[i] = Sinv[(long)k * n + i];
+            row[i] = Sinv[(long)i * n + k];
+        }
+        __syncthreads();
+        const T d = row[k];
+        if (!(d > T(0)) || !(d * T(0) == T(0))) return false;  // uniform: every thread reads the same LDS word
+        const T dinv = T(1) / d;
+        for (int e = tid; e < nn; e += nt) {
+            const int j = e / n, i = e - j * n;
+            const T rkj = (j == k ? T(1) : row[j]) * dinv;
+            T v;
+            if (i == k) {
+                v = rkj;
+            } else {
+                const T base = (j == k) ? T(0) : Sinv[e];
+                v = base - col[i] * rkj;
+            }
+            Sinv[e] = v;
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// rho_vec_update, qp.cpp:296-314
+template <typename T>
+__device__ __forceinline__ T rho_for_type(int ctype, T rho0) {
+    return ctype == SQPH_LOOSE_BOUNDS ? T(1e-6) : (ctype == SQPH_EQUALITY_CONSTRAINT ? T(1e+3) * rho0 : rho0);
+}
+
+#ifdef SQPH_SIM
+#define SQPH_DYN_SMEM(name) unsigned char *name = ::sqph_sim::dyn_smem()
+#else
+#define SQPH_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+template <typename T>
+__global__ void admm_generic_kernel(KArgs<T> a) {
+    SQPH_DYN_SMEM(smem_raw);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int qp = blockIdx.x;
+    if (qp >= a.batch) return;
+    const int n = a.n, m = a.m;
+
+    T *lds = reinterpret_cast<T *>(smem_raw);
+    T *x = lds;          lds += n;
+    T *xt = lds;         lds += n;
+    T *b = lds;          lds += n;
+    T *q = lds;          lds += n;
+    T *Px = lds;         lds += n;
+    T *gjrow = lds;      lds += n;
+    T *gjcol = lds;      lds += n;
+    T *z = lds;          lds += m;
+    T *y = lds;          lds += m;
+    T *w = lds;          lds += m;
+    T *l = lds;          lds += m;
+    T *u = lds;          lds += m;
+    T *rho = lds;        lds += m;
+    T *rinv = lds;       lds += m;
+    T *zt = lds;         lds += m;
+    T *Ax = lds;         lds += m;
+    T *part = lds;       lds += nt;
+    T *red = lds;
+
+    const T *gP = a.P + (long)qp * a.sP;
+    const T *gq = a.q + (long)qp * a.sq;
+    const T *gA = a.A + (long)qp * a.sA;
+    const T *gl = a.l + (long)qp * a.sl;
+    const T *gu = a.u + (long)qp * a.su;
+    T *sx = a.x + (long)qp * n;
+    T *sz = a.z + (long)qp * m;
+    T *sy = a.y + (long)qp * m;
+    T *srho = a.rho_vec + (long)qp * m;
+    int *sct = a.ctype + (long)qp * m;
+    T *Sinv = a.Sinv + (long)qp * n * n;
+    T *At = a.At + (long)qp * m * n;
+
+    sqph_info info = a.info[qp];
+    T rho_s = a.rho[qp];
+    const int mode = a.mode;
+
+    if (!(mode & (MODE_SETUP | MODE_UPDATE)) &&
+        (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
+        return;  // qp.cpp:68-71
+
+    for (int j = tid; j < n; j += nt) q[j] = gq[j];
+    for (int i = tid; i < m; i += nt) {
+        l[i] = gl[i];
+        u[i] = gu[i];
+    }
+
+    if (mode & (MODE_SETUP | MODE_UPDATE)) {
+        // constr_type_init (qp.cpp:283-294) + rho_vec_update(settings.rho) (qp.cpp:296-314)
+        rho_s = a.rho0;
+        for (int i = tid; i < m; i += nt) {
+            const T li = l[i], ui = u[i];
+            int ct;
+            if (li < -T(1e16) && ui > T(1e16))
+                ct = SQPH_LOOSE_BOUNDS;
+            else if (ui - li < T(1e-4))
+                ct = SQPH_EQUALITY_CONSTRAINT;
+            else
+                ct = SQPH_INEQUALITY_CONSTRAINT;
+            sct[i] = ct;
+            const T r = rho_for_type<T>(ct, rho_s);
+            rho[i] = r;
+            rinv[i] = T(1) / r;
+            srho[i] = r;
+        }
+        info.rho_updates += 1;
+        if (mode & MODE_SETUP) {
+            for (int j = tid; j < n; j += nt) x[j] = 0;
+            for (int i = tid; i < m; i += nt) z[i] = y[i] = 0;
+        } else {
+            for (int j = tid; j < n; j += nt) x[j] = sx[j];
+            for (int i = tid; i < m; i += nt) {
+                z[i] = sz[i];
+                y[i] = sy[i];
+            }
+        }
+        // row-major copy of A: At[i*n + j] = A[j*m + i]
+        for (int e = tid; e < m * n; e += nt) {
+            const int i = e / n, j = e - i * n;
+            At[e] = gA[(long)j * m + i];
+        }
+        __syncthreads();
+        const bool ok = factor_schur_inverse<T>(n, m, gP, At, rho, a.sigma, Sinv, gjrow, gjcol);
+        __syncthreads();
+        info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;
+    } else {
+        for (int j = tid; j < n; j += nt) x[j] = sx[j];
+        for (int i = tid; i < m; i += nt) {
+            z[i] = sz[i];
+            y[i] = sy[i];
+            const T r = srho[i];
+            rho[i] = r;
+            rinv[i] = T(1) / r;
+        }
+    }
+    __syncthreads();
+
+    bool state_dirty = (mode & MODE_SETUP) != 0;
+
+    if ((mode & MODE_SOLVE) && info.status != SQPH_NUMERICAL_ISSUES && info.status != SQPH_UNINITIALIZED) {
+        if ((mode & MODE_COLD_RESET) && !a.warm_start) {
+            for (int j = tid; j < n; j += nt) x[j] = 0;
+            for (int i = tid; i < m; i += nt) z[i] = y[i] = 0;
+            __syncthreads();
+        }
+        state_dirty = true;
+        const T alpha = a.alpha, sigma = a.sigma;
+        const T one_m_alpha = T(1) - alpha;
+        T nrm_prim = 0, nrm_dual = 0;  // max_Ax_z_norm_, max_Px_ATy_q_norm_
+        int iter;
+        for (iter = 1; iter <= a.max_iter; iter++) {
+            // rhs tail (qp.cpp:275) pre-multiplied by R: w = R (z - R^-1 y)
+            for (int i = tid; i < m; i += nt) w[i] = rho[i] * (z[i] - rinv[i] * y[i]);
+            __syncthreads();
+            matvec_cm<T>(At, n, n, m, w, b, part);  // b = A' w
+            for (int j = tid; j < n; j += nt) b[j] = (sigma * x[j] - q[j]) + b[j];
+            __syncthreads();
+            matvec_cm<T>(Sinv, n, n, n, b, xt, part);  // x~
+            matvec_cm<T>(gA, m, m, n, xt, zt, part);   // z~ = A x~
+            for (int j = tid; j < n; j += nt) x[j] = alpha * xt[j] + one_m_alpha * x[j];
+            for (int i = tid; i < m; i += nt) {
+                const T zr = alpha * zt[i] + one_m_alpha * z[i];
+                T zn = zr + rinv[i] * y[i];
+                zn = zn < l[i] ? l[i] : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
+                zn = zn > u[i] ? u[i] : zn;
+                y[i] = y[i] + rho[i] * (zr - zn);
+                z[i] = zn;
+            }
+            __syncthreads();
+
+            const bool check = a.check_termination != 0 && (iter % a.check_termination == 0);
+            const bool adapt = a.adaptive_rho && (iter % a.adaptive_rho_interval == 0);
+            if (check || adapt) {
+                // update_state (qp.cpp:316-331) + residuals (qp.cpp:353-361)
+                matvec_cm<T>(gA, m, m, n, x, Ax, part);
+                matvec_cm<T>(gP, n, n, n, x, Px, part);
+                matvec_cm<T>(At, n, n, m, y, b, part);  // b <- A' y (b is dead here)
+                T v[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (int i = tid; i < m; i += nt) {
+                    v[0] = nanmax(v[0], tabs(Ax[i]));
+                    v[1] = nanmax(v[1], tabs(z[i]));
+                    v[2] = nanmax(v[2], tabs(Ax[i] - z[i]));
+                }
+                for (int j = tid; j < n; j += nt) {
+                    v[3] = nanmax(v[3], tabs(Px[j]));
+                    v[4] = nanmax(v[4], tabs(b[j]));
+                    v[5] = nanmax(v[5], tabs(q[j]));
+                    v[6] = nanmax(v[6], tabs(Px[j] + q[j] + b[j]));
+                }
+                block_nanmax<T, 7>(v, red);
+                nrm_prim = nanmax(v[0], v[1]);
+                nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
+                info.res_prim = (double)v[2];
+                info.res_dual = (double)v[6];
+                if (check) {
+                    // termination_criteria, qp.cpp:343-351, 363-371
+                    if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                        info.status = SQPH_SOLVED;
+                        break;
+                    }
+                }
+                if (adapt) {
+                    // rho_estimate, qp.cpp:333-341 ; clamp + tolerance test, qp.cpp:130-136
+                    const T eps = Num<T>::eps();
+                    const T rp_norm = v[2] / (nrm_prim + eps);
+                    const T rd_norm = v[6] / (nrm_dual + eps);
+                    T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
+                    new_rho = new_rho < T(1e+6) ? new_rho : T(1e+6);  // fmax(RHO_MIN, fmin(new_rho, RHO_MAX))
+                    new_rho = new_rho > T(1e-6) ? new_rho : T(1e-6);
+                    info.rho_estimate = (double)new_rho;
+                    if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
+                        rho_s = new_rho;
+                        for (int i = tid; i < m; i += nt) {
+                            const T r = rho_for_type<T>(sct[i], rho_s);
+                            rho[i] = r;
+                            rinv[i] = T(1) / r;
+                        }
+                        info.rho_updates += 1;
+                        __syncthreads();
+                        const bool ok = factor_schur_inverse<T>(n, m, gP, At, rho, sigma, Sinv, gjrow, gjcol);
+                        __syncthreads();
+                        if (!ok) {
+                            info.status = SQPH_NUMERICAL_ISSUES;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        if (iter > a.max_iter) info.status = SQPH_MAX_ITER_EXCEEDED;
+        info.iter = iter;
+    }
+
+    if (state_dirty) {
+        for (int j = tid; j < n; j += nt) sx[j] = x[j];
+        for (int i = tid; i < m; i += nt) {
+            sz[i] = z[i];
+            sy[i] = y[i];
+            srho[i] = rho[i];
+        }
+    }
+    if (tid == 0) {
+        a.info[qp] = info;
+        a.rho[qp] = rho_s;
+    }
+}
+
+}  // namespace sqph

@@ -1,0 +1,401 @@
+// libsqp_hip.so — host side of the C-ABI declared in include/sqp_hip.h.
+// Owns the per-batch device state of N QPSolver instances and launches the ADMM kernels.
+// There is deliberately NO CPU execution path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/sqp_hip.h"
+#include "admm_generic.h"
+#include "admm_tile.h"
+#include "kargs.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+size_t dsize(int dtype) { return dtype == SQPH_F32 ? sizeof(float) : sizeof(double); }
+
+}  // namespace
+
+struct sqph_solver {
+    int device = 0, n = 0, m = 0, cap = 0, dtype = SQPH_F64, flags = 0;
+    hipStream_t stream = nullptr;
+    sqph_settings settings{};
+    // persistent device state
+    void *x = nullptr, *z = nullptr, *y = nullptr, *rho_vec = nullptr, *rho = nullptr;
+    int *ctype = nullptr;
+    sqph_info *info = nullptr;
+    void *Sinv = nullptr, *At = nullptr;
+    // device staging for host-memspace problem data
+    void *sP = nullptr, *sq = nullptr, *sA = nullptr, *sl = nullptr, *su = nullptr;
+    std::string err;
+    const char *kernel_name = "none";
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;  // one pair per launch while timing is on
+    size_t ev_used = 0;
+};
+
+#define SQPH_FAIL(s, code, ...)                        \
+    do {                                               \
+        char buf_[512];                                \
+        snprintf(buf_, sizeof(buf_), __VA_ARGS__);     \
+        if (s) (s)->err = buf_;                        \
+        g_err = buf_;                                  \
+        return (code);                                 \
+    } while (0)
+
+#define SQPH_HIP(s, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) SQPH_FAIL(s, SQPH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+int sqph_version(void) { return SQPH_VERSION; }
+
+void sqph_default_settings(sqph_settings *s) {
+    // QPSolverSettings defaults, /root/reference/include/solvers/qp.hpp:38-53
+    s->rho = 1e-1;
+    s->sigma = 1e-6;
+    s->alpha = 1.0;
+    s->eps_rel = 1e-3;
+    s->eps_abs = 1e-3;
+    s->max_iter = 1000;
+    s->check_termination = 25;
+    s->warm_start = 0;
+    s->adaptive_rho = 0;
+    s->adaptive_rho_tolerance = 5;
+    s->adaptive_rho_interval = 25;
+    s->verbose = 0;
+}
+
+const char *sqph_global_error(void) { return g_err.c_str(); }
+const char *sqph_last_error(const sqph_solver *s) { return s ? s->err.c_str() : g_err.c_str(); }
+const char *sqph_kernel_name(const sqph_solver *s) { return s ? s->kernel_name : "none"; }
+
+long long sqph_algorithmic_bytes(int n, int m, int dtype) {
+    const long long e = (long long)dsize(dtype);
+    return e * ((long long)n * n + n + (long long)m * n + 2LL * m) + e * ((long long)n + m) + (long long)sizeof(sqph_info);
+}
+
+int sqph_constr_type_init(int dtype, int m, const void *l, const void *u, int *out) {
+    // static QPSolver::constr_type_init, /root/reference/src/qp.cpp:283-294
+    if (m < 0 || (m > 0 && (!l || !u || !out))) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "constr_type_init: null argument");
+    for (int i = 0; i < m; i++) {
+        if (dtype == SQPH_F32) {
+            const float li = ((const float *)l)[i], ui = ((const float *)u)[i];
+            out[i] = (li < -1e16f && ui > 1e16f) ? SQPH_LOOSE_BOUNDS
+                     : (ui - li < 1e-4f)        ? SQPH_EQUALITY_CONSTRAINT
+                                                : SQPH_INEQUALITY_CONSTRAINT;
+        } else {
+            const double li = ((const double *)l)[i], ui = ((const double *)u)[i];
+            out[i] = (li < -1e16 && ui > 1e16) ? SQPH_LOOSE_BOUNDS
+                     : (ui - li < 1e-4)       ? SQPH_EQUALITY_CONSTRAINT
+                                              : SQPH_INEQUALITY_CONSTRAINT;
+        }
+    }
+    return SQPH_OK;
+}
+
+int sqph_create(sqph_solver **out, int device, int n, int m, int batch_capacity, int dtype, int flags) {
+    if (!out) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_create: out is null");
+    *out = nullptr;
+    if (n <= 0 || m < 0 || batch_capacity <= 0) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_create: bad shape n=%d m=%d batch=%d", n, m, batch_capacity);
+    if (dtype != SQPH_F64 && dtype != SQPH_F32) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_create: bad dtype %d", dtype);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_NO_DEVICE, "sqph_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_create: device %d out of range (%d devices)", device, ndev);
+
+    sqph_solver *s = new (std::nothrow) sqph_solver();
+    if (!s) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_create: out of host memory");
+    s->device = device;
+    s->n = n;
+    s->m = m;
+    s->cap = batch_capacity;
+    s->dtype = dtype;
+    s->flags = flags;
+    sqph_default_settings(&s->settings);
+
+    DeviceGuard g(device);
+    const size_t e = dsize(dtype), B = (size_t)batch_capacity;
+    const size_t mm = (size_t)(m > 0 ? m : 1);
+    hipError_t err = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (err == hipSuccess) err = hipMalloc(p, bytes);
+        if (err == hipSuccess) err = hipMemset(*p, 0, bytes);
+    };
+    alloc(&s->x, B * n * e);
+    alloc(&s->z, B * mm * e);
+    alloc(&s->y, B * mm * e);
+    alloc(&s->rho_vec, B * mm * e);
+    alloc(&s->rho, B * e);
+    alloc((void **)&s->ctype, B * mm * sizeof(int));
+    alloc((void **)&s->info, B * sizeof(sqph_info));
+    alloc(&s->Sinv, B * (size_t)n * n * e);
+    if (err == hipSuccess) {
+        // every instance starts UNINITIALIZED (qp.hpp:74): status field = 4, rest 0
+        sqph_info *h = new (std::nothrow) sqph_info[B];
+        if (h) {
+            memset(h, 0, B * sizeof(sqph_info));
+            for (size_t i = 0; i < B; i++) h[i].status = SQPH_UNINITIALIZED;
+            err = hipMemcpy(s->info, h, B * sizeof(sqph_info), hipMemcpyHostToDevice);
+            delete[] h;
+        }
+    }
+    if (err != hipSuccess) {
+        g_err = std::string("sqph_create: device allocation failed: ") + hipGetErrorString(err);
+        sqph_destroy(s);
+        return SQPH_ERR_HIP;
+    }
+    *out = s;
+    return SQPH_OK;
+}
+
+void sqph_destroy(sqph_solver *s) {
+    if (!s) return;
+    DeviceGuard g(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    else (void)hipDeviceSynchronize();
+    void *ptrs[] = {s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &p : s->evs) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    delete s;
+}
+
+int sqph_set_stream(sqph_solver *s, void *hip_stream) {
+    if (!s) return SQPH_ERR_INVALID;
+    s->stream = (hipStream_t)hip_stream;
+    return SQPH_OK;
+}
+
+int sqph_set_settings(sqph_solver *s, const sqph_settings *st) {
+    if (!s || !st) return SQPH_ERR_INVALID;
+    if (!(st->rho > 0) || !(st->sigma > 0) || !(st->alpha > 0 && st->alpha < 2) || st->max_iter < 0 ||
+        st->check_termination < 0 || (st->adaptive_rho && st->adaptive_rho_interval <= 0))
+        SQPH_FAIL(s, SQPH_ERR_INVALID, "sqph_set_settings: out-of-range setting (rho,sigma>0; 0<alpha<2; max_iter,check_termination>=0; adaptive_rho_interval>0)");
+    s->settings = *st;
+    return SQPH_OK;
+}
+
+int sqph_get_settings(const sqph_solver *s, sqph_settings *st) {
+    if (!s || !st) return SQPH_ERR_INVALID;
+    *st = s->settings;
+    return SQPH_OK;
+}
+
+int sqph_enable_timing(sqph_solver *s, int on) {
+    if (!s) return SQPH_ERR_INVALID;
+    s->timing = on != 0;
+    s->ev_used = 0;
+    return SQPH_OK;
+}
+
+int sqph_last_kernel_ms(sqph_solver *s, float *ms) {
+    if (!s || !ms) return SQPH_ERR_INVALID;
+    if (!s->timing || s->ev_used == 0) SQPH_FAIL(s, SQPH_ERR_INVALID, "sqph_last_kernel_ms: timing not enabled or nothing launched");
+    DeviceGuard g(s->device);
+    auto &p = s->evs[s->ev_used - 1];
+    SQPH_HIP(s, hipEventSynchronize(p.second));
+    SQPH_HIP(s, hipEventElapsedTime(ms, p.first, p.second));
+    return SQPH_OK;
+}
+
+int sqph_collect_kernel_ms(sqph_solver *s, float *ms, int cap, int *count) {
+    if (!s || !count) return SQPH_ERR_INVALID;
+    DeviceGuard g(s->device);
+    int k = 0;
+    for (size_t i = 0; i < s->ev_used; i++) {
+        auto &p = s->evs[i];
+        SQPH_HIP(s, hipEventSynchronize(p.second));
+        float t = 0;
+        SQPH_HIP(s, hipEventElapsedTime(&t, p.first, p.second));
+        if (ms && k < cap) ms[k] = t;
+        k++;
+    }
+    *count = k;
+    s->ev_used = 0;
+    return SQPH_OK;
+}
+
+int sqph_synchronize(sqph_solver *s) {
+    if (!s) return SQPH_ERR_INVALID;
+    DeviceGuard g(s->device);
+    SQPH_HIP(s, hipStreamSynchronize(s->stream));
+    return SQPH_OK;
+}
+
+int sqph_device_state(sqph_solver *s, void **x, void **y, void **z, sqph_info **info) {
+    if (!s) return SQPH_ERR_INVALID;
+    if (x) *x = s->x;
+    if (y) *y = s->y;
+    if (z) *z = s->z;
+    if (info) *info = s->info;
+    return SQPH_OK;
+}
+
+int sqph_get_solution(sqph_solver *s, int batch, int memspace, void *x, void *y, void *z, sqph_info *info) {
+    if (!s) return SQPH_ERR_INVALID;
+    if (batch < 0 || batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "sqph_get_solution: batch %d exceeds capacity %d", batch, s->cap);
+    DeviceGuard g(s->device);
+    const size_t e = dsize(s->dtype), B = (size_t)batch;
+    const hipMemcpyKind kind = memspace == SQPH_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (x) SQPH_HIP(s, hipMemcpyAsync(x, s->x, B * s->n * e, kind, s->stream));
+    if (y && s->m) SQPH_HIP(s, hipMemcpyAsync(y, s->y, B * s->m * e, kind, s->stream));
+    if (z && s->m) SQPH_HIP(s, hipMemcpyAsync(z, s->z, B * s->m * e, kind, s->stream));
+    if (info) SQPH_HIP(s, hipMemcpyAsync(info, s->info, B * sizeof(sqph_info), kind, s->stream));
+    if (memspace == SQPH_HOST) SQPH_HIP(s, hipStreamSynchronize(s->stream));
+    return SQPH_OK;
+}
+
+int sqph_set_state(sqph_solver *s, int batch, int memspace, const void *x, const void *z, const void *y) {
+    if (!s) return SQPH_ERR_INVALID;
+    if (batch < 0 || batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "sqph_set_state: batch %d exceeds capacity %d", batch, s->cap);
+    DeviceGuard g(s->device);
+    const size_t e = dsize(s->dtype), B = (size_t)batch;
+    const hipMemcpyKind kind = memspace == SQPH_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (x) SQPH_HIP(s, hipMemcpyAsync(s->x, x, B * s->n * e, kind, s->stream));
+    if (z && s->m) SQPH_HIP(s, hipMemcpyAsync(s->z, z, B * s->m * e, kind, s->stream));
+    if (y && s->m) SQPH_HIP(s, hipMemcpyAsync(s->y, y, B * s->m * e, kind, s->stream));
+    if (memspace == SQPH_HOST) SQPH_HIP(s, hipStreamSynchronize(s->stream));
+    return SQPH_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <typename T>
+int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *P, const void *q, const void *A,
+                 const void *l, const void *u, long long sP, long long sq, long long sA, long long sl, long long su) {
+    using namespace sqph;
+    KArgs<T> a{};
+    a.n = s->n;
+    a.m = s->m;
+    a.batch = qp->batch;
+    a.mode = mode | ((s->flags & SQPH_FLAG_LEGACY_COLD_START) ? MODE_COLD_RESET : 0);
+    a.P = (const T *)P; a.q = (const T *)q; a.A = (const T *)A; a.l = (const T *)l; a.u = (const T *)u;
+    a.sP = sP; a.sq = sq; a.sA = sA; a.sl = sl; a.su = su;
+    a.x = (T *)s->x; a.z = (T *)s->z; a.y = (T *)s->y; a.rho_vec = (T *)s->rho_vec; a.ctype = s->ctype;
+    a.rho = (T *)s->rho; a.info = s->info; a.Sinv = (T *)s->Sinv;
+    const sqph_settings &st = s->settings;
+    a.rho0 = (T)st.rho; a.sigma = (T)st.sigma; a.alpha = (T)st.alpha; a.eps_rel = (T)st.eps_rel; a.eps_abs = (T)st.eps_abs;
+    a.rho_tol = (T)st.adaptive_rho_tolerance;
+    a.max_iter = st.max_iter; a.check_termination = st.check_termination; a.warm_start = st.warm_start;
+    a.adaptive_rho = st.adaptive_rho; a.adaptive_rho_interval = st.adaptive_rho_interval;
+
+    if (s->timing) {
+        if (s->ev_used == s->evs.size()) {
+            hipEvent_t e0, e1;
+            SQPH_HIP(s, hipEventCreate(&e0));
+            SQPH_HIP(s, hipEventCreate(&e1));
+            s->evs.emplace_back(e0, e1);
+        }
+        SQPH_HIP(s, hipEventRecord(s->evs[s->ev_used].first, s->stream));
+    }
+
+    bool launched = false;
+    if (!(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
+        int rc = tile_try_launch<T>(a, s->stream, &s->kernel_name);
+        if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "tiled kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        launched = rc > 0;
+    }
+    if (!launched) {
+        if (!s->At) {
+            const size_t bytes = (size_t)s->cap * (size_t)(s->m > 0 ? s->m : 1) * s->n * sizeof(T);
+            SQPH_HIP(s, hipMalloc(&s->At, bytes));
+        }
+        a.At = (T *)s->At;
+        const int big = s->n > s->m ? s->n : s->m;
+        const int nt = big <= 128 ? 64 : 256;
+        const size_t lds = generic_lds_elems<T>(s->n, s->m, nt) * sizeof(T);
+        if (lds > 160 * 1024) SQPH_FAIL(s, SQPH_ERR_UNSUPPORTED, "n=%d m=%d needs %zu B of LDS (>160 KiB)", s->n, s->m, lds);
+        if (lds > 64 * 1024)
+            SQPH_HIP(s, hipFuncSetAttribute((const void *)admm_generic_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(admm_generic_kernel<T>, dim3(qp->batch), dim3(nt), lds, s->stream, a);
+        SQPH_HIP(s, hipGetLastError());
+        s->kernel_name = nt == 64 ? "generic_w1" : "generic_w4";
+    }
+    if (s->timing) {
+        SQPH_HIP(s, hipEventRecord(s->evs[s->ev_used].second, s->stream));
+        s->ev_used++;
+    }
+    return SQPH_OK;
+}
+
+int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what) {
+    if (!s) return SQPH_ERR_INVALID;
+    if (!qp) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: qp is null", what);
+    if (qp->batch < 0 || qp->batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: batch %d exceeds capacity %d", what, qp->batch, s->cap);
+    if (qp->batch == 0) return SQPH_OK;
+    if (!qp->P || !qp->q || (s->m > 0 && (!qp->A || !qp->l || !qp->u))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null problem pointer", what);
+    if (qp->stride_P < 0 || qp->stride_q < 0 || qp->stride_A < 0 || qp->stride_l < 0 || qp->stride_u < 0)
+        SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: negative stride", what);
+    if (qp->memspace != SQPH_HOST && qp->memspace != SQPH_DEVICE) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: bad memspace %d", what, qp->memspace);
+
+    DeviceGuard g(s->device);
+    const void *P = qp->P, *q = qp->q, *A = qp->A, *l = qp->l, *u = qp->u;
+    long long sP = qp->stride_P, sq = qp->stride_q, sA = qp->stride_A, sl = qp->stride_l, su = qp->stride_u;
+    const size_t e = dsize(s->dtype);
+    const size_t n = s->n, m = s->m;
+    if (qp->memspace == SQPH_HOST) {
+        // stage host data: one H2D per array into packed device buffers owned by the solver
+        struct Item { const void *src; void **dst; size_t elems; long long *stride; };
+        Item items[5] = {{qp->P, &s->sP, n * n, &sP}, {qp->q, &s->sq, n, &sq}, {qp->A, &s->sA, m * n, &sA},
+                         {qp->l, &s->sl, m, &sl}, {qp->u, &s->su, m, &su}};
+        for (auto &it : items) {
+            if (it.elems == 0) continue;
+            if (!*it.dst) SQPH_HIP(s, hipMalloc(it.dst, (size_t)s->cap * it.elems * e));
+            if (*it.stride == 0) {
+                SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, it.elems * e, hipMemcpyHostToDevice, s->stream));
+            } else if ((size_t)*it.stride == it.elems) {
+                SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, (size_t)qp->batch * it.elems * e, hipMemcpyHostToDevice, s->stream));
+            } else {
+                SQPH_HIP(s, hipMemcpy2DAsync(*it.dst, it.elems * e, it.src, (size_t)*it.stride * e, it.elems * e, (size_t)qp->batch,
+                                             hipMemcpyHostToDevice, s->stream));
+                *it.stride = (long long)it.elems;
+            }
+        }
+        P = s->sP; q = s->sq; A = s->sA; l = s->sl; u = s->su;
+        // pageable host memory: the async copies above have already consumed the caller's buffers
+        // only after the stream reaches them; make the borrow end with the call.
+        SQPH_HIP(s, hipStreamSynchronize(s->stream));
+    }
+    if (s->dtype == SQPH_F32) return launch_typed<float>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su);
+    return launch_typed<double>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su);
+}
+
+}  // namespace
+
+extern "C" {
+int sqph_setup(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_SETUP, "sqph_setup"); }
+int sqph_update_qp(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_UPDATE, "sqph_update_qp"); }
+int sqph_solve(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_SOLVE, "sqph_solve"); }
+int sqph_setup_solve(sqph_solver *s, const sqph_qp_batch *qp) {
+    return run(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE, "sqph_setup_solve");
+}
+}

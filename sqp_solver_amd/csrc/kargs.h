@@ -1,0 +1,36 @@
+// Kernel argument block shared by every ADMM kernel variant (host + device).
+#pragma once
+#include "../../include/sqp_hip.h"
+
+namespace sqph {
+
+enum : int {
+    MODE_SETUP = 1,       // QPSolver::setup   (src/qp.cpp:11-44): zero x,z,y; classify; rho; factor
+    MODE_UPDATE = 2,      // QPSolver::update_qp (src/qp.cpp:46-62): classify; rho; factor; keep x,z,y
+    MODE_SOLVE = 4,       // QPSolver::solve   (src/qp.cpp:64-157)
+    MODE_COLD_RESET = 8,  // legacy class: solve() zeroes x,z,y when !warm_start (unsupported/qp_solver.hpp:256-260)
+};
+
+template <typename T>
+struct KArgs {
+    int n, m, batch, mode;
+    // borrowed problem data (device pointers), per-QP column-major, element strides (0 = shared)
+    const T *P, *q, *A, *l, *u;
+    long long sP, sq, sA, sl, su;
+    // persistent per-QP solver state, QP-major
+    T *x;         // [batch][n]
+    T *z;         // [batch][m]
+    T *y;         // [batch][m]
+    T *rho_vec;   // [batch][m]
+    int *ctype;   // [batch][m]
+    T *rho;       // [batch]      current scalar rho (QPSolver::rho, qp.hpp:228)
+    sqph_info *info;  // [batch]
+    // factor workspace
+    T *Sinv;      // [batch][n*n]  inverse of S = P + sigma I + A' diag(rho) A
+    T *At;        // [batch][m*n]  row-major copy of A (generic kernel only; may be null for tiled kernels)
+    // settings converted to Scalar
+    T rho0, sigma, alpha, eps_rel, eps_abs, rho_tol;
+    int max_iter, check_termination, warm_start, adaptive_rho, adaptive_rho_interval;
+};
+
+}  // namespace sqph

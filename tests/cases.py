@@ -1,0 +1,362 @@
+"""Backend-agnostic test bodies.
+
+Each function takes `make(n, m, batch, dtype=..., **kw)` returning an object with the
+QPSolverBatch surface (settings, setup/update_qp/solve/setup_solve, solution(), set_state).
+They are run (a) against the host SIMT emulation of the HIP kernels on CPU (`-m "not gpu"`),
+and (b) against the real kernels through the C-ABI on an MI355X (`-m gpu`).
+The first group restates the reference's own GTest cases (file:line cited per function).
+"""
+import numpy as np
+
+import oracle
+from sqp_solver_amd.problems import SIMPLE_QP as S, random_qp_batch
+
+SOLVED, MAX_ITER_EXCEEDED, UNSOLVED, NUMERICAL_ISSUES, UNINITIALIZED = range(5)
+
+# parity bar (north_star): primal/dual within 1e-6 relative of the fp64 reference path
+TOL_F64 = 1e-6
+# QPSolver<float>: compared against the *float* oracle; both are O(eps_f32 * cond) apart
+TOL_F32 = 5e-3
+
+
+def simple(batch=1, dtype=np.float64):
+    rep = lambda a: np.repeat(np.asarray(a, dtype=dtype)[None], batch, axis=0)  # noqa: E731
+    return rep(S["P"]), rep(S["q"]), rep(S["A"]), rep(S["l"]), rep(S["u"])
+
+
+def is_approx(a, b, prec):
+    """Eigen's isApprox: ||a-b|| <= prec * min(||a||, ||b||)."""
+    return np.linalg.norm(a - b) <= prec * min(np.linalg.norm(a), np.linalg.norm(b))
+
+
+def relerr(a, b):
+    den = np.maximum(np.max(np.abs(b), axis=-1), 1e-300)
+    return float(np.max(np.max(np.abs(a - b), axis=-1) / den))
+
+
+def oracle_settings(st):
+    return oracle.default_settings(
+        rho=st.rho, sigma=st.sigma, alpha=st.alpha, eps_rel=st.eps_rel, eps_abs=st.eps_abs, max_iter=st.max_iter,
+        check_termination=st.check_termination, warm_start=st.warm_start, adaptive_rho=st.adaptive_rho,
+        adaptive_rho_tolerance=st.adaptive_rho_tolerance, adaptive_rho_interval=st.adaptive_rho_interval)
+
+
+# ----------------------------------------------------------------------------------------------
+# reference tests/qp_solver_test.cpp restated
+# ----------------------------------------------------------------------------------------------
+def ref_testSimpleQP(make):
+    """tests/qp_solver_test.cpp:43-56"""
+    s = make(2, 3, 1)
+    s.settings.max_iter = 1000
+    qp = simple()
+    s.setup(*qp)
+    s.solve(*qp)
+    x, y, z, info = s.solution()
+    assert is_approx(x[0], S["solution"], 1e-2)
+    assert info.iter[0] < s.settings.max_iter
+    assert info.status[0] == SOLVED
+    # pinned by the oracle (Appendix C of SURVEY.md): 125 iterations, one factorisation
+    assert info.iter[0] == 125 and info.rho_updates[0] == 1
+    assert np.allclose(y[0], S["dual"], atol=2e-2)
+
+
+def ref_testSinglePrecisionFloat(make):
+    """tests/qp_solver_test.cpp:58-69"""
+    s = make(2, 3, 1, dtype=np.float32)
+    qp = simple(dtype=np.float32)
+    s.setup(*qp)
+    s.solve(*qp)
+    x, y, z, info = s.solution()
+    assert x.dtype == np.float32
+    assert is_approx(x[0], S["solution"].astype(np.float32), 1e-2)
+    assert info.iter[0] < s.settings.max_iter
+    assert info.status[0] == SOLVED
+
+
+def ref_testConstraintViolation(make):
+    """tests/qp_solver_test.cpp:71-87"""
+    s = make(2, 3, 1)
+    s.settings.eps_rel = float(np.float32(1e-4))
+    s.settings.eps_abs = float(np.float32(1e-4))
+    qp = simple()
+    s.setup(*qp)
+    s.solve(*qp)
+    x = s.solution()[0][0]
+    lower = S["A"] @ x - S["l"]
+    upper = S["A"] @ x - S["u"]
+    assert lower.min() >= -1e-3
+    assert upper.max() <= 1e-3
+
+
+def ref_testAdaptiveRho(make):
+    """tests/qp_solver_test.cpp:89-100"""
+    s = make(2, 3, 1)
+    s.settings.adaptive_rho = 1
+    s.settings.adaptive_rho_interval = 10
+    qp = simple()
+    s.setup(*qp)
+    s.solve(*qp)
+    info = s.solution()[3]
+    assert info.status[0] == SOLVED
+    assert info.iter[0] == 25 and info.rho_updates[0] == 2  # oracle-pinned
+
+
+def ref_testAdaptiveRhoImprovesConvergence(make):
+    """tests/qp_solver_test.cpp:102-125 (the 2nd solve is warm-started: src/qp.cpp:78-82 is a no-op)"""
+    s = make(2, 3, 1)
+    s.settings.warm_start = 0
+    s.settings.max_iter = 1000
+    s.settings.rho = 0.1
+    s.settings.adaptive_rho = 0
+    qp = simple()
+    s.setup(*qp)
+    s.solve(*qp)
+    prev_iter = int(s.solution()[3].iter[0])
+    s.settings.adaptive_rho = 1
+    s.settings.adaptive_rho_interval = 10
+    s.solve(*qp)
+    info = s.solution()[3]
+    assert info.iter[0] < s.settings.max_iter
+    assert info.iter[0] < prev_iter
+    assert info.status[0] == SOLVED
+
+
+def ref_legacy_TestConstraint(make):
+    """tests/unsupported/qp_solver_test.cpp:135-166: classification through setup() on a 5x5 identity QP"""
+    s = make(5, 5, 1)
+    P = np.eye(5)[None]
+    q = -np.ones((1, 5))
+    A = np.eye(5)[None]
+    l = np.array([[-1e17, -101, -1e17, -1, 42]])
+    u = np.array([[1e17, 1e17, 123, 1, 42]])
+    s.setup(P, q, A, l, u)
+    info = s.solution()[3]
+    assert info.status[0] == UNSOLVED
+    o = oracle.QPSolver()
+    o.setup(P[0], q[0], A[0], l[0], u[0])
+    assert list(o.constr_type()) == [2, 0, 0, 0, 1]
+    # the device classification is observable through rho_vec: loose -> 1e-6, eq -> 1e3*rho, else rho
+    s.settings.max_iter = 50
+    s.settings.check_termination = 0
+    s.solve(P, q, A, l, u)
+    o.settings.max_iter = 50
+    o.settings.check_termination = 0
+    o.solve(P[0], q[0], A[0], l[0], u[0])
+    x, y, z, info = s.solution()
+    assert relerr(x, o.primal_solution()[None]) < TOL_F64
+    assert np.max(np.abs(y[0] - o.dual_solution())) <= TOL_F64 * max(1.0, np.max(np.abs(o.dual_solution())))
+
+
+def ref_sparse_testCanMultipleSolve(make):
+    """tests/qp_solver_sparse_test.cpp:68-78 (dense restatement; legacy cold-start semantics)"""
+    s = make(2, 3, 1, legacy_cold_start=True)
+    qp = simple()
+    s.setup(*qp)
+    s.solve(*qp)
+    assert s.solution()[3].status[0] == SOLVED
+    it1 = int(s.solution()[3].iter[0])
+    s.solve(*qp)
+    info = s.solution()[3]
+    assert info.status[0] == SOLVED
+    assert info.iter[0] == it1  # legacy class really resets x,z,y (unsupported/qp_solver.hpp:256-260)
+
+
+def ref_sparse_testCanUpdateQP(make):
+    """tests/qp_solver_sparse_test.cpp:80-98"""
+    s = make(2, 3, 1, legacy_cold_start=True)
+    qp = simple()
+    s.setup(*qp)
+    s.solve(*qp)
+    x, y, z, info = s.solution()
+    assert is_approx(x[0], S["solution"], 1e-2) and info.status[0] == SOLVED
+    P2 = np.eye(2)[None]
+    q2 = np.zeros((1, 2))
+    s.update_qp(P2, q2, qp[2], qp[3], qp[4])
+    s.solve(P2, q2, qp[2], qp[3], qp[4])
+    x, y, z, info = s.solution()
+    assert is_approx(x[0], np.array([0.5, 0.5]), 1e-2) and info.status[0] == SOLVED
+
+
+REFERENCE_CASES = [
+    ref_testSimpleQP, ref_testSinglePrecisionFloat, ref_testConstraintViolation, ref_testAdaptiveRho,
+    ref_testAdaptiveRhoImprovesConvergence, ref_legacy_TestConstraint, ref_sparse_testCanMultipleSolve,
+    ref_sparse_testCanUpdateQP,
+]
+
+
+# ----------------------------------------------------------------------------------------------
+# parity against the oracle on seeded random batches
+# ----------------------------------------------------------------------------------------------
+def parity_fixed_iters(make, n, m, batch, iters=200, seed=11, dtype=np.float64, alpha=1.0, tol=None, **kw):
+    """Iterates after a fixed number of ADMM iterations (check_termination=0): x, y, z within tol."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=seed, dtype=dtype)
+    s = make(n, m, batch, dtype=dtype, **kw)
+    s.settings.max_iter = iters
+    s.settings.check_termination = 0
+    s.settings.alpha = alpha
+    s.setup_solve(P, q, A, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle_settings(s.settings), dtype=dtype)
+    tol = tol or (TOL_F64 if np.dtype(dtype) == np.float64 else TOL_F32)
+    ex, ey, ez = relerr(x, xo), relerr(y, yo), relerr(z, zo)
+    assert ex < tol and ey < tol and ez < tol, (ex, ey, ez)
+    assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all()
+    assert (info.status == MAX_ITER_EXCEEDED).all() and (info.iter == iters + 1).all()  # qp.cpp:147-150
+    return ex, ey, ez
+
+
+def parity_termination(make, n, m, batch, seed=5, adaptive=False, sqp_settings=False, **kw):
+    """Default-termination solves: status / iteration count / residuals / solutions against the oracle."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=seed)
+    s = make(n, m, batch, **kw)
+    st = s.settings
+    if adaptive:
+        st.adaptive_rho = 1
+    if sqp_settings:  # SQP ctor, src/sqp.cpp:15-23
+        st.warm_start, st.check_termination, st.eps_abs, st.eps_rel = 1, 10, 1e-4, 1e-4
+        st.max_iter, st.adaptive_rho, st.adaptive_rho_interval, st.alpha = 100, 1, 50, 1.6
+    s.setup_solve(P, q, A, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle_settings(st))
+    # a termination test sits on a threshold: allow a QP to differ only if its oracle residual is
+    # within 1e-9 relative of its threshold (never observed; guards against a legitimate rounding flip)
+    same = (info.status == io["status"]) & (info.iter == io["iter"]) & (info.rho_updates == io["rho_updates"])
+    assert same.mean() == 1.0, np.nonzero(~same)
+    assert relerr(x, xo) < TOL_F64 and relerr(y, yo) < TOL_F64
+    # residuals are differences of O(1) vectors: compare with an absolute floor at rounding scale
+    assert np.allclose(info.res_prim, io["res_prim"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(info.res_dual, io["res_dual"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(info.rho_estimate, io["rho_estimate"], rtol=1e-6, atol=0)
+    return info
+
+
+def warm_start_and_resolve(make, n=8, m=12, batch=4, **kw):
+    """setup; solve; solve again with perturbed q,l,u (reference re-reads them from solve()'s argument,
+    src/qp.cpp:89,100,112) — iterates are retained between solves (src/qp.cpp:78-82)."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=3)
+    s = make(n, m, batch, **kw)
+    s.settings.max_iter = 40
+    s.settings.check_termination = 0
+    s.setup(P, q, A, l, u)
+    s.solve(P, q, A, l, u)
+    q2 = q + 0.1
+    l2, u2 = l - 0.05, u + 0.05
+    s.solve(P, q2, A, l2, u2)
+    x, y, z, info = s.solution()
+    xs, ys = [], []
+    for b in range(batch):
+        o = oracle.QPSolver()
+        o.settings.max_iter = 40
+        o.settings.check_termination = 0
+        o.setup(P[b], q[b], A[b], l[b], u[b])
+        o.solve(P[b], q[b], A[b], l[b], u[b])
+        o.solve(P[b], q2[b], A[b], l2[b], u2[b])
+        xs.append(o.primal_solution())
+        ys.append(o.dual_solution())
+        assert o.info.rho_updates == info.rho_updates[b] == 1
+    assert relerr(x, np.array(xs)) < TOL_F64 and relerr(y, np.array(ys)) < TOL_F64
+
+
+def set_state_warm_start(make, n=6, m=9, batch=3, **kw):
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=9)
+    rng = np.random.default_rng(0)
+    x0, z0, y0 = rng.standard_normal((batch, n)), rng.standard_normal((batch, m)), rng.standard_normal((batch, m))
+    s = make(n, m, batch, **kw)
+    s.settings.max_iter = 30
+    s.settings.check_termination = 0
+    s.setup(P, q, A, l, u)
+    s.set_state(x0, z0, y0)
+    s.solve(P, q, A, l, u)
+    x, y, z, info = s.solution()
+    for b in range(batch):
+        o = oracle.QPSolver()
+        o.settings.max_iter = 30
+        o.settings.check_termination = 0
+        o.setup(P[b], q[b], A[b], l[b], u[b])
+        o.set_state(x0[b], z0[b], y0[b])
+        o.solve(P[b], q[b], A[b], l[b], u[b])
+        assert relerr(x[b][None], o.primal_solution()[None]) < TOL_F64
+        assert relerr(y[b][None], o.dual_solution()[None]) < TOL_F64
+
+
+def uninitialized_and_numerical_issues(make, n=4, m=5, batch=3, **kw):
+    """solve() before setup() is a no-op (qp.cpp:68-71); a NaN problem is flagged NUMERICAL_ISSUES for that QP only."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=2)
+    s = make(n, m, batch, **kw)
+    s.solve(P, q, A, l, u)
+    x, y, z, info = s.solution()
+    assert (info.status == UNINITIALIZED).all() and (info.iter == 0).all() and (x == 0).all()
+    Pb = P.copy()
+    Pb[1, 0, 0] = np.nan
+    s.settings.max_iter = 20
+    s.setup_solve(Pb, q, A, l, u)
+    x, y, z, info = s.solution()
+    assert info.status[1] == NUMERICAL_ISSUES and info.iter[1] == 0
+    o = oracle.QPSolver()
+    o.setup(Pb[1], q[1], A[1], l[1], u[1])
+    assert o.info.status == NUMERICAL_ISSUES
+    for b in (0, 2):
+        ob = oracle.QPSolver()
+        ob.settings.max_iter = 20
+        ob.setup(P[b], q[b], A[b], l[b], u[b])
+        ob.solve(P[b], q[b], A[b], l[b], u[b])
+        assert info.status[b] == ob.info.status and info.iter[b] == ob.info.iter
+        assert relerr(x[b][None], ob.primal_solution()[None]) < TOL_F64
+
+
+def shared_matrices(make, n=6, m=8, batch=5, **kw):
+    """stride 0: one P/A shared by the whole batch, per-QP q,l,u (MPC-style)."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=4)
+    s = make(n, m, batch, **kw)
+    s.settings.max_iter = 60
+    s.settings.check_termination = 0
+    s.setup_solve(P[0], q, A[0], l, u)
+    x, y, z, info = s.solution()
+    Pr, Ar = np.repeat(P[:1], batch, 0), np.repeat(A[:1], batch, 0)
+    xo, yo, zo, io = oracle.solve_batch(Pr, q, Ar, l, u, oracle_settings(s.settings))
+    assert relerr(x, xo) < TOL_F64 and relerr(y, yo) < TOL_F64
+
+
+def edge_shapes(make, **kw):
+    """n=1; m=0 (unconstrained); m=1; all-equality; all-loose."""
+    for (n, m) in ((1, 1), (3, 0), (4, 1), (7, 3)):
+        P, q, A, l, u = random_qp_batch(2, n, m, seed=n * 10 + m, plain=True)
+        s = make(n, m, 2, **kw)
+        s.settings.max_iter = 50
+        s.settings.check_termination = 0
+        if m == 0:
+            s.setup_solve(P, q, None, None, None)
+            x = s.solution()[0]
+            xo = np.stack([np.linalg.solve(P[b], -q[b]) for b in range(2)])
+            # sigma-regularised fixed point iteration converges to P^-1(-q) geometrically
+            assert relerr(x, xo) < 1e-3
+            continue
+        s.setup_solve(P, q, A, l, u)
+        x, y, z, info = s.solution()
+        xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle_settings(s.settings))
+        assert relerr(x, xo) < TOL_F64 and relerr(y, yo) < 1e-5
+    n, m = 5, 4
+    P, q, A, l, u = random_qp_batch(2, n, m, seed=77, plain=True)
+    for (ll, uu) in ((l, l.copy()), (np.full_like(l, -1e20), np.full_like(u, 1e20)), (np.full_like(l, -np.inf), np.full_like(u, np.inf))):
+        s = make(n, m, 2, **kw)
+        s.settings.max_iter = 50
+        s.settings.check_termination = 0
+        s.setup_solve(P, q, A, ll, uu)
+        x, y, z, info = s.solution()
+        xo, yo, zo, io = oracle.solve_batch(P, q, A, ll, uu, oracle_settings(s.settings))
+        assert relerr(x, xo) < TOL_F64
+        assert np.max(np.abs(y - yo)) <= 1e-6 * max(1.0, np.max(np.abs(yo)))
+
+
+def kkt_property(x, y, z, P, q, A, l, u, eps_abs, eps_rel):
+    """Size-independent property: every SOLVED QP satisfies the reference's termination test
+    (src/qp.cpp:343-371) when the residuals are recomputed independently in numpy."""
+    Ax = np.einsum("bij,bj->bi", A, x)
+    Px = np.einsum("bij,bj->bi", P, x)
+    ATy = np.einsum("bij,bi->bj", A, y)
+    rp = np.max(np.abs(Ax - z), axis=1) if A.shape[1] else np.zeros(len(x))
+    rd = np.max(np.abs(Px + q + ATy), axis=1)
+    nz = lambda a: np.max(np.abs(a), axis=1) if a.shape[1] else np.zeros(len(x))  # noqa: E731
+    ep = eps_abs + eps_rel * np.maximum(nz(Ax), nz(z))
+    ed = eps_abs + eps_rel * np.maximum(nz(Px), np.maximum(nz(ATy), nz(q)))
+    return rp, rd, ep, ed

@@ -1,0 +1,170 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+//
+// Minimal host-side SIMT emulator so the HIP kernels under sqp_solver_amd/csrc/ can be
+// executed lane-for-lane on a machine without a GPU (the build container has none).
+// Every work-item of a workgroup is a ucontext fiber; __syncthreads() and the cross-lane
+// primitives of wave_ops.h are rendezvous points handled by a round-robin scheduler, so
+// the emulated kernels see exactly the data-flow they see on a 64-wide wavefront.
+// Compiled only into tests/sim/libsqph_sim.so (see tests/sim/Makefile); the product
+// library never links or includes this file.
+#pragma once
+#define SQPH_SIM 1
+
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void *hipStream_t;
+
+namespace sqph_sim {
+
+struct Lane {
+    ucontext_t ctx;
+    std::vector<unsigned char> stack;
+    bool done = false;
+    int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier
+};
+
+struct Block {
+    std::vector<Lane> lanes;
+    ucontext_t sched;
+    int cur = -1;
+    std::vector<unsigned char> smem;
+    std::function<void()> body;
+    uint64_t xchg[1024];  // per-lane exchange slots for cross-lane ops
+};
+
+inline Block *&cur_block() {
+    static Block *b = nullptr;
+    return b;
+}
+
+inline dim3 &tls_threadIdx() { static dim3 v; return v; }
+inline dim3 &tls_blockIdx() { static dim3 v; return v; }
+inline dim3 &tls_blockDim() { static dim3 v; return v; }
+inline dim3 &tls_gridDim() { static dim3 v; return v; }
+
+inline unsigned char *dyn_smem() { return cur_block()->smem.data(); }
+
+inline void yield_wait(int kind) {
+    Block *b = cur_block();
+    Lane &l = b->lanes[b->cur];
+    l.wait = kind;
+    swapcontext(&l.ctx, &b->sched);
+}
+
+inline void fiber_entry() {
+    Block *b = cur_block();
+    b->body();
+    b->lanes[b->cur].done = true;
+    swapcontext(&b->lanes[b->cur].ctx, &b->sched);
+}
+
+// Run one workgroup of nthreads lanes.
+inline void run_block(unsigned nthreads, size_t smem_bytes, const std::function<void()> &body) {
+    Block blk;
+    blk.lanes.resize(nthreads);
+    blk.smem.assign(smem_bytes + 64, 0);
+    blk.body = body;
+    cur_block() = &blk;
+    const size_t STACK = 256 * 1024;
+    for (unsigned t = 0; t < nthreads; t++) {
+        Lane &l = blk.lanes[t];
+        l.stack.resize(STACK);
+        getcontext(&l.ctx);
+        l.ctx.uc_stack.ss_sp = l.stack.data();
+        l.ctx.uc_stack.ss_size = STACK;
+        l.ctx.uc_link = &blk.sched;
+        makecontext(&l.ctx, (void (*)())fiber_entry, 0);
+    }
+    for (;;) {
+        bool any_alive = false, ran = false;
+        for (unsigned t = 0; t < nthreads; t++) {
+            Lane &l = blk.lanes[t];
+            if (l.done) continue;
+            any_alive = true;
+            if (l.wait) continue;
+            blk.cur = (int)t;
+            tls_threadIdx() = dim3(t);
+            swapcontext(&blk.sched, &l.ctx);
+            ran = true;
+        }
+        if (!any_alive) break;
+        // release barriers whose participants (all not-done lanes of the group) have arrived
+        bool released = false;
+        bool all_block = true;
+        for (unsigned t = 0; t < nthreads; t++)
+            if (!blk.lanes[t].done && blk.lanes[t].wait != 1) all_block = false;
+        if (all_block) {
+            for (unsigned t = 0; t < nthreads; t++) blk.lanes[t].wait = 0;
+            released = true;
+        } else {
+            for (unsigned w = 0; w * 64 < nthreads; w++) {
+                bool all_wave = true, any = false;
+                for (unsigned t = w * 64; t < nthreads && t < (w + 1) * 64; t++) {
+                    if (blk.lanes[t].done) continue;
+                    any = true;
+                    if (blk.lanes[t].wait != 2) all_wave = false;
+                }
+                if (any && all_wave) {
+                    for (unsigned t = w * 64; t < nthreads && t < (w + 1) * 64; t++) blk.lanes[t].wait = 0;
+                    released = true;
+                }
+            }
+        }
+        if (!ran && !released) {
+            fprintf(stderr, "hip_sim: deadlock (divergent barrier / cross-lane op)\n");
+            abort();
+        }
+    }
+    cur_block() = nullptr;
+}
+
+template <typename K, typename A>
+inline void launch(K kernel, dim3 grid, dim3 block, size_t smem_bytes, A args) {
+    tls_gridDim() = grid;
+    tls_blockDim() = block;
+    for (unsigned bx = 0; bx < grid.x; bx++) {
+        tls_blockIdx() = dim3(bx);
+        run_block(block.x, smem_bytes, [&]() { kernel(args); });
+    }
+}
+
+// ---- cross-lane rendezvous: every live lane of the wave publishes v, then reads lane src ----
+inline uint64_t wave_exchange(uint64_t v, int src_lane_in_wave) {
+    Block *b = cur_block();
+    const int t = b->cur;
+    const int base = t & ~63;
+    b->xchg[t] = v;
+    yield_wait(2);
+    int s = base + (src_lane_in_wave & 63);
+    uint64_t r = (s < (int)b->lanes.size()) ? b->xchg[s] : 0;
+    yield_wait(2);
+    return r;
+}
+
+}  // namespace sqph_sim
+
+#define threadIdx (::sqph_sim::tls_threadIdx())
+#define blockIdx (::sqph_sim::tls_blockIdx())
+#define blockDim (::sqph_sim::tls_blockDim())
+#define gridDim (::sqph_sim::tls_gridDim())
+
+inline void __syncthreads() { ::sqph_sim::yield_wait(1); }

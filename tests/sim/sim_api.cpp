@@ -1,0 +1,60 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+// Runs the product's HIP kernels (sqp_solver_amd/csrc/*.h) under the host SIMT emulator so the
+// CPU-only unit tests can compare kernel logic with the oracle. Built into libsqph_sim.so.
+#include "hip_sim.h"
+// kernels (device code only; host launch code lives in capi.hip and is not compiled here)
+#include "../../sqp_solver_amd/csrc/admm_generic.h"
+#include "../../sqp_solver_amd/csrc/admm_tile_kernel.h"
+
+extern "C" {
+
+// Flat mirror of sqph::KArgs with host pointers and double-typed settings.
+struct SimArgs {
+    int n, m, batch, mode;
+    const void *P, *q, *A, *l, *u;
+    long long sP, sq, sA, sl, su;
+    void *x, *z, *y, *rho_vec;
+    int *ctype;
+    void *rho;
+    sqph_info *info;
+    void *Sinv, *At;
+    double rho0, sigma, alpha, eps_rel, eps_abs, rho_tol;
+    int max_iter, check_termination, warm_start, adaptive_rho, adaptive_rho_interval;
+};
+
+}  // extern "C"
+
+namespace {
+template <typename T>
+sqph::KArgs<T> convert(const SimArgs &s) {
+    sqph::KArgs<T> a{};
+    a.n = s.n; a.m = s.m; a.batch = s.batch; a.mode = s.mode;
+    a.P = (const T *)s.P; a.q = (const T *)s.q; a.A = (const T *)s.A; a.l = (const T *)s.l; a.u = (const T *)s.u;
+    a.sP = s.sP; a.sq = s.sq; a.sA = s.sA; a.sl = s.sl; a.su = s.su;
+    a.x = (T *)s.x; a.z = (T *)s.z; a.y = (T *)s.y; a.rho_vec = (T *)s.rho_vec; a.ctype = s.ctype;
+    a.rho = (T *)s.rho; a.info = s.info; a.Sinv = (T *)s.Sinv; a.At = (T *)s.At;
+    a.rho0 = (T)s.rho0; a.sigma = (T)s.sigma; a.alpha = (T)s.alpha; a.eps_rel = (T)s.eps_rel; a.eps_abs = (T)s.eps_abs;
+    a.rho_tol = (T)s.rho_tol;
+    a.max_iter = s.max_iter; a.check_termination = s.check_termination; a.warm_start = s.warm_start;
+    a.adaptive_rho = s.adaptive_rho; a.adaptive_rho_interval = s.adaptive_rho_interval;
+    return a;
+}
+
+template <typename T>
+int run_generic(const SimArgs &s, int nt) {
+    auto a = convert<T>(s);
+    const size_t lds = sqph::generic_lds_elems<T>(s.n, s.m, nt) * sizeof(T);
+    sqph_sim::launch(sqph::admm_generic_kernel<T>, dim3(s.batch), dim3(nt), lds, a);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+// variant: 0 = generic (nt threads per QP); 1 = register-tiled wave-per-QP
+int sim_run(const SimArgs *s, int variant, int dtype, int nt) {
+    if (variant == 0) return dtype == SQPH_F32 ? run_generic<float>(*s, nt) : run_generic<double>(*s, nt);
+    if (variant == 1) return dtype == SQPH_F32 ? sqph::sim_run_tile<float>(convert<float>(*s)) : sqph::sim_run_tile<double>(convert<double>(*s));
+    return -1;
+}
+}

@@ -1,0 +1,137 @@
+"""TEST INFRASTRUCTURE: drive the product's HIP kernels under the host SIMT emulator (tests/sim/)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from sqp_solver_amd import _capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SIMDIR = os.path.join(HERE, "sim")
+LIB = os.path.join(SIMDIR, "libsqph_sim.so")
+
+MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET = 1, 2, 4, 8
+GENERIC, TILE = 0, 1
+
+
+class SimArgs(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int), ("m", ctypes.c_int), ("batch", ctypes.c_int), ("mode", ctypes.c_int),
+        ("P", ctypes.c_void_p), ("q", ctypes.c_void_p), ("A", ctypes.c_void_p), ("l", ctypes.c_void_p), ("u", ctypes.c_void_p),
+        ("sP", ctypes.c_longlong), ("sq", ctypes.c_longlong), ("sA", ctypes.c_longlong), ("sl", ctypes.c_longlong), ("su", ctypes.c_longlong),
+        ("x", ctypes.c_void_p), ("z", ctypes.c_void_p), ("y", ctypes.c_void_p), ("rho_vec", ctypes.c_void_p),
+        ("ctype", ctypes.c_void_p), ("rho", ctypes.c_void_p), ("info", ctypes.c_void_p),
+        ("Sinv", ctypes.c_void_p), ("At", ctypes.c_void_p),
+        ("rho0", ctypes.c_double), ("sigma", ctypes.c_double), ("alpha", ctypes.c_double),
+        ("eps_rel", ctypes.c_double), ("eps_abs", ctypes.c_double), ("rho_tol", ctypes.c_double),
+        ("max_iter", ctypes.c_int), ("check_termination", ctypes.c_int), ("warm_start", ctypes.c_int),
+        ("adaptive_rho", ctypes.c_int), ("adaptive_rho_interval", ctypes.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", SIMDIR, "-s"])
+        _lib = ctypes.CDLL(LIB)
+        _lib.sim_run.argtypes = [ctypes.POINTER(SimArgs), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _lib.sim_run.restype = ctypes.c_int
+    return _lib
+
+
+class SimSolverBatch:
+    """Same surface as sqp_solver_amd.QPSolverBatch, executed by the emulator (host arrays)."""
+
+    def __init__(self, n, m, batch, dtype=np.float64, variant=GENERIC, nt=64, legacy_cold_start=False):
+        self.n, self.m, self.batch = n, m, batch
+        self.dtype = np.dtype(dtype)
+        self.variant, self.nt = variant, nt
+        self.legacy = legacy_cold_start
+        self.settings = _capi.Settings()
+        s = self.settings
+        s.rho, s.sigma, s.alpha, s.eps_rel, s.eps_abs = 0.1, 1e-6, 1.0, 1e-3, 1e-3
+        s.max_iter, s.check_termination, s.warm_start, s.adaptive_rho = 1000, 25, 0, 0
+        s.adaptive_rho_tolerance, s.adaptive_rho_interval, s.verbose = 5, 25, 0
+        mm = max(m, 1)
+        self.x = np.zeros((batch, n), self.dtype)
+        self.zv = np.zeros((batch, mm), self.dtype)
+        self.y = np.zeros((batch, mm), self.dtype)
+        self.rho_vec = np.zeros((batch, mm), self.dtype)
+        self.ctype = np.zeros((batch, mm), np.int32)
+        self.rho = np.zeros(batch, self.dtype)
+        self.info_arr = np.zeros(batch, _capi.INFO_DTYPE)
+        self.info_arr["status"] = 4
+        self.Sinv = np.zeros((batch, n * n), self.dtype)
+        self.At = np.zeros((batch, mm * n), self.dtype)
+
+    def _run(self, mode, P, q, A, l, u):
+        n, m = self.n, self.m
+        if m == 0:
+            B0 = np.asarray(P).shape[0] if np.asarray(P).ndim == 3 else self.batch
+            A = np.zeros((B0, 0, n)) if A is None else A
+            l = np.zeros((B0, 0)) if l is None else l
+            u = np.zeros((B0, 0)) if u is None else u
+        P = np.ascontiguousarray(np.swapaxes(np.asarray(P, self.dtype), -1, -2))
+        A = np.ascontiguousarray(np.swapaxes(np.asarray(A, self.dtype), -1, -2))
+        q = np.ascontiguousarray(q, self.dtype)
+        l = np.ascontiguousarray(l, self.dtype)
+        u = np.ascontiguousarray(u, self.dtype)
+        B = P.shape[0] if P.ndim == 3 else self.batch
+        a = SimArgs()
+        a.n, a.m, a.batch = n, m, B
+        a.mode = mode | (MODE_COLD_RESET if self.legacy else 0)
+        for name, arr, per in (("P", P, n * n), ("q", q, n), ("A", A, m * n), ("l", l, m), ("u", u, m)):
+            setattr(a, name, arr.ctypes.data)
+            shared = arr.ndim == (2 if name in ("P", "A") else 1)
+            setattr(a, "s" + name, 0 if shared else per)
+        a.x, a.z, a.y = self.x.ctypes.data, self.zv.ctypes.data, self.y.ctypes.data
+        a.rho_vec, a.ctype, a.rho = self.rho_vec.ctypes.data, self.ctype.ctypes.data, self.rho.ctypes.data
+        a.info, a.Sinv, a.At = self.info_arr.ctypes.data, self.Sinv.ctypes.data, self.At.ctypes.data
+        s = self.settings
+        a.rho0, a.sigma, a.alpha, a.eps_rel, a.eps_abs = s.rho, s.sigma, s.alpha, s.eps_rel, s.eps_abs
+        a.rho_tol = s.adaptive_rho_tolerance
+        a.max_iter, a.check_termination, a.warm_start = s.max_iter, s.check_termination, s.warm_start
+        a.adaptive_rho, a.adaptive_rho_interval = s.adaptive_rho, s.adaptive_rho_interval
+        rc = lib().sim_run(ctypes.byref(a), self.variant, 1 if self.dtype == np.float32 else 0, self.nt)
+        if rc != 0:
+            raise RuntimeError("sim_run failed rc=%d" % rc)
+        self._last = B
+
+    def setup(self, P, q, A, l, u):
+        self._run(MODE_SETUP, P, q, A, l, u)
+
+    def update_qp(self, P, q, A, l, u):
+        self._run(MODE_UPDATE, P, q, A, l, u)
+
+    def solve(self, P, q, A, l, u):
+        self._run(MODE_SOLVE, P, q, A, l, u)
+
+    def setup_solve(self, P, q, A, l, u):
+        self._run(MODE_SETUP | MODE_SOLVE, P, q, A, l, u)
+
+    def primal_solution(self):
+        return self.x[: self._last].copy()
+
+    def dual_solution(self):
+        return self.y[: self._last, : self.m].copy()
+
+    def z(self):
+        return self.zv[: self._last, : self.m].copy()
+
+    def info(self):
+        return self.info_arr[: self._last].copy().view(np.recarray)
+
+    def solution(self):
+        return self.primal_solution(), self.dual_solution(), self.z(), self.info()
+
+    def set_state(self, x=None, z=None, y=None):
+        if x is not None:
+            self.x[:] = x
+        if z is not None:
+            self.zv[:, : self.m] = z
+        if y is not None:
+            self.y[:, : self.m] = y

@@ -1,0 +1,150 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP kernels through the C-ABI
+(libsqp_hip.so via sqp_solver_amd.QPSolverBatch) against the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+
+import cases
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def make_gpu(n, m, batch, dtype=np.float64, legacy_cold_start=False, force_generic=False, **kw):
+    from sqp_solver_amd import QPSolverBatch
+
+    return QPSolverBatch(n, m, batch, dtype=dtype, device=0, legacy_cold_start=legacy_cold_start, force_generic=force_generic)
+
+
+def make_gpu_generic(n, m, batch, **kw):
+    return make_gpu(n, m, batch, force_generic=True, **kw)
+
+
+MAKERS = [make_gpu, make_gpu_generic]
+IDS = ["auto", "generic"]
+
+
+def test_native_library_is_what_runs():
+    import ctypes
+
+    from sqp_solver_amd import _capi
+
+    L = _capi.load()
+    assert isinstance(L, ctypes.CDLL) and L.sqph_version() == 1
+    s = make_gpu(2, 3, 1)
+    qp = cases.simple()
+    s.setup_solve(*qp)
+    assert s.kernel_name() != "none"
+
+
+@pytest.mark.parametrize("make", MAKERS, ids=IDS)
+@pytest.mark.parametrize("case", cases.REFERENCE_CASES, ids=lambda f: f.__name__)
+def test_reference_cases(case, make):
+    case(make)
+
+
+@pytest.mark.parametrize("make", MAKERS, ids=IDS)
+@pytest.mark.parametrize("n,m,batch,iters", [(2, 3, 7, 200), (20, 40, 128, 200), (50, 100, 64, 200), (13, 57, 16, 100), (56, 104, 8, 50), (64, 30, 8, 50)])
+def test_parity_fixed_iters(n, m, batch, iters, make):
+    cases.parity_fixed_iters(make, n, m, batch, iters=iters)
+
+
+@pytest.mark.parametrize("make", MAKERS, ids=IDS)
+def test_parity_fixed_alpha_and_float(make):
+    cases.parity_fixed_iters(make, 20, 40, 32, iters=100, alpha=1.6)
+    cases.parity_fixed_iters(make, 20, 40, 32, iters=100, dtype=np.float32)
+
+
+@pytest.mark.parametrize("make", MAKERS, ids=IDS)
+@pytest.mark.parametrize("kw", [dict(), dict(adaptive=True), dict(sqp_settings=True)], ids=["default", "adaptive", "sqp"])
+@pytest.mark.parametrize("n,m,batch", [(20, 40, 96), (50, 100, 48)])
+def test_parity_termination(n, m, batch, kw, make):
+    cases.parity_termination(make, n, m, batch, **kw)
+
+
+@pytest.mark.parametrize("make", MAKERS, ids=IDS)
+def test_state_paths(make):
+    cases.warm_start_and_resolve(make)
+    cases.set_state_warm_start(make)
+    cases.uninitialized_and_numerical_issues(make)
+    cases.shared_matrices(make)
+    cases.edge_shapes(make)
+
+
+def test_large_generic_shape():
+    """beyond the tiled kernels: n=120, m=260 takes the 4-wave generic kernel"""
+    cases.parity_fixed_iters(make_gpu, 120, 260, 4, iters=40)
+
+
+def test_golden_fixtures():
+    import golden_io
+
+    for name, g in golden_io.load_all():
+        s = make_gpu(g["n"], g["m"], g["P"].shape[0])
+        golden_io.apply_settings(s.settings, g)
+        s.setup_solve(g["P"], g["q"], g["A"], g["l"], g["u"])
+        x, y, z, info = s.solution()
+        assert cases.relerr(x, g["x"]) < cases.TOL_F64, name
+        assert np.max(np.abs(y - g["y"])) <= cases.TOL_F64 * max(1.0, np.max(np.abs(g["y"]))), name
+        assert (info.status == g["status"]).all() and (info.iter == g["iter"]).all(), name
+
+
+def test_full_size_properties_c3():
+    """BASELINE config 3 shard (8,192 x n=50,m=100), default termination: size-independent properties.
+    (1) every SOLVED QP passes the reference's termination test recomputed in numpy;
+    (2) a sample agrees with the oracle; (3) solving the reversed batch reverses the results bit-exactly
+    (QPs are independent: no cross-QP coupling in the kernel)."""
+    import torch
+
+    from sqp_solver_amd.problems import random_qp_batch_torch
+
+    B, n, m = 8192, 50, 100
+    P, q, A_cm, l, u = random_qp_batch_torch(B, n, m, seed=123)
+    s = make_gpu(n, m, B)
+    s.setup_solve(P, q, A_cm, l, u, colmajor=True)
+    x, y, z, info = s.solution()
+    assert np.isin(info.status, [0, 1]).all()
+    assert (info.status == 0).mean() > 0.95
+    Ph, qh = P.cpu().numpy().transpose(0, 2, 1), q.cpu().numpy()
+    Ah, lh, uh = A_cm.cpu().numpy().transpose(0, 2, 1), l.cpu().numpy(), u.cpu().numpy()
+    rp, rd, ep, ed = cases.kkt_property(x, y, z, Ph, qh, Ah, lh, uh, 1e-3, 1e-3)
+    ok = info.status == 0
+    assert (rp[ok] <= ep[ok] * (1 + 1e-9)).all() and (rd[ok] <= ed[ok] * (1 + 1e-9) + 1e-12).all()
+    assert ((z >= lh - 1e-12) & (z <= uh + 1e-12)).all()  # z is a projection onto [l,u]
+    k = 96
+    xo, yo, zo, io = oracle.solve_batch(Ph[:k], qh[:k], Ah[:k], lh[:k], uh[:k], oracle.default_settings())
+    assert cases.relerr(x[:k], xo) < cases.TOL_F64 and cases.relerr(y[:k], yo) < cases.TOL_F64
+    assert (info.status[:k] == io["status"]).all() and (info.iter[:k] == io["iter"]).all()
+    rev = lambda t: torch.flip(t, dims=[0]).contiguous()  # noqa: E731
+    s.setup_solve(rev(P), rev(q), rev(A_cm), rev(l), rev(u), colmajor=True)
+    x2, y2, z2, info2 = s.solution()
+    assert np.array_equal(x2[::-1], x) and np.array_equal(y2[::-1], y) and np.array_equal(info2.iter[::-1], info.iter)
+
+
+def test_full_size_fixed_iters_c2():
+    """BASELINE config 2: 4,096 x (n=20, m=40), 200 ADMM iterations, whole batch against the oracle."""
+    from sqp_solver_amd.problems import random_qp_batch
+
+    B, n, m = 4096, 20, 40
+    P, q, A, l, u = random_qp_batch(B, n, m, seed=20250230)
+    s = make_gpu(n, m, B)
+    s.settings.max_iter = 200
+    s.settings.check_termination = 0
+    s.setup_solve(P, q, A, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings), nthreads=0)
+    assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
+    assert (info.iter == 201).all()
+
+
+def test_api_misuse_errors():
+    from sqp_solver_amd import QPSolverBatch, SqphError
+
+    s = QPSolverBatch(3, 4, 2)
+    P, q, A, l, u = __import__("sqp_solver_amd.problems", fromlist=["x"]).random_qp_batch(3, 3, 4)
+    with pytest.raises(ValueError):
+        s.setup(P, q, A, l, u)  # batch 3 > capacity 2
+    s.settings.alpha = 2.5
+    with pytest.raises(SqphError):
+        s.setup(P[:2], q[:2], A[:2], l[:2], u[:2])
+    with pytest.raises(SqphError):
+        QPSolverBatch(0, 1, 1)
