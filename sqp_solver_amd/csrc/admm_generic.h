@@ -23,8 +23,8 @@ __host__ __device__ inline size_t generic_lds_elems(int n, int m, int nt) {
 
 // out[r] = sum_k M[k*ld + r] * v[k]   (outputs contiguous in memory => coalesced across lanes).
 // v, out, part in LDS. Ends with a barrier; callers must have synchronised v beforehand.
-template <typename T>
-__device__ __forceinline__ void matvec_cm(const T *__restrict__ M, long ld, int R, int K, const T *v, T *out, T *part) {
+template <typename T, typename TM>
+__device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int R, int K, const T *v, T *out, T *part) {
     const int tid = threadIdx.x, nt = blockDim.x;
     if (R <= 0) return;  // m == 0 (unconstrained QP): block-uniform
     if (R >= nt) {
@@ -32,12 +32,12 @@ __device__ __forceinline__ void matvec_cm(const T *__restrict__ M, long ld, int 
             T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             int k = 0;
             for (; k + 3 < K; k += 4) {
-                a0 += M[(long)k * ld + r] * v[k];
-                a1 += M[(long)(k + 1) * ld + r] * v[k + 1];
-                a2 += M[(long)(k + 2) * ld + r] * v[k + 2];
-                a3 += M[(long)(k + 3) * ld + r] * v[k + 3];
+                a0 += (T)M[(long)k * ld + r] * v[k];
+                a1 += (T)M[(long)(k + 1) * ld + r] * v[k + 1];
+                a2 += (T)M[(long)(k + 2) * ld + r] * v[k + 2];
+                a3 += (T)M[(long)(k + 3) * ld + r] * v[k + 3];
             }
-            for (; k < K; k++) a0 += M[(long)k * ld + r] * v[k];
+            for (; k < K; k++) a0 += (T)M[(long)k * ld + r] * v[k];
             out[r] = (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
@@ -51,10 +51,10 @@ __device__ __forceinline__ void matvec_cm(const T *__restrict__ M, long ld, int 
     if (g < G) {
         int k = g;
         for (; k + G < K; k += 2 * G) {
-            a0 += M[(long)k * ld + r] * v[k];
-            a1 += M[(long)(k + G) * ld + r] * v[k + G];
+            a0 += (T)M[(long)k * ld + r] * v[k];
+            a1 += (T)M[(long)(k + G) * ld + r] * v[k + G];
         }
-        for (; k < K; k += G) a0 += M[(long)k * ld + r] * v[k];
+        for (; k < K; k += G) a0 += (T)M[(long)k * ld + r] * v[k];
     }
     part[tid] = a0 + a1;
     __syncthreads();
@@ -68,8 +68,8 @@ __device__ __forceinline__ void matvec_cm(const T *__restrict__ M, long ld, int 
 
 // S = Psym + sigma I + A' diag(rho) A, then in-place Gauss-Jordan inversion (S is SPD: no pivoting).
 // Returns false (block-uniform) on a non-positive / non-finite pivot  => NUMERICAL_ISSUES.
-template <typename T>
-__device__ bool factor_schur_inverse(int n, int m, const T *__restrict__ P, const T *__restrict__ At, const T *rho,
+template <typename T, typename TIN>
+__device__ bool factor_schur_inverse(int n, int m, const TIN *__restrict__ P, const T *__restrict__ At, const T *rho,
                                      T sigma, T *__restrict__ Sinv, T *row, T *col) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int nn = n * n;
@@ -77,7 +77,7 @@ __device__ bool factor_schur_inverse(int n, int m, const T *__restrict__ P, cons
         const int j = e / n, i = e - j * n;
         const int lo = i > j ? i : j, hi = i > j ? j : i;
         // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>, qp.hpp:129)
-        T acc = P[(long)hi * n + lo] + (i == j ? sigma : T(0));
+        T acc = (T)P[(long)hi * n + lo] + (i == j ? sigma : T(0));
         T s0 = 0, s1 = 0;
         int k = 0;
         for (; k + 1 < m; k += 2) {
@@ -114,20 +114,14 @@ __device__ bool factor_schur_inverse(int n, int m, const T *__restrict__ P, cons
     return true;
 }
 
-// rho_vec_update, qp.cpp:296-314
-template <typename T>
-__device__ __forceinline__ T rho_for_type(int ctype, T rho0) {
-    return ctype == SQPH_LOOSE_BOUNDS ? T(1e-6) : (ctype == SQPH_EQUALITY_CONSTRAINT ? T(1e+3) * rho0 : rho0);
-}
-
 #ifdef SQPH_SIM
 #define SQPH_DYN_SMEM(name) unsigned char *name = ::sqph_sim::dyn_smem()
 #else
 #define SQPH_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
-template <typename T>
-__global__ void admm_generic_kernel(KArgs<T> a) {
+template <typename T, typename TIN>
+__global__ void admm_generic_kernel(KArgs<T, TIN> a) {
     SQPH_DYN_SMEM(smem_raw);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int qp = blockIdx.x;
@@ -154,11 +148,11 @@ __global__ void admm_generic_kernel(KArgs<T> a) {
     T *part = lds;       lds += nt;
     T *red = lds;
 
-    const T *gP = a.P + (long)qp * a.sP;
-    const T *gq = a.q + (long)qp * a.sq;
-    const T *gA = a.A + (long)qp * a.sA;
-    const T *gl = a.l + (long)qp * a.sl;
-    const T *gu = a.u + (long)qp * a.su;
+    const TIN *gP = a.P + (long)qp * a.sP;
+    const TIN *gq = a.q + (long)qp * a.sq;
+    const TIN *gA = a.A + (long)qp * a.sA;
+    const TIN *gl = a.l + (long)qp * a.sl;
+    const TIN *gu = a.u + (long)qp * a.su;
     T *sx = a.x + (long)qp * n;
     T *sz = a.z + (long)qp * m;
     T *sy = a.y + (long)qp * m;
@@ -175,10 +169,10 @@ __global__ void admm_generic_kernel(KArgs<T> a) {
         (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
         return;  // qp.cpp:68-71
 
-    for (int j = tid; j < n; j += nt) q[j] = gq[j];
+    for (int j = tid; j < n; j += nt) q[j] = (T)gq[j];
     for (int i = tid; i < m; i += nt) {
-        l[i] = gl[i];
-        u[i] = gu[i];
+        l[i] = (T)gl[i];
+        u[i] = (T)gu[i];
     }
 
     if (mode & (MODE_SETUP | MODE_UPDATE)) {
@@ -187,14 +181,14 @@ __global__ void admm_generic_kernel(KArgs<T> a) {
         for (int i = tid; i < m; i += nt) {
             const T li = l[i], ui = u[i];
             int ct;
-            if (li < -T(1e16) && ui > T(1e16))
+            if (li < -a.loose_thresh && ui > a.loose_thresh)
                 ct = SQPH_LOOSE_BOUNDS;
-            else if (ui - li < T(1e-4))
+            else if (ui - li < a.eq_tol)
                 ct = SQPH_EQUALITY_CONSTRAINT;
             else
                 ct = SQPH_INEQUALITY_CONSTRAINT;
             sct[i] = ct;
-            const T r = rho_for_type<T>(ct, rho_s);
+            const T r = rho_for_type<T>(ct, rho_s, a.rho_min, a.rho_eq_factor);
             rho[i] = r;
             rinv[i] = T(1) / r;
             srho[i] = r;
@@ -213,10 +207,10 @@ __global__ void admm_generic_kernel(KArgs<T> a) {
         // row-major copy of A: At[i*n + j] = A[j*m + i]
         for (int e = tid; e < m * n; e += nt) {
             const int i = e / n, j = e - i * n;
-            At[e] = gA[(long)j * m + i];
+            At[e] = (T)gA[(long)j * m + i];
         }
         __syncthreads();
-        const bool ok = factor_schur_inverse<T>(n, m, gP, At, rho, a.sigma, Sinv, gjrow, gjcol);
+        const bool ok = factor_schur_inverse<T, TIN>(n, m, gP, At, rho, a.sigma, Sinv, gjrow, gjcol);
         __syncthreads();
         info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;
     } else {
@@ -297,23 +291,23 @@ __global__ void admm_generic_kernel(KArgs<T> a) {
                 }
                 if (adapt) {
                     // rho_estimate, qp.cpp:333-341 ; clamp + tolerance test, qp.cpp:130-136
-                    const T eps = Num<T>::eps();
+                    const T eps = a.regul;
                     const T rp_norm = v[2] / (nrm_prim + eps);
                     const T rd_norm = v[6] / (nrm_dual + eps);
                     T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
-                    new_rho = new_rho < T(1e+6) ? new_rho : T(1e+6);  // fmax(RHO_MIN, fmin(new_rho, RHO_MAX))
-                    new_rho = new_rho > T(1e-6) ? new_rho : T(1e-6);
+                    new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;  // fmax(RHO_MIN, fmin(new_rho, RHO_MAX))
+                    new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
                     info.rho_estimate = (double)new_rho;
                     if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
                         rho_s = new_rho;
                         for (int i = tid; i < m; i += nt) {
-                            const T r = rho_for_type<T>(sct[i], rho_s);
+                            const T r = rho_for_type<T>(sct[i], rho_s, a.rho_min, a.rho_eq_factor);
                             rho[i] = r;
                             rinv[i] = T(1) / r;
                         }
                         info.rho_updates += 1;
                         __syncthreads();
-                        const bool ok = factor_schur_inverse<T>(n, m, gP, At, rho, sigma, Sinv, gjrow, gjcol);
+                        const bool ok = factor_schur_inverse<T, TIN>(n, m, gP, At, rho, sigma, Sinv, gjrow, gjcol);
                         __syncthreads();
                         if (!ok) {
                             info.status = SQPH_NUMERICAL_ISSUES;

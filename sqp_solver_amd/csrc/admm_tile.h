@@ -1,13 +1,23 @@
-// Register-tiled wave-per-QP ADMM kernels (fast path). Placeholder until the tiled kernels land:
-// tile_try_launch returns 0 ("shape not covered") so every shape takes the generic kernel.
+// Host-side dispatch of the register-tiled kernels (admm_tile_kernel.h): picks the smallest
+// compiled tile shape {TR, TC} with m <= 8*TR and n <= 8*TC.
 #pragma once
-#include "kargs.h"
+#include <hip/hip_runtime.h>
+
+#include "admm_tile_kernel.h"
 
 namespace sqph {
 
 // >0: launched (name set), 0: shape not covered, <0: launch error
-template <typename T>
-inline int tile_try_launch(const KArgs<T> &, hipStream_t, const char **) {
+template <typename T, typename TIN>
+inline int tile_try_launch(const KArgs<T, TIN> &a, hipStream_t stream, const char **name) {
+#define SQPH_TILE_CASE(TR_, TC_, L_, W_)                                                                        \
+    if (a.m <= 8 * TR_ && a.n <= 8 * TC_) {                                                                     \
+        hipLaunchKernelGGL((admm_tile_kernel<T, TIN, TR_, TC_, L_, W_>), dim3(a.batch), dim3(64), 0, stream, a); \
+        *name = "tile_" #TR_ "x" #TC_;                                                                      \
+        return hipGetLastError() == hipSuccess ? 1 : -1;                                                    \
+    }
+    SQPH_TILE_SHAPES(SQPH_TILE_CASE)
+#undef SQPH_TILE_CASE
     return 0;
 }
 

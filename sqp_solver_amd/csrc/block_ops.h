@@ -25,6 +25,12 @@ __device__ __forceinline__ T tabs(T a) {
     return a < T(0) ? -a : a;
 }
 
+// rho_vec_update, reference src/qp.cpp:296-314 (ConstraintType order of qp.hpp:134: 0 ineq, 1 eq, 2 loose)
+template <typename T>
+__device__ __forceinline__ T rho_for_type(int ctype, T rho0, T rho_min, T eq_factor) {
+    return ctype == 2 ? rho_min : (ctype == 1 ? eq_factor * rho0 : rho0);
+}
+
 // Block-wide NaN-propagating max of K values per thread; result replicated to every thread.
 // red: LDS scratch of K*blockDim.x elements. Ends with a barrier.
 template <typename T, int K>

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <utility>
@@ -33,6 +34,15 @@ struct DeviceGuard {
 };
 
 size_t dsize(int dtype) { return dtype == SQPH_F32 ? sizeof(float) : sizeof(double); }
+
+__global__ void cvt_f64_to_f32(const double *__restrict__ src, float *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+__global__ void cvt_f32_to_f64(const float *__restrict__ src, double *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
 
 }  // namespace
 
@@ -138,7 +148,7 @@ int sqph_create(sqph_solver **out, int device, int n, int m, int batch_capacity,
     sqph_default_settings(&s->settings);
 
     DeviceGuard g(device);
-    const size_t e = dsize(dtype), B = (size_t)batch_capacity;
+    const size_t e = sizeof(double), B = (size_t)batch_capacity;  // state/workspace: always fp64
     const size_t mm = (size_t)(m > 0 ? m : 1);
     hipError_t err = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
@@ -262,11 +272,27 @@ int sqph_get_solution(sqph_solver *s, int batch, int memspace, void *x, void *y,
     if (!s) return SQPH_ERR_INVALID;
     if (batch < 0 || batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "sqph_get_solution: batch %d exceeds capacity %d", batch, s->cap);
     DeviceGuard g(s->device);
-    const size_t e = dsize(s->dtype), B = (size_t)batch;
+    const size_t B = (size_t)batch;
     const hipMemcpyKind kind = memspace == SQPH_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    if (x) SQPH_HIP(s, hipMemcpyAsync(x, s->x, B * s->n * e, kind, s->stream));
-    if (y && s->m) SQPH_HIP(s, hipMemcpyAsync(y, s->y, B * s->m * e, kind, s->stream));
-    if (z && s->m) SQPH_HIP(s, hipMemcpyAsync(z, s->z, B * s->m * e, kind, s->stream));
+    struct Item { void *dst; const void *src; size_t elems; };
+    const Item items[3] = {{x, s->x, B * s->n}, {y, s->y, B * s->m}, {z, s->z, B * s->m}};
+    for (const Item &it : items) {
+        if (!it.dst || it.elems == 0) continue;
+        if (s->dtype == SQPH_F64) {
+            SQPH_HIP(s, hipMemcpyAsync(it.dst, it.src, it.elems * sizeof(double), kind, s->stream));
+        } else if (memspace == SQPH_DEVICE) {
+            hipLaunchKernelGGL(cvt_f64_to_f32, dim3((unsigned)((it.elems + 255) / 256)), dim3(256), 0, s->stream,
+                               (const double *)it.src, (float *)it.dst, it.elems);
+            SQPH_HIP(s, hipGetLastError());
+        } else {
+            // QPSolver<float>: state is kept in fp64 on the device, narrowed on the way out
+            std::vector<double> tmp(it.elems);
+            SQPH_HIP(s, hipMemcpyAsync(tmp.data(), it.src, it.elems * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+            SQPH_HIP(s, hipStreamSynchronize(s->stream));
+            float *d = (float *)it.dst;
+            for (size_t i = 0; i < it.elems; i++) d[i] = (float)tmp[i];
+        }
+    }
     if (info) SQPH_HIP(s, hipMemcpyAsync(info, s->info, B * sizeof(sqph_info), kind, s->stream));
     if (memspace == SQPH_HOST) SQPH_HIP(s, hipStreamSynchronize(s->stream));
     return SQPH_OK;
@@ -276,11 +302,26 @@ int sqph_set_state(sqph_solver *s, int batch, int memspace, const void *x, const
     if (!s) return SQPH_ERR_INVALID;
     if (batch < 0 || batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "sqph_set_state: batch %d exceeds capacity %d", batch, s->cap);
     DeviceGuard g(s->device);
-    const size_t e = dsize(s->dtype), B = (size_t)batch;
+    const size_t B = (size_t)batch;
     const hipMemcpyKind kind = memspace == SQPH_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    if (x) SQPH_HIP(s, hipMemcpyAsync(s->x, x, B * s->n * e, kind, s->stream));
-    if (z && s->m) SQPH_HIP(s, hipMemcpyAsync(s->z, z, B * s->m * e, kind, s->stream));
-    if (y && s->m) SQPH_HIP(s, hipMemcpyAsync(s->y, y, B * s->m * e, kind, s->stream));
+    struct Item { void *dst; const void *src; size_t elems; };
+    const Item items[3] = {{s->x, x, B * s->n}, {s->z, z, B * s->m}, {s->y, y, B * s->m}};
+    for (const Item &it : items) {
+        if (!it.src || it.elems == 0) continue;
+        if (s->dtype == SQPH_F64) {
+            SQPH_HIP(s, hipMemcpyAsync(it.dst, it.src, it.elems * sizeof(double), kind, s->stream));
+        } else if (memspace == SQPH_DEVICE) {
+            hipLaunchKernelGGL(cvt_f32_to_f64, dim3((unsigned)((it.elems + 255) / 256)), dim3(256), 0, s->stream,
+                               (const float *)it.src, (double *)it.dst, it.elems);
+            SQPH_HIP(s, hipGetLastError());
+        } else {
+            std::vector<double> tmp(it.elems);
+            const float *f = (const float *)it.src;
+            for (size_t i = 0; i < it.elems; i++) tmp[i] = (double)f[i];
+            SQPH_HIP(s, hipMemcpyAsync(it.dst, tmp.data(), it.elems * sizeof(double), hipMemcpyHostToDevice, s->stream));
+            SQPH_HIP(s, hipStreamSynchronize(s->stream));
+        }
+    }
     if (memspace == SQPH_HOST) SQPH_HIP(s, hipStreamSynchronize(s->stream));
     return SQPH_OK;
 }
@@ -289,22 +330,27 @@ int sqph_set_state(sqph_solver *s, int batch, int memspace, const void *x, const
 
 namespace {
 
-template <typename T>
+// Scalar constants of the reference class (qp.hpp:136-141) and the settings are rounded through the
+// interface Scalar (TIN) first, then widened to the fp64 the kernels compute in.
+template <typename TIN>
 int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *P, const void *q, const void *A,
                  const void *l, const void *u, long long sP, long long sq, long long sA, long long sl, long long su) {
     using namespace sqph;
-    KArgs<T> a{};
+    using T = double;
+    KArgs<T, TIN> a{};
     a.n = s->n;
     a.m = s->m;
     a.batch = qp->batch;
     a.mode = mode | ((s->flags & SQPH_FLAG_LEGACY_COLD_START) ? MODE_COLD_RESET : 0);
-    a.P = (const T *)P; a.q = (const T *)q; a.A = (const T *)A; a.l = (const T *)l; a.u = (const T *)u;
+    a.P = (const TIN *)P; a.q = (const TIN *)q; a.A = (const TIN *)A; a.l = (const TIN *)l; a.u = (const TIN *)u;
     a.sP = sP; a.sq = sq; a.sA = sA; a.sl = sl; a.su = su;
     a.x = (T *)s->x; a.z = (T *)s->z; a.y = (T *)s->y; a.rho_vec = (T *)s->rho_vec; a.ctype = s->ctype;
     a.rho = (T *)s->rho; a.info = s->info; a.Sinv = (T *)s->Sinv;
     const sqph_settings &st = s->settings;
-    a.rho0 = (T)st.rho; a.sigma = (T)st.sigma; a.alpha = (T)st.alpha; a.eps_rel = (T)st.eps_rel; a.eps_abs = (T)st.eps_abs;
-    a.rho_tol = (T)st.adaptive_rho_tolerance;
+    a.rho0 = (T)(TIN)st.rho; a.sigma = (T)(TIN)st.sigma; a.alpha = (T)(TIN)st.alpha;
+    a.eps_rel = (T)(TIN)st.eps_rel; a.eps_abs = (T)(TIN)st.eps_abs; a.rho_tol = (T)(TIN)st.adaptive_rho_tolerance;
+    a.rho_min = (T)(TIN)1e-6; a.rho_max = (T)(TIN)1e+6; a.eq_tol = (T)(TIN)1e-4; a.rho_eq_factor = (T)(TIN)1e+3;
+    a.loose_thresh = (T)(TIN)1e+16; a.regul = (T)std::numeric_limits<TIN>::epsilon();
     a.max_iter = st.max_iter; a.check_termination = st.check_termination; a.warm_start = st.warm_start;
     a.adaptive_rho = st.adaptive_rho; a.adaptive_rho_interval = st.adaptive_rho_interval;
 
@@ -320,7 +366,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
 
     bool launched = false;
     if (!(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
-        int rc = tile_try_launch<T>(a, s->stream, &s->kernel_name);
+        int rc = tile_try_launch<T, TIN>(a, s->stream, &s->kernel_name);
         if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "tiled kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         launched = rc > 0;
     }
@@ -335,8 +381,8 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         const size_t lds = generic_lds_elems<T>(s->n, s->m, nt) * sizeof(T);
         if (lds > 160 * 1024) SQPH_FAIL(s, SQPH_ERR_UNSUPPORTED, "n=%d m=%d needs %zu B of LDS (>160 KiB)", s->n, s->m, lds);
         if (lds > 64 * 1024)
-            SQPH_HIP(s, hipFuncSetAttribute((const void *)admm_generic_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(admm_generic_kernel<T>, dim3(qp->batch), dim3(nt), lds, s->stream, a);
+            SQPH_HIP(s, hipFuncSetAttribute((const void *)admm_generic_kernel<T, TIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((admm_generic_kernel<T, TIN>), dim3(qp->batch), dim3(nt), lds, s->stream, a);
         SQPH_HIP(s, hipGetLastError());
         s->kernel_name = nt == 64 ? "generic_w1" : "generic_w4";
     }

@@ -11,11 +11,13 @@ enum : int {
     MODE_COLD_RESET = 8,  // legacy class: solve() zeroes x,z,y when !warm_start (unsupported/qp_solver.hpp:256-260)
 };
 
-template <typename T>
+// T   = arithmetic / state type (always double in the shipped library)
+// TIN = type of the caller's problem arrays (double for QPSolver<double>, float for QPSolver<float>)
+template <typename T, typename TIN = T>
 struct KArgs {
     int n, m, batch, mode;
     // borrowed problem data (device pointers), per-QP column-major, element strides (0 = shared)
-    const T *P, *q, *A, *l, *u;
+    const TIN *P, *q, *A, *l, *u;
     long long sP, sq, sA, sl, su;
     // persistent per-QP solver state, QP-major
     T *x;         // [batch][n]
@@ -30,6 +32,8 @@ struct KArgs {
     T *At;        // [batch][m*n]  row-major copy of A (generic kernel only; may be null for tiled kernels)
     // settings converted to Scalar
     T rho0, sigma, alpha, eps_rel, eps_abs, rho_tol;
+    // class constants (qp.hpp:136-141), rounded through Scalar on the host
+    T rho_min, rho_max, eq_tol, rho_eq_factor, loose_thresh, regul;
     int max_iter, check_termination, warm_start, adaptive_rho, adaptive_rho_interval;
 };
 

@@ -1,0 +1,150 @@
+// Cross-lane primitives for the wave-per-QP kernels (64-wide wavefront, 8 x 8 lane grid).
+//
+// lane = 8*c + r :  r = lane & 7 (row group, contiguous lanes), c = lane >> 3 (column group,
+// lanes 8 apart).  Two 8-lane communicators exist per lane:
+//     "row-of-grid" group  = lanes sharing c (contiguous, index r): xor masks 1, 2, 4
+//     "col-of-grid" group  = lanes sharing r (stride 8,  index c): xor masks 8, 16, 32
+// rs8  = reduce-scatter of 8 values inside one group (lane with index g ends with sum of v[g]),
+// ag8  = all-gather (every lane of the group ends with the 8 values, ordered by index).
+// Both are 3-stage butterflies on whole VGPRs: no LDS storage is touched.
+//
+// Under SQPH_SIM the exchange is routed through the host SIMT emulator (tests/sim/hip_sim.h).
+#pragma once
+#ifndef SQPH_SIM
+#include <hip/hip_runtime.h>
+#endif
+
+namespace sqph {
+
+#ifdef SQPH_SIM
+template <typename T>
+inline T lane_xor(T v, int mask) {
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    const int lane = (int)(threadIdx.x & 63);
+    uint64_t r = ::sqph_sim::wave_exchange(bits, lane ^ mask);
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
+}
+inline double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+inline float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#else
+// ---- gfx950 implementations -----------------------------------------------------------------
+// DPP controls (VOP_DPP): quad_perm:[1,0,3,2] = 0xB1, quad_perm:[2,3,0,1] = 0x4E, row_ror:n = 0x120+n,
+// row_half_mirror = 0x141.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int MASK>
+__device__ __forceinline__ int xor_i32(int v) {
+    if constexpr (MASK == 1) {
+        return dpp_mov_i32<0xB1>(v);
+    } else if constexpr (MASK == 2) {
+        return dpp_mov_i32<0x4E>(v);
+    } else if constexpr (MASK == 4) {
+        // lane^4 == quad-reverse( half-mirror(lane) ): i^7^3
+        return dpp_mov_i32<0x1B>(dpp_mov_i32<0x141>(v));
+    } else if constexpr (MASK == 8) {
+        return dpp_mov_i32<0x128>(v);  // row_ror:8 inside each row of 16
+    } else if constexpr (MASK == 16) {
+        // v_permlane16_swap: swaps odd rows of the first operand with even rows of the second
+        auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        // r[0] = {row0: v.row0, row1: v.row0, row2: v.row2, row3: v.row2}; r[1] = {v.row1, v.row1, v.row3, v.row3}
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        return (lane & 16) ? (int)r[0] : (int)r[1];
+    } else if constexpr (MASK == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        return (lane & 32) ? (int)r[0] : (int)r[1];
+    } else {
+        return __shfl_xor(v, MASK);
+    }
+}
+template <int MASK>
+__device__ __forceinline__ double lane_xor_c(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = xor_i32<MASK>(lo);
+    hi = xor_i32<MASK>(hi);
+    return __hiloint2double(hi, lo);
+}
+template <int MASK>
+__device__ __forceinline__ float lane_xor_c(float v) {
+    return __int_as_float(xor_i32<MASK>(__float_as_int(v)));
+}
+template <typename T>
+__device__ __forceinline__ T lane_xor(T v, int mask) {
+    return __shfl_xor(v, mask);
+}
+__device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#endif
+
+// partner exchange with a compile-time xor mask
+template <int MASK, typename T>
+__device__ __forceinline__ T xchg(T v) {
+#if defined(SQPH_SIM) || defined(SQPH_XCHG_BPERMUTE)
+    return lane_xor<T>(v, MASK);
+#else
+    return lane_xor_c<MASK>(v);
+#endif
+}
+
+// reduce-scatter of v[0..7] over the 8 lanes {g ^ k*M0-ish}; g = my index in the group (bits -> masks M0,M1,M2)
+template <int M0, int M1, int M2, typename T>
+__device__ __forceinline__ T rs8(const T (&v)[8], int g) {
+    const bool b2 = g & 4, b1 = g & 2, b0 = g & 1;
+    T u[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const T send = b2 ? v[k] : v[k + 4];
+        const T keep = b2 ? v[k + 4] : v[k];
+        u[k] = keep + xchg<M2>(send);
+    }
+    T w[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const T send = b1 ? u[k] : u[k + 2];
+        const T keep = b1 ? u[k + 2] : u[k];
+        w[k] = keep + xchg<M1>(send);
+    }
+    const T send = b0 ? w[0] : w[1];
+    const T keep = b0 ? w[1] : w[0];
+    return keep + xchg<M0>(send);
+}
+
+// all-gather: v[k] = x of the group lane with index k
+template <int M0, int M1, int M2, typename T>
+__device__ __forceinline__ void ag8(T x, int g, T (&v)[8]) {
+    const bool b2 = g & 4, b1 = g & 2, b0 = g & 1;
+    const T p = xchg<M0>(x);
+    const T a0 = b0 ? p : x, a1 = b0 ? x : p;
+    const T p0 = xchg<M1>(a0), p1 = xchg<M1>(a1);
+    T q[4];
+    q[0] = b1 ? p0 : a0;
+    q[1] = b1 ? p1 : a1;
+    q[2] = b1 ? a0 : p0;
+    q[3] = b1 ? a1 : p1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const T rk = xchg<M2>(q[k]);
+        v[k] = b2 ? rk : q[k];
+        v[k + 4] = b2 ? q[k] : rk;
+    }
+}
+
+// wave-wide NaN-propagating max (all 64 lanes end with the result)
+template <typename T>
+__device__ __forceinline__ T wave_nanmax(T v) {
+#define SQPH_WM_STEP(M)                       \
+    {                                         \
+        const T o = xchg<M>(v);               \
+        v = (o > v || o != o) ? o : v;        \
+    }
+    SQPH_WM_STEP(1) SQPH_WM_STEP(2) SQPH_WM_STEP(4) SQPH_WM_STEP(8) SQPH_WM_STEP(16) SQPH_WM_STEP(32)
+#undef SQPH_WM_STEP
+    return v;
+}
+
+}  // namespace sqph

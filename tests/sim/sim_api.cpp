@@ -2,6 +2,8 @@
 // Runs the product's HIP kernels (sqp_solver_amd/csrc/*.h) under the host SIMT emulator so the
 // CPU-only unit tests can compare kernel logic with the oracle. Built into libsqph_sim.so.
 #include "hip_sim.h"
+
+#include <limits>
 // kernels (device code only; host launch code lives in capi.hip and is not compiled here)
 #include "../../sqp_solver_amd/csrc/admm_generic.h"
 #include "../../sqp_solver_amd/csrc/admm_tile_kernel.h"
@@ -25,26 +27,29 @@ struct SimArgs {
 }  // extern "C"
 
 namespace {
-template <typename T>
-sqph::KArgs<T> convert(const SimArgs &s) {
-    sqph::KArgs<T> a{};
+template <typename TIN>
+sqph::KArgs<double, TIN> convert(const SimArgs &s) {
+    using T = double;
+    sqph::KArgs<T, TIN> a{};
     a.n = s.n; a.m = s.m; a.batch = s.batch; a.mode = s.mode;
-    a.P = (const T *)s.P; a.q = (const T *)s.q; a.A = (const T *)s.A; a.l = (const T *)s.l; a.u = (const T *)s.u;
+    a.P = (const TIN *)s.P; a.q = (const TIN *)s.q; a.A = (const TIN *)s.A; a.l = (const TIN *)s.l; a.u = (const TIN *)s.u;
     a.sP = s.sP; a.sq = s.sq; a.sA = s.sA; a.sl = s.sl; a.su = s.su;
     a.x = (T *)s.x; a.z = (T *)s.z; a.y = (T *)s.y; a.rho_vec = (T *)s.rho_vec; a.ctype = s.ctype;
     a.rho = (T *)s.rho; a.info = s.info; a.Sinv = (T *)s.Sinv; a.At = (T *)s.At;
-    a.rho0 = (T)s.rho0; a.sigma = (T)s.sigma; a.alpha = (T)s.alpha; a.eps_rel = (T)s.eps_rel; a.eps_abs = (T)s.eps_abs;
-    a.rho_tol = (T)s.rho_tol;
+    a.rho0 = (T)(TIN)s.rho0; a.sigma = (T)(TIN)s.sigma; a.alpha = (T)(TIN)s.alpha; a.eps_rel = (T)(TIN)s.eps_rel;
+    a.eps_abs = (T)(TIN)s.eps_abs; a.rho_tol = (T)(TIN)s.rho_tol;
+    a.rho_min = (T)(TIN)1e-6; a.rho_max = (T)(TIN)1e+6; a.eq_tol = (T)(TIN)1e-4; a.rho_eq_factor = (T)(TIN)1e+3;
+    a.loose_thresh = (T)(TIN)1e+16; a.regul = (T)std::numeric_limits<TIN>::epsilon();
     a.max_iter = s.max_iter; a.check_termination = s.check_termination; a.warm_start = s.warm_start;
     a.adaptive_rho = s.adaptive_rho; a.adaptive_rho_interval = s.adaptive_rho_interval;
     return a;
 }
 
-template <typename T>
+template <typename TIN>
 int run_generic(const SimArgs &s, int nt) {
-    auto a = convert<T>(s);
-    const size_t lds = sqph::generic_lds_elems<T>(s.n, s.m, nt) * sizeof(T);
-    sqph_sim::launch(sqph::admm_generic_kernel<T>, dim3(s.batch), dim3(nt), lds, a);
+    auto a = convert<TIN>(s);
+    const size_t lds = sqph::generic_lds_elems<double>(s.n, s.m, nt) * sizeof(double);
+    sqph_sim::launch(sqph::admm_generic_kernel<double, TIN>, dim3(s.batch), dim3(nt), lds, a);
     return 0;
 }
 }  // namespace
@@ -54,7 +59,7 @@ extern "C" {
 // variant: 0 = generic (nt threads per QP); 1 = register-tiled wave-per-QP
 int sim_run(const SimArgs *s, int variant, int dtype, int nt) {
     if (variant == 0) return dtype == SQPH_F32 ? run_generic<float>(*s, nt) : run_generic<double>(*s, nt);
-    if (variant == 1) return dtype == SQPH_F32 ? sqph::sim_run_tile<float>(convert<float>(*s)) : sqph::sim_run_tile<double>(convert<double>(*s));
+    if (variant == 1) return dtype == SQPH_F32 ? sqph::sim_run_tile<double, float>(convert<float>(*s)) : sqph::sim_run_tile<double, double>(convert<double>(*s));
     return -1;
 }
 }

@@ -57,16 +57,17 @@ class SimSolverBatch:
         s.max_iter, s.check_termination, s.warm_start, s.adaptive_rho = 1000, 25, 0, 0
         s.adaptive_rho_tolerance, s.adaptive_rho_interval, s.verbose = 5, 25, 0
         mm = max(m, 1)
-        self.x = np.zeros((batch, n), self.dtype)
-        self.zv = np.zeros((batch, mm), self.dtype)
-        self.y = np.zeros((batch, mm), self.dtype)
-        self.rho_vec = np.zeros((batch, mm), self.dtype)
+        # solver state is fp64 whatever the interface Scalar is (QPSolver<float>)
+        self.x = np.zeros((batch, n), np.float64)
+        self.zv = np.zeros((batch, mm), np.float64)
+        self.y = np.zeros((batch, mm), np.float64)
+        self.rho_vec = np.zeros((batch, mm), np.float64)
         self.ctype = np.zeros((batch, mm), np.int32)
-        self.rho = np.zeros(batch, self.dtype)
+        self.rho = np.zeros(batch, np.float64)
         self.info_arr = np.zeros(batch, _capi.INFO_DTYPE)
         self.info_arr["status"] = 4
-        self.Sinv = np.zeros((batch, n * n), self.dtype)
-        self.At = np.zeros((batch, mm * n), self.dtype)
+        self.Sinv = np.zeros((batch, n * n), np.float64)
+        self.At = np.zeros((batch, mm * n), np.float64)
 
     def _run(self, mode, P, q, A, l, u):
         n, m = self.n, self.m
@@ -114,13 +115,13 @@ class SimSolverBatch:
         self._run(MODE_SETUP | MODE_SOLVE, P, q, A, l, u)
 
     def primal_solution(self):
-        return self.x[: self._last].copy()
+        return self.x[: self._last].astype(self.dtype)
 
     def dual_solution(self):
-        return self.y[: self._last, : self.m].copy()
+        return self.y[: self._last, : self.m].astype(self.dtype)
 
     def z(self):
-        return self.zv[: self._last, : self.m].copy()
+        return self.zv[: self._last, : self.m].astype(self.dtype)
 
     def info(self):
         return self.info_arr[: self._last].copy().view(np.recarray)
