@@ -86,7 +86,7 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.qpo_default_settings.argtypes = [ctypes.POINTER(Settings)]
         _lib.qpo_max_threads.restype = ctypes.c_int
-        for sfx, ct in (("_f64", ctypes.c_double), ("_f32", ctypes.c_float)):
+        for sfx, ct in (("_f64", ctypes.c_double), ("_f32", ctypes.c_float), ("_f80", ctypes.c_longdouble)):
             p = ctypes.POINTER(ct)
             pi = ctypes.POINTER(ctypes.c_int)
             g = lambda name: getattr(_lib, name + sfx)  # noqa: E731
@@ -132,6 +132,8 @@ def _sfx(dtype):
         return "_f64", ctypes.c_double
     if dtype == np.float32:
         return "_f32", ctypes.c_float
+    if dtype == np.longdouble:
+        return "_f80", ctypes.c_longdouble  # x87 extended precision yard-stick (not a reference instantiation)
     raise TypeError(dtype)
 
 

@@ -39,16 +39,40 @@ int qpo_max_threads(void) {
 #define SCALAR double
 #define SCALAR_EPS DBL_EPSILON
 #define SCALAR_MIN DBL_MIN
+#define SABS(x) fabs(x)
+#define SSQRT(x) sqrt(x)
 #define SFX(name) name##_f64
 #include "qp_oracle_impl.h"
 #undef SCALAR
 #undef SCALAR_EPS
 #undef SCALAR_MIN
+#undef SABS
+#undef SSQRT
+#undef SFX
+
+/* x87 80-bit extended precision instance: NOT a reference instantiation. It is the yard-stick the
+ * tests use to tell how far the fp64 reference path itself is from the exact ADMM iterate on
+ * ill-conditioned problems (adaptive rho can push rho_eq = 1e3*rho to 1e6+). DIV_BY_ZERO_REGUL and
+ * the pseudo-inverse threshold keep their double values so the trajectory is the double one. */
+#define SCALAR long double
+#define SCALAR_EPS DBL_EPSILON
+#define SCALAR_MIN DBL_MIN
+#define SABS(x) fabsl(x)
+#define SSQRT(x) sqrtl(x)
+#define SFX(name) name##_f80
+#include "qp_oracle_impl.h"
+#undef SCALAR
+#undef SCALAR_EPS
+#undef SCALAR_MIN
+#undef SABS
+#undef SSQRT
 #undef SFX
 
 #define SCALAR float
 #define SCALAR_EPS FLT_EPSILON
 #define SCALAR_MIN FLT_MIN
+#define SABS(x) fabsf(x)
+#define SSQRT(x) ((float)sqrt((double)(x)))
 #define SFX(name) name##_f32
 #include "qp_oracle_impl.h"
 #undef SCALAR

@@ -66,6 +66,7 @@ void qpo_default_settings(qpo_settings *s);
 
 QPO_DECL(_f64, double)
 QPO_DECL(_f32, float)
+QPO_DECL(_f80, long double) /* extended-precision yard-stick, see qp_oracle.c */
 
 int qpo_max_threads(void);
 

@@ -75,9 +75,9 @@ static int SFX(ldlt_compute_inplace)(SFX(qpo_ldlt) *f) {
     for (int k = 0; k < size; k++) {
         /* largest stored diagonal entry of the trailing block */
         int p = k;
-        SCALAR best = (SCALAR)fabs((double)MAT(k, k));
+        SCALAR best = SABS(MAT(k, k));
         for (int i = k + 1; i < size; i++) {
-            SCALAR a = (SCALAR)fabs((double)MAT(i, i));
+            SCALAR a = SABS(MAT(i, i));
             if (a > best) {
                 best = a;
                 p = i;
@@ -123,7 +123,7 @@ static int SFX(ldlt_compute_inplace)(SFX(qpo_ldlt) *f) {
         }
 
         const SCALAR akk = MAT(k, k);
-        const int pivot_is_valid = fabs((double)akk) > 0.0;
+        const int pivot_is_valid = SABS(akk) > (SCALAR)0;
 
         if (k == 0 && !pivot_is_valid) {
             /* whole diagonal is zero */
@@ -177,7 +177,7 @@ static void SFX(ldlt_solve_inplace)(const SFX(qpo_ldlt) *f, SCALAR *x) {
     const SCALAR tol = SCALAR_MIN;
     for (int i = 0; i < size; i++) {
         const SCALAR d = MAT(i, i);
-        if (fabs((double)d) > (double)tol)
+        if (SABS(d) > tol)
             x[i] /= d;
         else
             x[i] = 0;
@@ -387,7 +387,7 @@ void SFX(qpo_update_qp)(SFX(qpo_solver) * s, const SCALAR *P, const SCALAR *q, c
 static SCALAR SFX(inf_norm)(const SCALAR *v, int k) {
     SCALAR r = 0;
     for (int i = 0; i < k; i++) {
-        SCALAR a = (SCALAR)fabs((double)v[i]);
+        SCALAR a = SABS(v[i]);
         if (a > r || a != a) r = a; /* NaN propagates like Eigen's lpNorm<Infinity> maxCoeff */
     }
     return r;
@@ -419,12 +419,12 @@ static void SFX(update_state)(SFX(qpo_solver) * s, const SCALAR *P, const SCALAR
     SFX(gemv_A)(m, n, A, s->x, Ax);
     SCALAR norm_Ax = SFX(inf_norm)(Ax, m);
     SCALAR norm_z = SFX(inf_norm)(s->z, m);
-    s->max_Ax_z_norm = (SCALAR)fmax((double)norm_Ax, (double)norm_z);
+    s->max_Ax_z_norm = norm_Ax > norm_z ? norm_Ax : norm_z; /* fmax(norm_Ax, norm_z) */
 
     /* residual_prim: ||A x - z||_inf */
     SCALAR rp = 0;
     for (int i = 0; i < m; i++) {
-        SCALAR a = (SCALAR)fabs((double)(Ax[i] - s->z[i]));
+        SCALAR a = SABS(Ax[i] - s->z[i]);
         if (a > rp || a != a) rp = a;
     }
 
@@ -434,11 +434,11 @@ static void SFX(update_state)(SFX(qpo_solver) * s, const SCALAR *P, const SCALAR
     SFX(gemv_AT)(m, n, A, s->y, ATy);
     SCALAR norm_ATy = SFX(inf_norm)(ATy, n);
     SCALAR norm_q = SFX(inf_norm)(q, n);
-    s->max_Px_ATy_q_norm = (SCALAR)fmax((double)norm_Px, fmax((double)norm_ATy, (double)norm_q));
+    { SCALAR t_ = norm_ATy > norm_q ? norm_ATy : norm_q; s->max_Px_ATy_q_norm = norm_Px > t_ ? norm_Px : t_; } /* fmax(norm_Px, fmax(norm_ATy, norm_q)) */
 
     SCALAR rd = 0;
     for (int j = 0; j < n; j++) {
-        SCALAR a = (SCALAR)fabs((double)(tn[j] + q[j] + ATy[j]));
+        SCALAR a = SABS(tn[j] + q[j] + ATy[j]);
         if (a > rd || a != a) rd = a;
     }
     s->info.res_prim = rp;
@@ -511,8 +511,9 @@ void SFX(qpo_solve)(SFX(qpo_solver) * s, const SCALAR *P, const SCALAR *q, const
             /* rho_estimate, qp.cpp:333-341 */
             SCALAR rp_norm = (SCALAR)s->info.res_prim / (s->max_Ax_z_norm + REGUL);
             SCALAR rd_norm = (SCALAR)s->info.res_dual / (s->max_Px_ATy_q_norm + REGUL);
-            SCALAR new_rho = s->rho * (SCALAR)sqrt((double)(rp_norm / (rd_norm + REGUL)));
-            new_rho = (SCALAR)fmax((double)RHO_MIN, fmin((double)new_rho, (double)RHO_MAX));
+            SCALAR new_rho = s->rho * SSQRT(rp_norm / (rd_norm + REGUL));
+            new_rho = new_rho < RHO_MAX ? new_rho : RHO_MAX; /* fmax(RHO_MIN, fmin(new_rho, RHO_MAX)) */
+            new_rho = new_rho > RHO_MIN ? new_rho : RHO_MIN;
             s->info.rho_estimate = new_rho;
 
             const SCALAR tol = (SCALAR)s->settings.adaptive_rho_tolerance;

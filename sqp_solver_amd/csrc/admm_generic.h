@@ -4,8 +4,8 @@
 // QP is being iterated), vectors live in LDS.  The register-tiled kernels in admm_tile.h are
 // the fast path for the shapes they cover.  Algorithm = the reference ADMM
 // (/root/reference/src/qp.cpp:64-157) on the Schur-ordered KKT system: with R = diag(rho_vec)
-//     S = P + sigma I + A' R A            (n x n, SPD)          [replaces the (n+m)^2 LDL^T, qp.cpp:159-259]
-//     x~ = S^-1 ( sigma x - q + A' R (z - R^-1 y) )             [== head(n) of K^-1 rhs, qp.cpp:89-92]
+//     S = P + sigma I + A' R A = (W'W)^-1 (n x n, SPD)          [replaces the (n+m)^2 LDL^T, qp.cpp:159-259]
+//     x~ = W' W ( sigma x - q + A' R (z - R^-1 y) )             [== head(n) of K^-1 rhs, qp.cpp:89-92]
 //     z~ = A x~                                                 [== z_prev + R^-1 (nu - y),  qp.cpp:93]
 // followed by the verbatim x / z / y updates (qp.cpp:96-103), the residual/termination block
 // (qp.cpp:105-123, 316-371) and adaptive rho (qp.cpp:125-144, 296-314, 333-341).
@@ -66,11 +66,21 @@ __device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int
     __syncthreads();
 }
 
-// S = Psym + sigma I + A' diag(rho) A, then in-place Gauss-Jordan inversion (S is SPD: no pivoting).
+// Factor of the Schur matrix S = Psym + sigma I + A' diag(rho) A (SPD):
+//     S = D_J^1/2 (L D L') D_J^1/2      (Jacobi scaling to unit diagonal, then LDL' without pivoting)
+//     W = D^-1/2 L^-1 D_J^-1/2          (lower triangular)      =>   S^-1 = W' W
+// The solve x~ = W'(W b) is two mat-vecs with cond(W) = sqrt(cond(S)); multiplying by an explicit
+// S^-1 instead costs ~2 more digits in the ADMM iterates (measured: 1.6e-11 vs 2e-13 after 50
+// iterations at cond(S) = 4e3), which matters once adaptive rho amplifies differences.
+// L^-1 is formed in place by forward elimination of [S | I]: after step k the strictly-lower part of
+// column k holds -l_ik, later steps apply their row operations to it as well; the "+1" on the pivot
+// position of the broadcast row makes the generic rank-1 update write that entry (pivots are <= 1
+// after the scaling, so there is no cancellation).
+// Wm: n*n col-major result W; Wt: n*n row-major copy (W' with coalesced rows). row/sj/dsv: LDS [n].
 // Returns false (block-uniform) on a non-positive / non-finite pivot  => NUMERICAL_ISSUES.
 template <typename T, typename TIN>
-__device__ bool factor_schur_inverse(int n, int m, const TIN *__restrict__ P, const T *__restrict__ At, const T *rho,
-                                     T sigma, T *__restrict__ Sinv, T *row, T *col) {
+__device__ bool factor_schur(int n, int m, const TIN *__restrict__ P, const T *__restrict__ At, const T *rho, T sigma,
+                             T *__restrict__ Wm, T *__restrict__ Wt, T *row, T *sj, T *dsv) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int nn = n * n;
     for (int e = tid; e < nn; e += nt) {
@@ -85,32 +95,49 @@ __device__ bool factor_schur_inverse(int n, int m, const TIN *__restrict__ P, co
             s1 += At[(long)(k + 1) * n + i] * rho[k + 1] * At[(long)(k + 1) * n + j];
         }
         if (k < m) s0 += At[(long)k * n + i] * rho[k] * At[(long)k * n + j];
-        Sinv[e] = acc + (s0 + s1);
+        Wm[e] = acc + (s0 + s1);
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += nt) sj[j] = Wm[(long)j * n + j];
+    __syncthreads();
+    bool bad = false;
+    for (int j = 0; j < n; j++) {
+        const T d = sj[j];
+        if (!(d > T(0)) || !(d * T(0) == T(0))) bad = true;  // uniform: every thread scans the same LDS words
+    }
+    __syncthreads();
+    if (bad) return false;
+    for (int j = tid; j < n; j += nt) sj[j] = T(1) / (T)sqrt((double)sj[j]);
+    __syncthreads();
+    for (int e = tid; e < nn; e += nt) {
+        const int j = e / n, i = e - j * n;
+        Wm[e] = Wm[e] * sj[i] * sj[j];
     }
     __syncthreads();
     for (int k = 0; k < n; k++) {
-        for (int i = tid; i < n; i += nt) {
-            col[i] = Sinv[(long)k * n + i];
-            row[i] = Sinv[(long)i * n + k];
-        }
+        for (int j = tid; j < n; j += nt) row[j] = Wm[(long)j * n + k];
         __syncthreads();
         const T d = row[k];
-        if (!(d > T(0)) || !(d * T(0) == T(0))) return false;  // uniform: every thread reads the same LDS word
+        if (!(d > T(0)) || !(d * T(0) == T(0))) return false;
         const T dinv = T(1) / d;
+        if (tid == 0) dsv[k] = d;
         for (int e = tid; e < nn; e += nt) {
             const int j = e / n, i = e - j * n;
-            const T rkj = (j == k ? T(1) : row[j]) * dinv;
-            T v;
-            if (i == k) {
-                v = rkj;
-            } else {
-                const T base = (j == k) ? T(0) : Sinv[e];
-                v = base - col[i] * rkj;
+            if (i > k) {
+                const T g = (j == k) ? d + T(1) : row[j];
+                Wm[e] = Wm[e] - (row[i] * dinv) * g;
             }
-            Sinv[e] = v;
         }
         __syncthreads();
     }
+    for (int e = tid; e < nn; e += nt) {
+        const int j = e / n, i = e - j * n;
+        const T rs = T(1) / (T)sqrt((double)dsv[i]);
+        const T v = (i > j ? Wm[e] * rs : (i == j ? rs : T(0))) * sj[j];
+        Wm[e] = v;
+        Wt[(long)i * n + j] = v;
+    }
+    __syncthreads();
     return true;
 }
 
@@ -158,7 +185,8 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
     T *sy = a.y + (long)qp * m;
     T *srho = a.rho_vec + (long)qp * m;
     int *sct = a.ctype + (long)qp * m;
-    T *Sinv = a.Sinv + (long)qp * n * n;
+    T *Wm = a.Sinv + (long)qp * 2 * n * n;  // factor W (col-major) followed by its row-major copy
+    T *Wt = Wm + (long)n * n;
     T *At = a.At + (long)qp * m * n;
 
     sqph_info info = a.info[qp];
@@ -210,7 +238,7 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
             At[e] = (T)gA[(long)j * m + i];
         }
         __syncthreads();
-        const bool ok = factor_schur_inverse<T, TIN>(n, m, gP, At, rho, a.sigma, Sinv, gjrow, gjcol);
+        const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, a.sigma, Wm, Wt, gjrow, gjcol, Px);
         __syncthreads();
         info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;
     } else {
@@ -245,7 +273,8 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
             matvec_cm<T>(At, n, n, m, w, b, part);  // b = A' w
             for (int j = tid; j < n; j += nt) b[j] = (sigma * x[j] - q[j]) + b[j];
             __syncthreads();
-            matvec_cm<T>(Sinv, n, n, n, b, xt, part);  // x~
+            matvec_cm<T>(Wm, n, n, n, b, Px, part);   // W b      (Px is scratch outside the checks)
+            matvec_cm<T>(Wt, n, n, n, Px, xt, part);  // x~ = W' (W b)
             matvec_cm<T>(gA, m, m, n, xt, zt, part);   // z~ = A x~
             for (int j = tid; j < n; j += nt) x[j] = alpha * xt[j] + one_m_alpha * x[j];
             for (int i = tid; i < m; i += nt) {
@@ -307,7 +336,7 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
                         }
                         info.rho_updates += 1;
                         __syncthreads();
-                        const bool ok = factor_schur_inverse<T, TIN>(n, m, gP, At, rho, sigma, Sinv, gjrow, gjcol);
+                        const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, sigma, Wm, Wt, gjrow, gjcol, Px);
                         __syncthreads();
                         if (!ok) {
                             info.status = SQPH_NUMERICAL_ISSUES;

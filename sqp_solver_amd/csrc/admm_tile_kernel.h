@@ -5,7 +5,7 @@
 // in VGPRs for the whole solve, so BOTH products of an ADMM iteration use the same registers:
 //        A' w : pb[t] = sum_s a[s][t] * w[8s+r]   -> reduce-scatter over the 8 lanes sharing c
 //        A x~ : pz[s] = sum_t a[s][t] * x~[TC c+t] -> reduce-scatter over the 8 lanes sharing r
-// The Schur factor S^-1 (n x n) is tiled the same way (lane (r,c) holds rows TC*c'+r, c'=0..7, and
+// The Schur factor W (n x n lower triangular, S^-1 = W'W; applied as x~ = W'(W b)) is tiled the same way (lane (r,c) holds rows TC*c'+r, c'=0..7, and
 // columns TC*c+t): in VGPRs for small tiles, in LDS ([element][lane], conflict-free) for large ones.
 // Vectors live "scattered" (each element owned by exactly one lane: m-index i = lane + 64k,
 // n-index j = TC*c + r for r < TC) and are all-gathered / reduce-scattered with whole-register
@@ -99,6 +99,31 @@ struct TileKernel {
         }
         return rs8<8, 16, 32>(px, c);
     }
+    // transpose product with the same tile: scattered vector y -> (M' y) scattered
+    static __device__ __forceinline__ T mul_sqT(const T (&si)[8][TC], T y, int r, int c) {
+        T yr[8];
+        ag8<8, 16, 32>(y, c, yr);  // yr[c'] = y[TC*c' + r]
+        T px[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) px[t] = 0;
+#pragma unroll
+        for (int cp = 0; cp < 8; cp++)
+#pragma unroll
+            for (int t = 0; t < TC; t++) px[t] = tfma(si[cp][t], yr[cp], px[t]);
+        return rs8<1, 2, 4>(px, r);
+    }
+    static __device__ __forceinline__ T mul_sqT_lds(const T *si_lds, int lane, T y, int r, int c) {
+        T yr[8];
+        ag8<8, 16, 32>(y, c, yr);
+        T px[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) px[t] = 0;
+#pragma unroll
+        for (int cp = 0; cp < 8; cp++)
+#pragma unroll
+            for (int t = 0; t < TC; t++) px[t] = tfma(si_lds[(cp * TC + t) * 64 + lane], yr[cp], px[t]);
+        return rs8<1, 2, 4>(px, r);
+    }
     // same product with the matrix streamed from global memory (used for P x at the rare checks)
     template <typename TM>
     static __device__ __forceinline__ T mul_sq_gmem(const TM *__restrict__ M, int n, int r, const T (&bc)[8], int c) {
@@ -156,8 +181,8 @@ struct TileKernel {
     }
 
     // ---------------------------------------------------------------- Schur factor
-    // S = Psym + sigma I + A' diag(rho) A as a register tile, inverted in place by symmetric sweeps
-    // (pivots of an SPD matrix are positive in any order, so no pivoting). On return si = S^-1.
+    // S = Psym + sigma I + A' diag(rho) A as a register tile, factored in place (no pivoting: S is SPD).
+    // On return si = W (lower triangular), S^-1 = W' W.
     // rho_lds: [MP] rho per row (0 in the padding). rowbuf: [NP + 8] LDS scratch. Returns false on a
     // non-positive / non-finite pivot (=> NUMERICAL_ISSUES), wave-uniform.
     static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const TIN *__restrict__ gA, int n, int m, T sigma,
@@ -221,20 +246,28 @@ struct TileKernel {
         for (int cp = 0; cp < 8; cp++)
 #pragma unroll
             for (int t = 0; t < TC; t++) si[cp][t] = si[cp][t] * srow[cp] * scol[t];
-        // symmetric sweeps; step k = TC*ck + rk processed rk-major so the column position is static
+        // Forward elimination of [S~ | I] in place (see admm_generic.h factor_schur for the algebra): after
+        // step k the strictly-lower part of column k holds the unit-lower L^-1 entries, the rest U = D L'.
+        // Row k lives in the lanes with r == rk (register row ck, static because ck is unrolled); it is
+        // broadcast through LDS with "d + 1" on the pivot position so the plain rank-1 update
+        //        a_ij -= (a_ki / d) * g_j ,  i > k          (a_ik == a_ki: the trailing block is symmetric)
+        // also writes a_ik = -l_ik.  Pivots are <= 1 after the Jacobi scaling, so that is cancellation-free.
         for (int e = lane; e < NP + 8; e += 64) rowbuf[e] = 0;
         __syncthreads();
         if (wave_nanmax(dg_bad ? T(1) : T(0)) != T(0)) return false;  // non-positive diagonal: not SPD
         bool ok_all = true;
+        T dsave[8];
 #pragma unroll
-        for (int rk = 0; rk < TC; rk++) {
-            for (int ck = 0; ck < 8; ck++) {
+        for (int cp = 0; cp < 8; cp++) dsave[cp] = T(1);
+#pragma unroll
+        for (int ck = 0; ck < 8; ck++) {
+#pragma unroll 1
+            for (int rk = 0; rk < TC; rk++) {
                 const int k = TC * ck + rk;
-                if (k >= n) break;
-                // column k (== row k by symmetry) lives in the lanes with c == ck: entries si[c'][rk]
-                if (c == ck && rvalid) {
+                if (k >= n || !ok_all) break;
+                if (r == rk) {
 #pragma unroll
-                    for (int cp = 0; cp < 8; cp++) rowbuf[TC * cp + r] = si[cp][rk];
+                    for (int t = 0; t < TC; t++) rowbuf[TC * c + t] = si[ck][t];
                 }
                 __syncthreads();
                 const T d = rowbuf[k];
@@ -243,33 +276,38 @@ struct TileKernel {
                     break;
                 }
                 const T dinv = T(1) / d;
-                T g[TC], fx[8], fh[8];
+                T g[TC], f[8];
 #pragma unroll
-                for (int t = 0; t < TC; t++) g[t] = rowbuf[TC * c + t];
+                for (int t = 0; t < TC; t++) {
+                    const T gt = rowbuf[TC * c + t];
+                    g[t] = (c == ck && t == rk) ? d + T(1) : gt;
+                }
 #pragma unroll
                 for (int cp = 0; cp < 8; cp++) {
-                    const T f = rvalid ? rowbuf[TC * cp + r] : T(0);
-                    const bool is_k = rvalid && (TC * cp + r == k);
-                    fx[cp] = is_k ? -dinv : f * dinv;        // exact new column-k entries
-                    fh[cp] = is_k ? (T(1) - dinv) : f * dinv;  // row k: g - (1 - 1/d) g == g/d
+                    const T gi = rowbuf[rvalid ? TC * cp + r : 0];
+                    f[cp] = (rvalid && TC * cp + r > k) ? gi * dinv : T(0);
                 }
                 __syncthreads();  // everyone has read rowbuf before the next step overwrites it
 #pragma unroll
                 for (int cp = 0; cp < 8; cp++)
 #pragma unroll
-                    for (int t = 0; t < TC; t++) si[cp][t] = tfma(-fh[cp], g[t], si[cp][t]);
-                if (c == ck) {
-#pragma unroll
-                    for (int cp = 0; cp < 8; cp++) si[cp][rk] = fx[cp];
-                }
+                    for (int t = 0; t < TC; t++) si[cp][t] = tfma(-f[cp], g[t], si[cp][t]);
+                dsave[ck] = (r == rk) ? d : dsave[ck];
             }
-            if (!ok_all) break;
         }
-        // swept matrix is -S~^-1 ; undo the scaling: S^-1 = D^-1/2 S~^-1 D^-1/2
+        // W = D^-1/2 L^-1 D_J^-1/2 : lower triangular, S^-1 = W' W
 #pragma unroll
-        for (int cp = 0; cp < 8; cp++)
+        for (int cp = 0; cp < 8; cp++) {
+            const int i = TC * cp + r;
+            const T rs = T(1) / (T)sqrt((double)dsave[cp]);
 #pragma unroll
-            for (int t = 0; t < TC; t++) si[cp][t] = -(si[cp][t] * srow[cp] * scol[t]);
+            for (int t = 0; t < TC; t++) {
+                const int j = TC * c + t;
+                const bool ok = rvalid && i < n && j < n;
+                const T v = i > j ? si[cp][t] * rs : (i == j ? rs : T(0));
+                si[cp][t] = ok ? v * scol[t] : T(0);
+            }
+        }
         return ok_all;
     }
 
@@ -450,11 +488,16 @@ struct TileKernel {
                 b = nvalid ? (sigma * x - q) + b : T(0);
                 T bc[8];
                 gather_cols(b, r, bc);
-                T xt;
-                if constexpr (SI_LDS)
-                    xt = mul_sq_lds(si_lds, lane, bc, c);
-                else
-                    xt = mul_sq(si, bc, c);
+                T xt;  // x~ = W' (W b)
+                if constexpr (SI_LDS) {
+                    T wb = mul_sq_lds(si_lds, lane, bc, c);
+                    wb = nvalid ? wb : T(0);
+                    xt = mul_sqT_lds(si_lds, lane, wb, r, c);
+                } else {
+                    T wb = mul_sq(si, bc, c);
+                    wb = nvalid ? wb : T(0);
+                    xt = mul_sqT(si, wb, r, c);
+                }
                 xt = nvalid ? xt : T(0);
                 T xc[8];
                 gather_cols(xt, r, xc);

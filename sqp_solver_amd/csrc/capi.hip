@@ -162,7 +162,7 @@ int sqph_create(sqph_solver **out, int device, int n, int m, int batch_capacity,
     alloc(&s->rho, B * e);
     alloc((void **)&s->ctype, B * mm * sizeof(int));
     alloc((void **)&s->info, B * sizeof(sqph_info));
-    alloc(&s->Sinv, B * (size_t)n * n * e);
+    alloc(&s->Sinv, B * 2 * (size_t)n * n * e);
     if (err == hipSuccess) {
         // every instance starts UNINITIALIZED (qp.hpp:74): status field = 4, rest 0
         sqph_info *h = new (std::nothrow) sqph_info[B];

@@ -28,7 +28,7 @@ struct KArgs {
     T *rho;       // [batch]      current scalar rho (QPSolver::rho, qp.hpp:228)
     sqph_info *info;  // [batch]
     // factor workspace
-    T *Sinv;      // [batch][n*n]  inverse of S = P + sigma I + A' diag(rho) A
+    T *Sinv;      // [batch][2*n*n] factor W of S = P + sigma I + A' diag(rho) A, S^-1 = W'W (tiled kernels use n*n)
     T *At;        // [batch][m*n]  row-major copy of A (generic kernel only; may be null for tiled kernels)
     // settings converted to Scalar
     T rho0, sigma, alpha, eps_rel, eps_abs, rho_tol;

@@ -66,7 +66,7 @@ class SimSolverBatch:
         self.rho = np.zeros(batch, np.float64)
         self.info_arr = np.zeros(batch, _capi.INFO_DTYPE)
         self.info_arr["status"] = 4
-        self.Sinv = np.zeros((batch, n * n), np.float64)
+        self.Sinv = np.zeros((batch, 2 * n * n), np.float64)
         self.At = np.zeros((batch, mm * n), np.float64)
 
     def _run(self, mode, P, q, A, l, u):

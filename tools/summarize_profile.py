@@ -1,0 +1,42 @@
+"""Condense a tools/profile_gpu.sh output directory into a short text summary (kept under profiles/)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+
+
+def main(out):
+    print("# rocprofv3 summary for", out)
+    for f in find(os.path.join(out, "trace"), "*kernel_stats.csv"):
+        print("\n## kernel stats (%s)" % os.path.relpath(f, out))
+        with open(f) as fh:
+            rows = list(csv.DictReader(fh))
+        for r in rows[:12]:
+            print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+    for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+        files = find(os.path.join(out, sub), "*counter_collection.csv")
+        for f in files:
+            acc = defaultdict(lambda: defaultdict(float))
+            cnt = defaultdict(set)
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    k = r.get("Kernel_Name", "?")
+                    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                    cnt[k].add(r.get("Dispatch_Id"))
+            print("\n## %s (%s) — per-dispatch averages" % (sub, os.path.relpath(f, out)))
+            for k in acc:
+                n = max(len(cnt[k]), 1)
+                if "admm" not in k:
+                    continue
+                print(k[:90], "dispatches", n)
+                for c, v in sorted(acc[k].items()):
+                    print("   %-28s %.6g" % (c, v / n))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
