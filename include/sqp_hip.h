@@ -110,7 +110,10 @@ enum {
      * 1: legacy-class semantics, include/unsupported/qp_solver.hpp:256-260 — it does reset. */
     SQPH_FLAG_LEGACY_COLD_START = 1,
     /* force the generic (global-memory) kernel even where a register-tiled one exists */
-    SQPH_FLAG_FORCE_GENERIC = 2
+    SQPH_FLAG_FORCE_GENERIC = 2,
+    /* prefer the single-wave register-butterfly kernels (admm_tile_kernel.h) over the workgroup-tiled
+     * ones (admm_wg_kernel.h); kept for A/B measurements */
+    SQPH_FLAG_WAVE_TILE = 4
 };
 
 void sqph_default_settings(sqph_settings *s);

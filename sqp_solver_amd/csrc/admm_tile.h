@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "admm_tile_kernel.h"
+#include "admm_wg_kernel.h"
 
 namespace sqph {
 
@@ -18,6 +19,20 @@ inline int tile_try_launch(const KArgs<T, TIN> &a, hipStream_t stream, const cha
     }
     SQPH_TILE_SHAPES(SQPH_TILE_CASE)
 #undef SQPH_TILE_CASE
+    return 0;
+}
+
+// workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
+template <typename TIN>
+inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
+#define SQPH_WG_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                                            \
+    if (a.m <= R_ * TR_ && a.n <= C_ * TC_) {                                                                                   \
+        hipLaunchKernelGGL((admm_wg_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
+        *name = "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_;                                                                    \
+        return hipGetLastError() == hipSuccess ? 1 : -1;                                                                        \
+    }
+    SQPH_WG_SHAPES(SQPH_WG_CASE)
+#undef SQPH_WG_CASE
     return 0;
 }
 

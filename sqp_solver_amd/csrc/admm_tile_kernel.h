@@ -38,8 +38,50 @@ struct MVec {
     T v[NS];
 };
 
-template <typename T, typename TIN, int TR, int TC, bool SI_LDS>
+// ---------------------------------------------------------------------------------------------
+// Collectives through LDS (XLDS = true).  Measured on gfx950 (tools/ubench): a lone wave issues one
+// VALU instruction per ~5 cycles whatever its type, so the register butterflies of wave_ops.h
+// (~45-50 VALU instructions per 8-value all-gather / reduce-scatter of doubles) dominated the
+// iteration.  The same exchanges cost 5-20 DS instructions when staged through a few hundred bytes
+// of LDS.  One wave owns its scratch, DS operations of a wave execute in order, so no s_barrier is
+// involved: __syncthreads() in a 64-thread workgroup is only a compiler-level fence here.
+// Layout strides are chosen so that ds_write_b64 / ds_read_b128 are bank-conflict free.
+// ---------------------------------------------------------------------------------------------
+typedef double sqph_d2 __attribute__((vector_size(16)));
+
+template <int TR>
+struct XlLayout {
+    static constexpr int ROWS_STRIDE = 18;  // per r; 2*18 dwords == 4 (mod 32)
+    static constexpr int O_ROWS = 0;        // [8][18]
+    static constexpr int O_COLS = 144;      // [64]
+    static constexpr int O_BLK = 208;       // [8][10]
+    static constexpr int O_RS = 288;        // reduce-scatter staging, shared
+    static constexpr int RS_COLS_STRIDE = 72;  // per c:  [8 t][8 r']
+    static constexpr int RS_BLK_STRIDE = 66;   // per r:  [8 c'][8 c'']
+    static constexpr int RS_ROWS_STRIDE = ((8 * TR + 13) / 16) * 16 + 2;  // per r: [TR s][8 c''], == 2 (mod 16)
+    static constexpr int RS_SIZE = (8 * RS_ROWS_STRIDE > 8 * RS_COLS_STRIDE) ? 8 * RS_ROWS_STRIDE : 8 * RS_COLS_STRIDE;
+    static constexpr int TOTAL = O_RS + RS_SIZE;
+};
+
+// 8 contiguous doubles (16-byte aligned) from LDS
+__device__ __forceinline__ void lds_read8(const double *p, double (&v)[8]) {
+    const sqph_d2 *q = reinterpret_cast<const sqph_d2 *>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const sqph_d2 t = q[k];
+        v[2 * k] = t[0];
+        v[2 * k + 1] = t[1];
+    }
+}
+__device__ __forceinline__ double lds_sum8(const double *p) {
+    double v[8];
+    lds_read8(p, v);
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
+template <typename T, typename TIN, int TR, int TC, bool SI_LDS, bool XLDS>
 struct TileKernel {
+    using XL = XlLayout<TR>;
     static constexpr int NS = (TR + 7) / 8;  // m-slots per lane (m <= 64*NS)
     static constexpr int MP = 8 * TR;        // padded m
     static constexpr int NP = 8 * TC;        // padded n
@@ -47,20 +89,98 @@ struct TileKernel {
 
     // ---------------------------------------------------------------- products on the A tile
     // scattered m-vector -> "row form": wr[s] = w[8s + r], s < TR (all-gather over lanes sharing r)
-    static __device__ __forceinline__ void gather_rows(const T (&w)[NS], int c, T (&wr)[8 * NS]) {
+    static __device__ __forceinline__ void gather_rows(const T (&w)[NS], int r, int c, T *xl, T (&wr)[8 * NS]) {
+        if constexpr (XLDS) {
+            T *buf = xl + XL::O_ROWS + XL::ROWS_STRIDE * r;
 #pragma unroll
-        for (int k = 0; k < NS; k++) {
-            T tmp[8];
-            ag8<8, 16, 32>(w[k], c, tmp);
+            for (int k = 0; k < NS; k++) buf[c + 8 * k] = w[k];
+            __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; e++) wr[8 * k + e] = tmp[e];
+            for (int k = 0; k < NS; k++) {
+                T tmp[8];
+                lds_read8(buf + 8 * k, tmp);
+#pragma unroll
+                for (int e = 0; e < 8; e++) wr[8 * k + e] = tmp[e];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                T tmp[8];
+                ag8<8, 16, 32>(w[k], c, tmp);
+#pragma unroll
+                for (int e = 0; e < 8; e++) wr[8 * k + e] = tmp[e];
+            }
         }
     }
     // scattered n-vector -> "column form": xc[t] = x[TC*c + t] (all-gather over lanes sharing c)
-    static __device__ __forceinline__ void gather_cols(T x, int r, T (&xc)[8]) { ag8<1, 2, 4>(x, r, xc); }
+    static __device__ __forceinline__ void gather_cols(T x, int r, int c, T *xl, T (&xc)[8]) {
+        if constexpr (XLDS) {
+            xl[XL::O_COLS + 8 * c + r] = x;
+            __syncthreads();
+            lds_read8(xl + XL::O_COLS + 8 * c, xc);
+        } else {
+            ag8<1, 2, 4>(x, r, xc);
+        }
+    }
+    // scattered n-vector -> "block form": yr[c'] = y[TC*c' + r] (all-gather over lanes sharing r)
+    static __device__ __forceinline__ void gather_blk(T y, int r, int c, T *xl, T (&yr)[8]) {
+        if constexpr (XLDS) {
+            xl[XL::O_BLK + 10 * r + c] = y;
+            __syncthreads();
+            lds_read8(xl + XL::O_BLK + 10 * r, yr);
+        } else {
+            ag8<8, 16, 32>(y, c, yr);
+        }
+    }
+    // reduce-scatter over the lanes sharing c: lane r receives sum_r' pb_{r'}[r]
+    static __device__ __forceinline__ T reduce_cols(const T (&pb)[8], int r, int c, T *xl) {
+        if constexpr (XLDS) {
+            T *buf = xl + XL::O_RS + XL::RS_COLS_STRIDE * c;
+            __syncthreads();  // the staging area is shared by all reduce_*: order after the previous readers
+#pragma unroll
+            for (int t = 0; t < TC; t++) buf[8 * t + r] = pb[t];
+            __syncthreads();
+            return lds_sum8(buf + 8 * (r < TC ? r : 0));
+        } else {
+            return rs8<1, 2, 4>(pb, r);
+        }
+    }
+    // reduce-scatter over the lanes sharing r: lane c receives sum_c'' px_{c''}[c]
+    static __device__ __forceinline__ T reduce_blk(const T (&px)[8], int r, int c, T *xl) {
+        if constexpr (XLDS) {
+            T *buf = xl + XL::O_RS + XL::RS_BLK_STRIDE * r;
+            __syncthreads();
+#pragma unroll
+            for (int cp = 0; cp < 8; cp++) buf[8 * cp + c] = px[cp];
+            __syncthreads();
+            return lds_sum8(buf + 8 * c);
+        } else {
+            return rs8<8, 16, 32>(px, c);
+        }
+    }
+    // reduce-scatter of row partials over the lanes sharing r: slot k of lane c receives row s = c + 8k
+    static __device__ __forceinline__ void reduce_rows(const T (&pz)[8 * NS], int r, int c, T *xl, T (&out)[NS]) {
+        if constexpr (XLDS) {
+            T *buf = xl + XL::O_RS + XL::RS_ROWS_STRIDE * r;
+            __syncthreads();
+#pragma unroll
+            for (int s_ = 0; s_ < TR; s_++) buf[8 * s_ + c] = pz[s_];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NS; k++) out[k] = lds_sum8(buf + 8 * ((c + 8 * k) < TR ? (c + 8 * k) : 0));
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                T tmp[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) tmp[e] = pz[8 * k + e];
+                out[k] = rs8<8, 16, 32>(tmp, c);
+            }
+        }
+    }
 
     // A' w  -> scattered n-vector
-    static __device__ __forceinline__ T mul_AT(const T (&a)[TR][TC], const T (&wr)[8 * NS], int r) {
+    static __device__ __forceinline__ T mul_AT(const T (&a)[TR][TC], const T (&wr)[8 * NS], int r, int c, T *xl) {
         T pb[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) pb[t] = 0;
@@ -68,10 +188,10 @@ struct TileKernel {
         for (int s = 0; s < TR; s++)
 #pragma unroll
             for (int t = 0; t < TC; t++) pb[t] = tfma(a[s][t], wr[s], pb[t]);
-        return rs8<1, 2, 4>(pb, r);
+        return reduce_cols(pb, r, c, xl);
     }
     // A x -> scattered m-vector
-    static __device__ __forceinline__ void mul_A(const T (&a)[TR][TC], const T (&xc)[8], int c, T (&out)[NS]) {
+    static __device__ __forceinline__ void mul_A(const T (&a)[TR][TC], const T (&xc)[8], int r, int c, T *xl, T (&out)[NS]) {
         T pz[8 * NS];
 #pragma unroll
         for (int s = 0; s < 8 * NS; s++) pz[s] = 0;
@@ -79,16 +199,10 @@ struct TileKernel {
         for (int t = 0; t < TC; t++)
 #pragma unroll
             for (int s = 0; s < TR; s++) pz[s] = tfma(a[s][t], xc[t], pz[s]);
-#pragma unroll
-        for (int k = 0; k < NS; k++) {
-            T tmp[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) tmp[e] = pz[8 * k + e];
-            out[k] = rs8<8, 16, 32>(tmp, c);
-        }
+        reduce_rows(pz, r, c, xl, out);
     }
     // (n x n matrix tiled as si[c'][t]) * column-form vector -> scattered n-vector
-    static __device__ __forceinline__ T mul_sq(const T (&si)[8][TC], const T (&bc)[8], int c) {
+    static __device__ __forceinline__ T mul_sq(const T (&si)[8][TC], const T (&bc)[8], int r, int c, T *xl) {
         T px[8];
 #pragma unroll
         for (int cp = 0; cp < 8; cp++) {
@@ -97,12 +211,12 @@ struct TileKernel {
             for (int t = 0; t < TC; t++) acc = tfma(si[cp][t], bc[t], acc);
             px[cp] = acc;
         }
-        return rs8<8, 16, 32>(px, c);
+        return reduce_blk(px, r, c, xl);
     }
     // transpose product with the same tile: scattered vector y -> (M' y) scattered
-    static __device__ __forceinline__ T mul_sqT(const T (&si)[8][TC], T y, int r, int c) {
+    static __device__ __forceinline__ T mul_sqT(const T (&si)[8][TC], T y, int r, int c, T *xl) {
         T yr[8];
-        ag8<8, 16, 32>(y, c, yr);  // yr[c'] = y[TC*c' + r]
+        gather_blk(y, r, c, xl, yr);  // yr[c'] = y[TC*c' + r]
         T px[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) px[t] = 0;
@@ -110,11 +224,11 @@ struct TileKernel {
         for (int cp = 0; cp < 8; cp++)
 #pragma unroll
             for (int t = 0; t < TC; t++) px[t] = tfma(si[cp][t], yr[cp], px[t]);
-        return rs8<1, 2, 4>(px, r);
+        return reduce_cols(px, r, c, xl);
     }
-    static __device__ __forceinline__ T mul_sqT_lds(const T *si_lds, int lane, T y, int r, int c) {
+    static __device__ __forceinline__ T mul_sqT_lds(const T *si_lds, int lane, T y, int r, int c, T *xl) {
         T yr[8];
-        ag8<8, 16, 32>(y, c, yr);
+        gather_blk(y, r, c, xl, yr);
         T px[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) px[t] = 0;
@@ -122,11 +236,11 @@ struct TileKernel {
         for (int cp = 0; cp < 8; cp++)
 #pragma unroll
             for (int t = 0; t < TC; t++) px[t] = tfma(si_lds[(cp * TC + t) * 64 + lane], yr[cp], px[t]);
-        return rs8<1, 2, 4>(px, r);
+        return reduce_cols(px, r, c, xl);
     }
     // same product with the matrix streamed from global memory (used for P x at the rare checks)
     template <typename TM>
-    static __device__ __forceinline__ T mul_sq_gmem(const TM *__restrict__ M, int n, int r, const T (&bc)[8], int c) {
+    static __device__ __forceinline__ T mul_sq_gmem(const TM *__restrict__ M, int n, int r, const T (&bc)[8], int c, T *xl) {
         T px[8];
 #pragma unroll
         for (int cp = 0; cp < 8; cp++) {
@@ -140,9 +254,9 @@ struct TileKernel {
             }
             px[cp] = acc;
         }
-        return rs8<8, 16, 32>(px, c);
+        return reduce_blk(px, r, c, xl);
     }
-    static __device__ __forceinline__ T mul_sq_lds(const T *si_lds, int lane, const T (&bc)[8], int c) {
+    static __device__ __forceinline__ T mul_sq_lds(const T *si_lds, int lane, const T (&bc)[8], int r, int c, T *xl) {
         T px[8];
 #pragma unroll
         for (int cp = 0; cp < 8; cp++) {
@@ -151,7 +265,7 @@ struct TileKernel {
             for (int t = 0; t < TC; t++) acc = tfma(si_lds[(cp * TC + t) * 64 + lane], bc[t], acc);
             px[cp] = acc;
         }
-        return rs8<8, 16, 32>(px, c);
+        return reduce_blk(px, r, c, xl);
     }
 
     // ---------------------------------------------------------------- tile loads
@@ -324,7 +438,7 @@ struct TileKernel {
     }
 
     // ---------------------------------------------------------------- the kernel body
-    static __device__ void run(const KArgs<T, TIN> &a, T *rho_lds, T *rowbuf, T *si_lds) {
+    static __device__ void run(const KArgs<T, TIN> &a, T *rho_lds, T *rowbuf, T *si_lds, T *xl) {
         const int lane = threadIdx.x & 63;
         const int r = lane & 7, c = lane >> 3;
         const int qp = blockIdx.x;
@@ -417,6 +531,7 @@ struct TileKernel {
 
         auto publish_rho = [&]() {
             // rho per constraint row for the factor routine (0 in the padding)
+            __syncthreads();  // rho_lds aliases the reduce staging area
 #pragma unroll
             for (int k = 0; k < NS; k++) rho_lds[lane + 64 * k] = mvalid[k] ? rho[k] : T(0);
             __syncthreads();
@@ -483,26 +598,26 @@ struct TileKernel {
 #pragma unroll
                 for (int k = 0; k < NS; k++) w[k] = mvalid[k] ? rho[k] * (z[k] - rinv[k] * y[k]) : T(0);
                 T wr[8 * NS];
-                gather_rows(w, c, wr);
-                T b = mul_AT(at, wr, r);
+                gather_rows(w, r, c, xl, wr);
+                T b = mul_AT(at, wr, r, c, xl);
                 b = nvalid ? (sigma * x - q) + b : T(0);
                 T bc[8];
-                gather_cols(b, r, bc);
+                gather_cols(b, r, c, xl, bc);
                 T xt;  // x~ = W' (W b)
                 if constexpr (SI_LDS) {
-                    T wb = mul_sq_lds(si_lds, lane, bc, c);
+                    T wb = mul_sq_lds(si_lds, lane, bc, r, c, xl);
                     wb = nvalid ? wb : T(0);
-                    xt = mul_sqT_lds(si_lds, lane, wb, r, c);
+                    xt = mul_sqT_lds(si_lds, lane, wb, r, c, xl);
                 } else {
-                    T wb = mul_sq(si, bc, c);
+                    T wb = mul_sq(si, bc, r, c, xl);
                     wb = nvalid ? wb : T(0);
-                    xt = mul_sqT(si, wb, r, c);
+                    xt = mul_sqT(si, wb, r, c, xl);
                 }
                 xt = nvalid ? xt : T(0);
                 T xc[8];
-                gather_cols(xt, r, xc);
+                gather_cols(xt, r, c, xl, xc);
                 T zt[NS];
-                mul_A(at, xc, c, zt);
+                mul_A(at, xc, r, c, xl, zt);
                 x = alpha * xt + oma * x;
 #pragma unroll
                 for (int k = 0; k < NS; k++) {
@@ -519,16 +634,16 @@ struct TileKernel {
                 if (check || adapt) {
                     // update_state + residuals, qp.cpp:316-331, 353-361
                     T xcur[8];
-                    gather_cols(x, r, xcur);
+                    gather_cols(x, r, c, xl, xcur);
                     T Ax[NS];
-                    mul_A(at, xcur, c, Ax);
+                    mul_A(at, xcur, r, c, xl, Ax);
                     T yr[8 * NS];
-                    gather_rows(y, c, yr);
-                    const T ATy = mul_AT(at, yr, r);
+                    gather_rows(y, r, c, xl, yr);
+                    const T ATy = mul_AT(at, yr, r, c, xl);
                     int n_c = n, r_c = r, c_c = c;
                     const TIN *gP_c = gP;
                     SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gP_c);
-                    const T Px = mul_sq_gmem<TIN>(gP_c, n_c, r_c, xcur, c_c);  // full P (both triangles), as qp.cpp:324
+                    const T Px = mul_sq_gmem<TIN>(gP_c, n_c, r_c, xcur, c_c, xl);  // full P (both triangles), as qp.cpp:324
                     T v[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                     for (int k = 0; k < NS; k++)
@@ -604,12 +719,15 @@ struct TileKernel {
 };
 
 // WPE = waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
-template <typename T, typename TIN, int TR, int TC, bool SI_LDS, int WPE>
+template <typename T, typename TIN, int TR, int TC, bool SI_LDS, int WPE, bool XLDS = true>
 __global__ __launch_bounds__(64, WPE) void admm_tile_kernel(KArgs<T, TIN> a) {
-    __shared__ T rho_lds[64 * ((TR + 7) / 8)];
-    __shared__ T rowbuf[8 * TC + 8];
-    __shared__ T si_lds[SI_LDS ? 8 * TC * 64 : 1];
-    TileKernel<T, TIN, TR, TC, SI_LDS>::run(a, rho_lds, rowbuf, si_lds);
+    // factor-time scratch (rho per row, broadcast row) aliases the reduce-scatter staging area
+    __shared__ __attribute__((aligned(16))) T xl[XlLayout<TR>::TOTAL];
+    __shared__ __attribute__((aligned(16))) T si_lds[SI_LDS ? 8 * TC * 64 : 2];
+    static_assert(XlLayout<TR>::RS_SIZE >= 64 * ((TR + 7) / 8) + 8 * TC + 8, "factor scratch must fit the staging area");
+    T *rho_lds = xl + XlLayout<TR>::O_RS;
+    T *rowbuf = rho_lds + 64 * ((TR + 7) / 8);
+    TileKernel<T, TIN, TR, TC, SI_LDS, XLDS>::run(a, rho_lds, rowbuf, si_lds, xl);
 }
 
 // tile shapes compiled into the library: {TR, TC, SI_LDS, WPE}; first fit wins

@@ -1,0 +1,619 @@
+// Workgroup-tiled ADMM kernel: NW wavefronts (64*NW lanes) per QP, matrices in VGPRs, vectors in LDS.
+//
+// Lanes form an R x C grid (t = c*R + r, R*C = 64*NW).  Lane (r,c) keeps two register tiles for the
+// whole solve:
+//     at[s][k] = A[R*s + r][TC*c + k]     s < TR, k < TC      (rows cyclic over r, columns blocked by c)
+//     wt[u][k] = W[R*u + r][TC*c + k]     u < TW, k < TC      (W lower triangular, S^-1 = W'W)
+// so that A x / A'w and W b / W'y all run out of the same registers.  Vectors never live in more than
+// one lane's registers: a product is   gather operand from LDS -> FMAs on the tile -> write partial sums
+// to an LDS staging area -> owners (lane t owns element t) reduce them.   Measured on gfx950
+// (tools/ubench): one wave issues one VALU instruction every ~5 cycles whatever the opcode, two waves on
+// a SIMD bring that to ~3.5, four to ~2.5 — so the kernel is organised to (a) keep the instruction count
+// per iteration close to the FMA count (LDS moves 16 B per lane per instruction, whole-register
+// butterflies cost ~45 VALU instructions per 8-value exchange of doubles) and (b) fit two or more waves
+// per SIMD (a 50x100 QP is split over two waves: 98 + 56 VGPRs of tiles per lane).
+//
+// Numerics: identical formulas to admm_generic.h (reference src/qp.cpp:84-144 on the Schur-ordered
+// system, factor W of admm_generic.h:factor_schur), fp64 arithmetic, TIN inputs.
+#pragma once
+#include "block_ops.h"
+#include "kargs.h"
+
+#ifndef SQPH_OPAQUE_S
+#ifdef SQPH_SIM
+#define SQPH_OPAQUE_S(x) (void)0
+#define SQPH_OPAQUE_V(x) (void)0
+#else
+#define SQPH_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#define SQPH_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+#endif
+
+namespace sqph {
+
+typedef double sqph_v2 __attribute__((vector_size(16)));
+
+__device__ __forceinline__ double wg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// N contiguous doubles from a 16-byte aligned LDS address (N rounded up to even is read)
+template <int N>
+__device__ __forceinline__ void wg_read(const double *p, double (&v)[N]) {
+    const sqph_v2 *q = reinterpret_cast<const sqph_v2 *>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) {
+        const sqph_v2 t = q[k];
+        v[2 * k] = t[0];
+        v[2 * k + 1] = t[1];
+    }
+    if constexpr (N & 1) v[N - 1] = p[N - 1];
+}
+template <int N>
+__device__ __forceinline__ double wg_sum(const double *p) {
+    double v[N];
+    wg_read<N>(p, v);
+    double s0 = v[0], s1 = N > 1 ? v[1] : 0.0;
+#pragma unroll
+    for (int k = 2; k + 1 < N; k += 2) {
+        s0 += v[k];
+        s1 += v[k + 1];
+    }
+    if constexpr ((N & 1) && N > 1) s0 += v[N - 1];
+    return s0 + s1;
+}
+
+template <int NW, int R, int C, int TR, int TC, int TW>
+struct WgLayout {
+    static_assert(R * C == 64 * NW, "lane grid must cover the workgroup");
+    static constexpr int NT = 64 * NW;
+    static constexpr int MP = R * TR;  // padded m
+    static constexpr int NP = C * TC;  // padded n (columns)
+    static constexpr int NR = R * TW;  // padded n (rows of W)
+    static_assert(NP <= NT && NR >= NP && NR <= NT && MP <= NT, "owners: lane t owns n-element t and m-element t");
+    static constexpr int ev(int x) { return (x + 1) & ~1; }
+    static constexpr int TRp = ev(TR) + 2;  // row-gather stride per r    (w, y)
+    static constexpr int TWp = ev(TW) + 2;  // W-row gather stride per r  (y1)
+    static constexpr int TCp = ev(TC);      // column-gather stride per c (b, x~, x)
+    static constexpr int Rp = R + 2;        // staging stride per output for reductions over r
+    static constexpr int Cp = C + 2;        // staging stride per output for reductions over c
+    // LDS map (doubles)
+    static constexpr int O_ROWV = 0;                       // [R][TRp]  m-vector in row-gather order
+    static constexpr int O_COLV = O_ROWV + R * TRp;        // [C][TCp]  n-vector in column-gather order
+    static constexpr int O_WROW = O_COLV + C * TCp;        // [R][TWp]  n-vector in W-row-gather order
+    static constexpr int O_STAGE = ev(O_WROW + R * TWp);   // staging (aliased by all reductions and by the factor scratch)
+    static constexpr int mx(int a, int b) { return a > b ? a : b; }
+    static constexpr int STAGE = mx(mx(NP * Rp, NR * Cp), mx(MP * Cp, MP + 2 * NP + 16 + 8 * NT));
+    static constexpr int TOTAL = O_STAGE + STAGE;
+};
+
+template <typename TIN, int NW, int R, int C, int TR, int TC, int TW>
+struct WgKernel {
+    using T = double;
+    using L = WgLayout<NW, R, C, TR, TC, TW>;
+    static constexpr int NT = L::NT;
+
+    // ------------------------------------------------------------------ gathers (operand from LDS)
+    static __device__ __forceinline__ void put_rowv(T *lds, int r, int c, T v) { lds[L::O_ROWV + r * L::TRp + c] = v; }
+    static __device__ __forceinline__ void get_rowv(const T *lds, int r, T (&w)[TR]) { wg_read<TR>(lds + L::O_ROWV + r * L::TRp, w); }
+    static __device__ __forceinline__ void put_colv(T *lds, int j, T v) { lds[L::O_COLV + (j / TC) * L::TCp + (j % TC)] = v; }
+    static __device__ __forceinline__ void get_colv(const T *lds, int c, T (&x)[TC]) { wg_read<TC>(lds + L::O_COLV + c * L::TCp, x); }
+    static __device__ __forceinline__ void put_wrow(T *lds, int r, int c, T v) { lds[L::O_WROW + r * L::TWp + c] = v; }
+    static __device__ __forceinline__ void get_wrow(const T *lds, int r, T (&y)[TW]) { wg_read<TW>(lds + L::O_WROW + r * L::TWp, y); }
+
+    // ------------------------------------------------------------------ tile products -> staging
+    // A' w : partial over my rows for my TC columns; staged for a reduction over r
+    static __device__ __forceinline__ void stage_AT(const T (&at)[TR][TC], const T (&w)[TR], T *lds, int r, int c) {
+        T pb[TC];
+#pragma unroll
+        for (int k = 0; k < TC; k++) pb[k] = 0;
+#pragma unroll
+        for (int s = 0; s < TR; s++)
+#pragma unroll
+            for (int k = 0; k < TC; k++) pb[k] = wg_fma(at[s][k], w[s], pb[k]);
+        T *st = lds + L::O_STAGE;
+#pragma unroll
+        for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = pb[k];
+    }
+    // A x : partial over my columns for my TR rows; staged for a reduction over c
+    static __device__ __forceinline__ void stage_A(const T (&at)[TR][TC], const T (&x)[TC], T *lds, int r, int c) {
+        T pz[TR];
+#pragma unroll
+        for (int s = 0; s < TR; s++) pz[s] = 0;
+#pragma unroll
+        for (int k = 0; k < TC; k++)
+#pragma unroll
+            for (int s = 0; s < TR; s++) pz[s] = wg_fma(at[s][k], x[k], pz[s]);
+        T *st = lds + L::O_STAGE;
+#pragma unroll
+        for (int s = 0; s < TR; s++) st[(R * s + r) * L::Cp + c] = pz[s];
+    }
+    // M x with the square tile (rows R*u + r): staged for a reduction over c
+    static __device__ __forceinline__ void stage_W(const T (&wt)[TW][TC], const T (&x)[TC], T *lds, int r, int c) {
+        T py[TW];
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            T acc = 0;
+#pragma unroll
+            for (int k = 0; k < TC; k++) acc = wg_fma(wt[u][k], x[k], acc);
+            py[u] = acc;
+        }
+        T *st = lds + L::O_STAGE;
+#pragma unroll
+        for (int u = 0; u < TW; u++) st[(R * u + r) * L::Cp + c] = py[u];
+    }
+    // M' y with the square tile: staged for a reduction over r
+    static __device__ __forceinline__ void stage_WT(const T (&wt)[TW][TC], const T (&y)[TW], T *lds, int r, int c) {
+        T px[TC];
+#pragma unroll
+        for (int k = 0; k < TC; k++) px[k] = 0;
+#pragma unroll
+        for (int u = 0; u < TW; u++)
+#pragma unroll
+            for (int k = 0; k < TC; k++) px[k] = wg_fma(wt[u][k], y[u], px[k]);
+        T *st = lds + L::O_STAGE;
+#pragma unroll
+        for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = px[k];
+    }
+    // owner-side reductions (lane t owns output t)
+    static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? t : 0) * L::Rp); }
+    static __device__ __forceinline__ T reduce_over_c(const T *lds, int t) { return wg_sum<C>(lds + L::O_STAGE + t * L::Cp); }
+
+    // ------------------------------------------------------------------ tile loads
+    static __device__ __forceinline__ void load_A_tile(const TIN *__restrict__ gA, int n, int m, int r, int c, T (&at)[TR][TC]) {
+#pragma unroll
+        for (int k = 0; k < TC; k++) {
+            const int j = TC * c + k;
+#pragma unroll
+            for (int s = 0; s < TR; s++) {
+                const int i = R * s + r;
+                at[s][k] = (j < n && i < m) ? (T)gA[(long)j * m + i] : T(0);
+            }
+        }
+    }
+    template <typename TM>
+    static __device__ __forceinline__ void load_sq_tile(const TM *__restrict__ M, int n, int r, int c, T (&wt)[TW][TC]) {
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const int i = R * u + r;
+#pragma unroll
+            for (int k = 0; k < TC; k++) {
+                const int j = TC * c + k;
+                wt[u][k] = (i < n && j < n) ? (T)M[(long)j * n + i] : T(0);
+            }
+        }
+    }
+    static __device__ __forceinline__ void store_sq_tile(T *__restrict__ M, int n, int r, int c, const T (&wt)[TW][TC]) {
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const int i = R * u + r;
+#pragma unroll
+            for (int k = 0; k < TC; k++) {
+                const int j = TC * c + k;
+                if (i < n && j < n) M[(long)j * n + i] = wt[u][k];
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ factor (see admm_generic.h factor_schur)
+    // Scratch inside the staging area: rho[MP] | rowbuf[NP + 1] | sj[NP]   (doubles)
+    static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const TIN *__restrict__ gA, int n, int m, T sigma,
+                                                  T *lds, int t, int r, int c, T (&wt)[TW][TC]) {
+        T *rho_l = lds + L::O_STAGE;
+        T *rowbuf = rho_l + L::MP;
+        T *sjv = rowbuf + L::NP + 2;
+        int ir[TW], jc[TC];
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const int i = R * u + r;
+            ir[u] = i < n ? i : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < TC; k++) {
+            const int j = TC * c + k;
+            jc[k] = j < n ? j : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < TW; u++)
+#pragma unroll
+            for (int k = 0; k < TC; k++) wt[u][k] = 0;
+        // S = A' diag(rho) A : rows of A streamed from global memory (L1/L2 hits after the first touch)
+#pragma unroll 2
+        for (int i = 0; i < m; i++) {
+            const T ri = rho_l[i];
+            T a1[TW], a2[TC];
+#pragma unroll
+            for (int u = 0; u < TW; u++) a1[u] = (T)gA[(long)ir[u] * m + i] * ri;
+#pragma unroll
+            for (int k = 0; k < TC; k++) a2[k] = (T)gA[(long)jc[k] * m + i];
+#pragma unroll
+            for (int u = 0; u < TW; u++)
+#pragma unroll
+                for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
+        }
+        for (int e = t; e < L::NP + 2; e += NT) {
+            rowbuf[e] = 0;
+            if (e < L::NP) sjv[e] = T(1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const int i = R * u + r;
+#pragma unroll
+            for (int k = 0; k < TC; k++) {
+                const int j = TC * c + k;
+                const bool ok = i < n && j < n;
+                const int lo = i > j ? i : j, hi = i > j ? j : i;
+                // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>)
+                const T p = ok ? (T)gP[(long)hi * n + lo] : T(0);
+                wt[u][k] = ok ? (wt[u][k] + p + (i == j ? sigma : T(0))) : T(0);
+                if (ok && i == j) sjv[j] = wt[u][k];  // the diagonal, for the Jacobi scaling
+            }
+        }
+        __syncthreads();
+        // non-positive / non-finite diagonal => not SPD (block-uniform decision through LDS)
+        bool bad = false;
+        for (int j = 0; j < n; j++) {
+            const T d = sjv[j];
+            bad = bad || !(d > T(0)) || !(d * T(0) == T(0));
+        }
+        __syncthreads();
+        if (bad) return false;
+        if (t < n) sjv[t] = T(1) / (T)sqrt((double)sjv[t]);
+        __syncthreads();
+        T srow[TW], scol[TC];
+#pragma unroll
+        for (int u = 0; u < TW; u++) srow[u] = sjv[ir[u]];
+#pragma unroll
+        for (int k = 0; k < TC; k++) scol[k] = sjv[jc[k]];
+#pragma unroll
+        for (int u = 0; u < TW; u++)
+#pragma unroll
+            for (int k = 0; k < TC; k++) wt[u][k] = wt[u][k] * srow[u] * scol[k];
+        // forward elimination of [S~ | I] in place; row k = R*u + rr is broadcast through LDS
+        bool ok_all = true;
+        T dsave[TW];
+#pragma unroll
+        for (int u = 0; u < TW; u++) dsave[u] = T(1);
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+#pragma unroll 1
+            for (int rr = 0; rr < R; rr++) {
+                const int k = R * u + rr;
+                if (k >= n || !ok_all) break;
+                if (r == rr) {
+#pragma unroll
+                    for (int q = 0; q < TC; q++) rowbuf[TC * c + q] = wt[u][q];
+                }
+                __syncthreads();
+                const T d = rowbuf[k];
+                if (!(d > T(0)) || !(d * T(0) == T(0))) {
+                    ok_all = false;
+                    break;
+                }
+                const T dinv = T(1) / d;
+                T g[TC], f[TW];
+#pragma unroll
+                for (int q = 0; q < TC; q++) {
+                    const T gq = rowbuf[TC * c + q];
+                    g[q] = (TC * c + q == k) ? d + T(1) : gq;
+                }
+#pragma unroll
+                for (int v = 0; v < TW; v++) {
+                    const int i = R * v + r;
+                    const T gi = rowbuf[i < L::NP ? i : 0];
+                    f[v] = (i > k && i < n) ? gi * dinv : T(0);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int v = 0; v < TW; v++)
+#pragma unroll
+                    for (int q = 0; q < TC; q++) wt[v][q] = wg_fma(-f[v], g[q], wt[v][q]);
+                dsave[u] = (r == rr) ? d : dsave[u];
+            }
+        }
+        // W = D^-1/2 L^-1 D_J^-1/2
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const int i = R * u + r;
+            const T rs = T(1) / (T)sqrt((double)dsave[u]);
+#pragma unroll
+            for (int k = 0; k < TC; k++) {
+                const int j = TC * c + k;
+                const bool ok = i < n && j < n;
+                const T v = i > j ? wt[u][k] * rs : (i == j ? rs : T(0));
+                wt[u][k] = ok ? v * scol[k] : T(0);
+            }
+        }
+        return ok_all;
+    }
+
+    // ------------------------------------------------------------------ kernel body
+    static __device__ void run(const KArgs<T, TIN> &a, T *lds) {
+        const int t = threadIdx.x;
+        const int r = t % R, c = t / R;
+        const int qp = blockIdx.x;
+        if (qp >= a.batch) return;
+        const int n = a.n, m = a.m;
+        const TIN *gP = a.P + (long)qp * a.sP;
+        const TIN *gq = a.q + (long)qp * a.sq;
+        const TIN *gA = a.A + (long)qp * a.sA;
+        const TIN *gl = a.l + (long)qp * a.sl;
+        const TIN *gu = a.u + (long)qp * a.su;
+        T *sx = a.x + (long)qp * n;
+        T *sz = a.z + (long)qp * m;
+        T *sy = a.y + (long)qp * m;
+        T *srho = a.rho_vec + (long)qp * m;
+        int *sct = a.ctype + (long)qp * m;
+        T *gW = a.Sinv + (long)qp * 2 * n * n;
+
+        sqph_info info = a.info[qp];
+        T rho_s = a.rho[qp];
+        const int mode = a.mode;
+        if (!(mode & (MODE_SETUP | MODE_UPDATE)) &&
+            (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
+            return;  // qp.cpp:68-71 (block-uniform)
+
+        // lane t owns x[t], q[t] (t < n) and z[t], y[t], l[t], u[t], rho[t] (t < m)
+        const bool nown = t < n, mown = t < m;
+        const T INF = T(1) / T(0);
+        T q = nown ? (T)gq[t] : T(0);
+        T x = 0, z = 0, y = 0;
+        T lo = mown ? (T)gl[t] : -INF, up = mown ? (T)gu[t] : INF;
+        T rho = T(1), rinv = T(1);
+        int ctype = SQPH_INEQUALITY_CONSTRAINT;
+
+        if (mode & (MODE_SETUP | MODE_UPDATE)) {
+            rho_s = a.rho0;
+            if (mown) {
+                if (lo < -a.loose_thresh && up > a.loose_thresh)
+                    ctype = SQPH_LOOSE_BOUNDS;
+                else if (up - lo < a.eq_tol)
+                    ctype = SQPH_EQUALITY_CONSTRAINT;
+                rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
+                rinv = T(1) / rho;
+                sct[t] = ctype;
+                srho[t] = rho;
+            }
+            info.rho_updates += 1;
+            if (!(mode & MODE_SETUP)) {
+                if (nown) x = sx[t];
+                if (mown) {
+                    z = sz[t];
+                    y = sy[t];
+                }
+            }
+        } else {
+            if (nown) x = sx[t];
+            if (mown) {
+                z = sz[t];
+                y = sy[t];
+                rho = srho[t];
+                rinv = T(1) / rho;
+                ctype = sct[t];
+            }
+        }
+
+        T wt[TW][TC];
+        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
+        bool solving = false;
+        bool state_dirty = (mode & MODE_SETUP) != 0;
+        if (!need_factor) load_sq_tile<T>(gW, n, r, c, wt);
+        const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
+        int iter = 1;
+        for (;;) {
+            if (need_factor) {
+                __syncthreads();
+                if (t < L::MP) lds[L::O_STAGE + t] = mown ? rho : T(0);
+                __syncthreads();
+                int n_f = n, m_f = m, r_f = r, c_f = c, t_f = t;
+                const TIN *gA_f = gA, *gP_f = gP;
+                SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(m_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_V(t_f);
+                SQPH_OPAQUE_S(gA_f); SQPH_OPAQUE_S(gP_f);
+                const bool ok = factor(gP_f, gA_f, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt);
+                store_sq_tile(gW, n_f, r_f, c_f, wt);
+                __syncthreads();
+                need_factor = false;
+                if (!solving) {
+                    info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
+                } else if (!ok) {
+                    info.status = SQPH_NUMERICAL_ISSUES;  // qp.cpp:139-142: break, iter not advanced
+                    break;
+                } else {
+                    iter++;  // the for-loop increment of the iteration that requested the new factor
+                }
+            }
+            if (!(mode & MODE_SOLVE) || info.status == SQPH_NUMERICAL_ISSUES || info.status == SQPH_UNINITIALIZED) break;
+            if (!solving) {
+                solving = true;
+                state_dirty = true;
+                if ((mode & MODE_COLD_RESET) && !a.warm_start) x = z = y = 0;
+            }
+            T at[TR][TC];
+            {
+                int n_t = n, m_t = m, r_t = r, c_t = c;
+                const TIN *gA_t = gA;
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_S(m_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t); SQPH_OPAQUE_S(gA_t);
+                load_A_tile(gA_t, n_t, m_t, r_t, c_t, at);  // (re)loaded after every factor: its registers were free meanwhile
+            }
+            for (; iter <= a.max_iter; iter++) {
+                // w = R (z - R^-1 y)   [rhs tail of qp.cpp:275 pre-multiplied by R]
+                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
+                __syncthreads();
+                {
+                    T w[TR];
+                    get_rowv(lds, r, w);
+                    stage_AT(at, w, lds, r, c);
+                }
+                __syncthreads();
+                if (t < L::NP) {
+                    const T b = nown ? (sigma * x - q) + reduce_over_r(lds, t) : T(0);
+                    put_colv(lds, t, b);
+                }
+                __syncthreads();
+                {
+                    T b[TC];
+                    get_colv(lds, c, b);
+                    stage_W(wt, b, lds, r, c);  // W b
+                }
+                __syncthreads();
+                if (t < L::NR) put_wrow(lds, r, c, nown ? reduce_over_c(lds, t) : T(0));
+                __syncthreads();
+                {
+                    T y1[TW];
+                    get_wrow(lds, r, y1);
+                    stage_WT(wt, y1, lds, r, c);  // W' (W b)
+                }
+                __syncthreads();
+                T xt = 0;
+                if (t < L::NP) {
+                    xt = nown ? reduce_over_r(lds, t) : T(0);
+                    put_colv(lds, t, xt);
+                }
+                __syncthreads();
+                {
+                    T xc[TC];
+                    get_colv(lds, c, xc);
+                    stage_A(at, xc, lds, r, c);  // z~ = A x~
+                }
+                __syncthreads();
+                x = alpha * xt + oma * x;
+                if (mown) {
+                    const T zt = reduce_over_c(lds, t);
+                    const T zr = alpha * zt + oma * z;
+                    T zn = zr + rinv * y;
+                    zn = zn < lo ? lo : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
+                    zn = zn > up ? up : zn;
+                    y = y + rho * (zr - zn);
+                    z = zn;
+                }
+
+                const bool check = a.check_termination != 0 && (iter % a.check_termination == 0);
+                const bool adapt = a.adaptive_rho && (iter % a.adaptive_rho_interval == 0);
+                if (check || adapt) {
+                    // update_state + residuals, qp.cpp:316-331, 353-361
+                    __syncthreads();
+                    if (t < L::NP) put_colv(lds, t, nown ? x : T(0));
+                    if (t < L::MP) put_rowv(lds, r, c, mown ? y : T(0));
+                    __syncthreads();
+                    T xc[TC];
+                    get_colv(lds, c, xc);
+                    stage_A(at, xc, lds, r, c);
+                    __syncthreads();
+                    const T Ax = mown ? reduce_over_c(lds, t) : T(0);
+                    __syncthreads();
+                    {
+                        T yr[TR];
+                        get_rowv(lds, r, yr);
+                        stage_AT(at, yr, lds, r, c);
+                    }
+                    __syncthreads();
+                    const T ATy = nown ? reduce_over_r(lds, t) : T(0);
+                    __syncthreads();
+                    {
+                        int n_c = n, r_c = r, c_c = c;
+                        const TIN *gP_c = gP;
+                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gP_c);
+                        T pt[TW][TC];
+                        load_sq_tile<TIN>(gP_c, n_c, r_c, c_c, pt);  // full P (both triangles), as qp.cpp:324
+                        stage_W(pt, xc, lds, r, c);
+                    }
+                    __syncthreads();
+                    const T Px = nown ? reduce_over_c(lds, t) : T(0);
+                    __syncthreads();
+                    T v[7] = {0, 0, 0, 0, 0, 0, 0};
+                    if (mown) {
+                        v[0] = tabs(Ax);
+                        v[1] = tabs(z);
+                        v[2] = tabs(Ax - z);
+                    }
+                    if (nown) {
+                        v[3] = tabs(Px);
+                        v[4] = tabs(ATy);
+                        v[5] = tabs(q);
+                        v[6] = tabs(Px + q + ATy);
+                    }
+                    block_nanmax<T, 7>(v, lds + L::O_STAGE + L::MP + 2 * L::NP + 16);
+                    const T nrm_prim = nanmax(v[0], v[1]);
+                    const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
+                    info.res_prim = (double)v[2];
+                    info.res_dual = (double)v[6];
+                    if (check) {
+                        if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                            info.status = SQPH_SOLVED;
+                            break;
+                        }
+                    }
+                    if (adapt) {
+                        const T eps = a.regul;
+                        const T rp_norm = v[2] / (nrm_prim + eps);
+                        const T rd_norm = v[6] / (nrm_dual + eps);
+                        T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
+                        new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
+                        new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
+                        info.rho_estimate = (double)new_rho;
+                        if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
+                            rho_s = new_rho;
+                            if (mown) {
+                                rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
+                                rinv = T(1) / rho;
+                            }
+                            info.rho_updates += 1;
+                            need_factor = true;
+                            break;  // leave the iteration loop WITHOUT advancing iter; the factor block does it
+                        }
+                    }
+                }
+            }
+            if (!need_factor) break;  // converged, exhausted, or no refactor pending
+        }
+        if (solving) {
+            if (iter > a.max_iter) info.status = SQPH_MAX_ITER_EXCEEDED;
+            info.iter = iter;
+        }
+
+        if (state_dirty) {
+            if (nown) sx[t] = x;
+            if (mown) {
+                sz[t] = z;
+                sy[t] = y;
+                srho[t] = rho;
+            }
+        }
+        if (t == 0) {
+            a.info[qp] = info;
+            a.rho[qp] = rho_s;
+        }
+    }
+};
+
+// WPE = waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN> a) {
+    __shared__ __attribute__((aligned(16))) double lds[WgLayout<NW, R, C, TR, TC, TW>::TOTAL];
+    WgKernel<TIN, NW, R, C, TR, TC, TW>::run(a, lds);
+}
+
+// shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins
+#define SQPH_WG_SHAPES(X)        \
+    X(1, 8, 8, 1, 1, 1, 8)       \
+    X(1, 8, 8, 3, 2, 2, 8)       \
+    X(1, 8, 8, 5, 3, 3, 6)       \
+    X(1, 8, 8, 8, 4, 4, 4)       \
+    X(2, 16, 8, 7, 7, 4, 2)      \
+    X(4, 16, 16, 8, 4, 4, 4)     \
+    X(4, 16, 16, 13, 7, 7, 2)
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_wg(const KArgs<double, TIN> &a) {
+#define SQPH_SIM_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                         \
+    if (a.m <= R_ * TR_ && a.n <= C_ * TC_) {                                                                 \
+        ::sqph_sim::launch(admm_wg_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>, dim3(a.batch), dim3(64 * NW_), 0, a); \
+        return 0;                                                                                             \
+    }
+    SQPH_WG_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
+
+}  // namespace sqph

@@ -16,8 +16,10 @@ def main(out):
         print("\n## kernel stats (%s)" % os.path.relpath(f, out))
         with open(f) as fh:
             rows = list(csv.DictReader(fh))
-        for r in rows[:12]:
-            print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+        for r in rows[:6]:
+            d = {k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
+            d["Name"] = d["Name"][:100]
+            print(d)
     for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
         files = find(os.path.join(out, sub), "*counter_collection.csv")
         for f in files:
