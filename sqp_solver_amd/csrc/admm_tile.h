@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "admm_tile_kernel.h"
 #include "admm_wg_kernel.h"
 
@@ -25,10 +27,13 @@ inline int tile_try_launch(const KArgs<T, TIN> &a, hipStream_t stream, const cha
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>
 inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
+    // SQPH_WG_SKIP=k (experiments only): skip the first k shapes that would fit
+    static const int skip_env = getenv("SQPH_WG_SKIP") ? atoi(getenv("SQPH_WG_SKIP")) : 0;
+    int skip = skip_env;
 #define SQPH_WG_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                                            \
-    if (a.m <= R_ * TR_ && a.n <= C_ * TC_) {                                                                                   \
+    if (a.m <= R_ * TR_ && a.n <= C_ * TC_ && skip-- <= 0) {                                                                    \
         hipLaunchKernelGGL((admm_wg_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
-        *name = "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_;                                                                    \
+        *name = "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_ "_w" #W_;                                                                    \
         return hipGetLastError() == hipSuccess ? 1 : -1;                                                                        \
     }
     SQPH_WG_SHAPES(SQPH_WG_CASE)

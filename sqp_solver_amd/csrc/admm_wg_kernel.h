@@ -18,6 +18,7 @@
 #pragma once
 #include "block_ops.h"
 #include "kargs.h"
+#include "wave_ops.h"
 
 #ifndef SQPH_OPAQUE_S
 #ifdef SQPH_SIM
@@ -76,12 +77,17 @@ struct WgLayout {
     static constexpr int Rp = R + 2;        // staging stride per output for reductions over r
     static constexpr int Cp = C + 2;        // staging stride per output for reductions over c
     // LDS map (doubles)
-    static constexpr int O_ROWV = 0;                       // [R][TRp]  m-vector in row-gather order
-    static constexpr int O_COLV = O_ROWV + R * TRp;        // [C][TCp]  n-vector in column-gather order
-    static constexpr int O_WROW = O_COLV + C * TCp;        // [R][TWp]  n-vector in W-row-gather order
-    static constexpr int O_STAGE = ev(O_WROW + R * TWp);   // staging (aliased by all reductions and by the factor scratch)
+    static constexpr int O_ROWV = 0;                       // [R][TRp]  m-vector in row-gather order      (w ; y at checks)
+    static constexpr int O_COLV = O_ROWV + R * TRp;        // [C][TCp]  n-vector in column-gather order   (u ; x at checks)
+    static constexpr int O_COLV2 = O_COLV + C * TCp;       // [C][TCp]  second n-vector, column order     (y1)
+    static constexpr int O_WROW = O_COLV2 + C * TCp;       // [R][TWp]  n-vector in W-row-gather order    (y1)
+    static constexpr int O_STAGE = ev(O_WROW + R * TWp);   // staging X: partials reduced over r  [NP][Rp]
     static constexpr int mx(int a, int b) { return a > b ? a : b; }
-    static constexpr int STAGE = mx(mx(NP * Rp, NR * Cp), mx(MP * Cp, MP + 2 * NP + 16 + 8 * NT));
+    static constexpr int STAGE_X = NP * Rp;
+    static constexpr int O_STAGE_Y = O_STAGE + STAGE_X;    // staging Y: partials reduced over c  [max(NR,MP)][Cp]
+    static constexpr int STAGE_Y = mx(NR, MP) * Cp;
+    // the factor scratch (rho | rowbuf | sj) and the block-max scratch alias the staging areas
+    static constexpr int STAGE = mx(STAGE_X + STAGE_Y, MP + 2 * NP + 16 + 8 * NW);
     static constexpr int TOTAL = O_STAGE + STAGE;
 };
 
@@ -96,6 +102,8 @@ struct WgKernel {
     static __device__ __forceinline__ void get_rowv(const T *lds, int r, T (&w)[TR]) { wg_read<TR>(lds + L::O_ROWV + r * L::TRp, w); }
     static __device__ __forceinline__ void put_colv(T *lds, int j, T v) { lds[L::O_COLV + (j / TC) * L::TCp + (j % TC)] = v; }
     static __device__ __forceinline__ void get_colv(const T *lds, int c, T (&x)[TC]) { wg_read<TC>(lds + L::O_COLV + c * L::TCp, x); }
+    static __device__ __forceinline__ void put_colv2(T *lds, int j, T v) { lds[L::O_COLV2 + (j / TC) * L::TCp + (j % TC)] = v; }
+    static __device__ __forceinline__ void get_colv2(const T *lds, int c, T (&x)[TC]) { wg_read<TC>(lds + L::O_COLV2 + c * L::TCp, x); }
     static __device__ __forceinline__ void put_wrow(T *lds, int r, int c, T v) { lds[L::O_WROW + r * L::TWp + c] = v; }
     static __device__ __forceinline__ void get_wrow(const T *lds, int r, T (&y)[TW]) { wg_read<TW>(lds + L::O_WROW + r * L::TWp, y); }
 
@@ -122,7 +130,7 @@ struct WgKernel {
         for (int k = 0; k < TC; k++)
 #pragma unroll
             for (int s = 0; s < TR; s++) pz[s] = wg_fma(at[s][k], x[k], pz[s]);
-        T *st = lds + L::O_STAGE;
+        T *st = lds + L::O_STAGE_Y;
 #pragma unroll
         for (int s = 0; s < TR; s++) st[(R * s + r) * L::Cp + c] = pz[s];
     }
@@ -136,7 +144,7 @@ struct WgKernel {
             for (int k = 0; k < TC; k++) acc = wg_fma(wt[u][k], x[k], acc);
             py[u] = acc;
         }
-        T *st = lds + L::O_STAGE;
+        T *st = lds + L::O_STAGE_Y;
 #pragma unroll
         for (int u = 0; u < TW; u++) st[(R * u + r) * L::Cp + c] = py[u];
     }
@@ -155,7 +163,7 @@ struct WgKernel {
     }
     // owner-side reductions (lane t owns output t)
     static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? t : 0) * L::Rp); }
-    static __device__ __forceinline__ T reduce_over_c(const T *lds, int t) { return wg_sum<C>(lds + L::O_STAGE + t * L::Cp); }
+    static __device__ __forceinline__ T reduce_over_c(const T *lds, int t) { return wg_sum<C>(lds + L::O_STAGE_Y + t * L::Cp); }
 
     // ------------------------------------------------------------------ tile loads
     static __device__ __forceinline__ void load_A_tile(const TIN *__restrict__ gA, int n, int m, int r, int c, T (&at)[TR][TC]) {
@@ -193,6 +201,89 @@ struct WgKernel {
         }
     }
 
+    // B = A W' as a register tile: bt[s][k] = sum_j A[R s + r][j] * W[TC c + k][j]   (W lower triangular)
+    // A columns and W rows are streamed from global memory (W was just stored by this workgroup).
+    static __device__ __forceinline__ void build_B(const TIN *__restrict__ gA, const T *gW, int n, int m, int r, int c, T (&bt)[TR][TC]) {
+        int ia[TR], jw[TC];
+#pragma unroll
+        for (int s = 0; s < TR; s++) {
+            const int i = R * s + r;
+            ia[s] = i < m ? i : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < TC; k++) {
+            const int j = TC * c + k;
+            jw[k] = j < n ? j : 0;
+        }
+#pragma unroll
+        for (int s = 0; s < TR; s++)
+#pragma unroll
+            for (int k = 0; k < TC; k++) bt[s][k] = 0;
+#pragma unroll 1
+        for (int j = 0; j < (m > 0 ? n : 0); j++) {  // m == 0: no constraint rows, gA may be null
+            T av[TR], wv[TC];
+#pragma unroll
+            for (int s = 0; s < TR; s++) av[s] = (T)gA[(long)j * m + ia[s]];
+#pragma unroll
+            for (int k = 0; k < TC; k++) wv[k] = gW[(long)j * n + jw[k]];
+#pragma unroll
+            for (int s = 0; s < TR; s++)
+#pragma unroll
+                for (int k = 0; k < TC; k++) bt[s][k] = wg_fma(av[s], wv[k], bt[s][k]);
+        }
+#pragma unroll
+        for (int s = 0; s < TR; s++)
+#pragma unroll
+            for (int k = 0; k < TC; k++) bt[s][k] = (R * s + r < m && TC * c + k < n) ? bt[s][k] : T(0);
+    }
+    // residual check only: A x partials (staged for the reduction over c) and A' y partials (over r), with
+    // the A tile streamed column by column from global memory.  The column loop is deliberately NOT
+    // unrolled (x[k] comes from LDS) so this rare block does not raise the kernel's register high-water
+    // mark — occupancy is decided by the peak over the whole kernel, not by the hot loop.
+    static __device__ __forceinline__ void stage_A_AT_gmem(const TIN *__restrict__ gA, int n, int m, int r, int c,
+                                                           const T (&y)[TR], T *lds) {
+        T pz[TR];
+#pragma unroll
+        for (int s = 0; s < TR; s++) pz[s] = 0;
+        T *stx = lds + L::O_STAGE;
+        const T *xv = lds + L::O_COLV + c * L::TCp;
+#pragma unroll 1
+        for (int k = 0; k < TC; k++) {
+            const int j = TC * c + k;
+            const T xk = xv[k];
+            T pb = 0;
+#pragma unroll
+            for (int s = 0; s < TR; s++) {
+                const int i = R * s + r;
+                const T av = (j < n && i < m) ? (T)gA[(long)j * m + i] : T(0);
+                pz[s] = wg_fma(av, xk, pz[s]);
+                pb = wg_fma(av, y[s], pb);
+            }
+            stx[(TC * c + k) * L::Rp + r] = pb;
+        }
+        T *sty = lds + L::O_STAGE_Y;
+#pragma unroll
+        for (int s = 0; s < TR; s++) sty[(R * s + r) * L::Cp + c] = pz[s];
+    }
+    // residual check only: P x partials with the P tile streamed row-block by row-block (not unrolled)
+    static __device__ __forceinline__ void stage_P_gmem(const TIN *__restrict__ gP, int n, int r, int c, T *lds) {
+        T xc[TC];
+        get_colv(lds, c, xc);
+        T *sty = lds + L::O_STAGE_Y;
+#pragma unroll 1
+        for (int u = 0; u < TW; u++) {
+            const int i = R * u + r;
+            T acc = 0;
+#pragma unroll
+            for (int k = 0; k < TC; k++) {
+                const int j = TC * c + k;
+                const T pv = (i < n && j < n) ? (T)gP[(long)j * n + i] : T(0);
+                acc = wg_fma(pv, xc[k], acc);
+            }
+            sty[(R * u + r) * L::Cp + c] = acc;
+        }
+    }
+
     // ------------------------------------------------------------------ factor (see admm_generic.h factor_schur)
     // Scratch inside the staging area: rho[MP] | rowbuf[NP + 1] | sj[NP]   (doubles)
     static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const TIN *__restrict__ gA, int n, int m, T sigma,
@@ -216,7 +307,7 @@ struct WgKernel {
 #pragma unroll
             for (int k = 0; k < TC; k++) wt[u][k] = 0;
         // S = A' diag(rho) A : rows of A streamed from global memory (L1/L2 hits after the first touch)
-#pragma unroll 2
+#pragma unroll 1
         for (int i = 0; i < m; i++) {
             const T ri = rho_l[i];
             T a1[TW], a2[TC];
@@ -427,55 +518,44 @@ struct WgKernel {
                 state_dirty = true;
                 if ((mode & MODE_COLD_RESET) && !a.warm_start) x = z = y = 0;
             }
-            T at[TR][TC];
+            // B = A W' replaces A in the iteration:  y1 = W u + B' w,  x~ = W' y1,  z~ = B y1   (u = sigma x - q)
+            // => two dependent stages per iteration instead of four (A'w -> W -> W' -> A), i.e. 4 barriers, not 8.
+            T bt[TR][TC];
             {
                 int n_t = n, m_t = m, r_t = r, c_t = c;
                 const TIN *gA_t = gA;
-                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_S(m_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t); SQPH_OPAQUE_S(gA_t);
-                load_A_tile(gA_t, n_t, m_t, r_t, c_t, at);  // (re)loaded after every factor: its registers were free meanwhile
+                const T *gW_t = gW;
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_S(m_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t); SQPH_OPAQUE_S(gA_t); SQPH_OPAQUE_S(gW_t);
+                build_B(gA_t, gW_t, n_t, m_t, r_t, c_t, bt);  // (re)built after every factor: its registers were free meanwhile
             }
+            // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
+            if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
+            if (t < L::NP) put_colv(lds, t, nown ? sigma * x - q : T(0));
             for (; iter <= a.max_iter; iter++) {
-                // w = R (z - R^-1 y)   [rhs tail of qp.cpp:275 pre-multiplied by R]
-                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
                 __syncthreads();
-                {
-                    T w[TR];
+                {   // stage 1 partials:  B' w (reduced over r)  and  W u (reduced over c)
+                    T w[TR], uu[TC];
                     get_rowv(lds, r, w);
-                    stage_AT(at, w, lds, r, c);
+                    get_colv(lds, c, uu);
+                    stage_AT(bt, w, lds, r, c);
+                    stage_W(wt, uu, lds, r, c);
                 }
                 __syncthreads();
-                if (t < L::NP) {
-                    const T b = nown ? (sigma * x - q) + reduce_over_r(lds, t) : T(0);
-                    put_colv(lds, t, b);
+                if (t < L::NR) {   // y1 = W u + B' w, published in both gather orders
+                    const T y1 = nown ? reduce_over_c(lds, t) + reduce_over_r(lds, t) : T(0);
+                    put_wrow(lds, r, c, y1);
+                    if (t < L::NP) put_colv2(lds, t, y1);
                 }
                 __syncthreads();
-                {
-                    T b[TC];
-                    get_colv(lds, c, b);
-                    stage_W(wt, b, lds, r, c);  // W b
+                {   // stage 2 partials:  z~ = B y1 (reduced over c)  and  x~ = W' y1 (reduced over r)
+                    T y1c[TC], y1r[TW];
+                    get_colv2(lds, c, y1c);
+                    get_wrow(lds, r, y1r);
+                    stage_A(bt, y1c, lds, r, c);
+                    stage_WT(wt, y1r, lds, r, c);
                 }
                 __syncthreads();
-                if (t < L::NR) put_wrow(lds, r, c, nown ? reduce_over_c(lds, t) : T(0));
-                __syncthreads();
-                {
-                    T y1[TW];
-                    get_wrow(lds, r, y1);
-                    stage_WT(wt, y1, lds, r, c);  // W' (W b)
-                }
-                __syncthreads();
-                T xt = 0;
-                if (t < L::NP) {
-                    xt = nown ? reduce_over_r(lds, t) : T(0);
-                    put_colv(lds, t, xt);
-                }
-                __syncthreads();
-                {
-                    T xc[TC];
-                    get_colv(lds, c, xc);
-                    stage_A(at, xc, lds, r, c);  // z~ = A x~
-                }
-                __syncthreads();
-                x = alpha * xt + oma * x;
+                if (nown) x = alpha * reduce_over_r(lds, t) + oma * x;
                 if (mown) {
                     const T zt = reduce_over_c(lds, t);
                     const T zr = alpha * zt + oma * z;
@@ -489,32 +569,30 @@ struct WgKernel {
                 const bool check = a.check_termination != 0 && (iter % a.check_termination == 0);
                 const bool adapt = a.adaptive_rho && (iter % a.adaptive_rho_interval == 0);
                 if (check || adapt) {
-                    // update_state + residuals, qp.cpp:316-331, 353-361
+                    // update_state + residuals, qp.cpp:316-331, 353-361.  A and P are streamed from global
+                    // memory here (the register tiles hold B and W); this block runs every check_termination
+                    // iterations only.
                     __syncthreads();
                     if (t < L::NP) put_colv(lds, t, nown ? x : T(0));
                     if (t < L::MP) put_rowv(lds, r, c, mown ? y : T(0));
                     __syncthreads();
-                    T xc[TC];
-                    get_colv(lds, c, xc);
-                    stage_A(at, xc, lds, r, c);
-                    __syncthreads();
-                    const T Ax = mown ? reduce_over_c(lds, t) : T(0);
-                    __syncthreads();
                     {
                         T yr[TR];
                         get_rowv(lds, r, yr);
-                        stage_AT(at, yr, lds, r, c);
+                        int n_c = n, m_c = m, r_c = r, c_c = c;
+                        const TIN *gA_c = gA;
+                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_S(m_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gA_c);
+                        stage_A_AT_gmem(gA_c, n_c, m_c, r_c, c_c, yr, lds);  // A x (over c) and A' y (over r)
                     }
                     __syncthreads();
+                    const T Ax = mown ? reduce_over_c(lds, t) : T(0);
                     const T ATy = nown ? reduce_over_r(lds, t) : T(0);
                     __syncthreads();
                     {
                         int n_c = n, r_c = r, c_c = c;
                         const TIN *gP_c = gP;
                         SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gP_c);
-                        T pt[TW][TC];
-                        load_sq_tile<TIN>(gP_c, n_c, r_c, c_c, pt);  // full P (both triangles), as qp.cpp:324
-                        stage_W(pt, xc, lds, r, c);
+                        stage_P_gmem(gP_c, n_c, r_c, c_c, lds);  // full P (both triangles), as qp.cpp:324
                     }
                     __syncthreads();
                     const T Px = nown ? reduce_over_c(lds, t) : T(0);
@@ -531,7 +609,26 @@ struct WgKernel {
                         v[5] = tabs(q);
                         v[6] = tabs(Px + q + ATy);
                     }
-                    block_nanmax<T, 7>(v, lds + L::O_STAGE + L::MP + 2 * L::NP + 16);
+                    {   // workgroup-wide NaN-propagating max: butterfly inside each wave, NW values through LDS
+                        T *red = lds + L::O_STAGE + L::MP + 2 * L::NP + 16;
+#pragma unroll
+                        for (int e = 0; e < 7; e++) v[e] = wave_nanmax(v[e]);
+                        if constexpr (NW > 1) {
+                            if ((t & 63) == 0) {
+#pragma unroll
+                                for (int e = 0; e < 7; e++) red[e * NW + (t >> 6)] = v[e];
+                            }
+                            __syncthreads();
+#pragma unroll
+                            for (int e = 0; e < 7; e++) {
+                                T mval = red[e * NW];
+#pragma unroll
+                                for (int wv_ = 1; wv_ < NW; wv_++) mval = nanmax(mval, red[e * NW + wv_]);
+                                v[e] = mval;
+                            }
+                            __syncthreads();
+                        }
+                    }
                     const T nrm_prim = nanmax(v[0], v[1]);
                     const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
                     info.res_prim = (double)v[2];
@@ -562,6 +659,9 @@ struct WgKernel {
                         }
                     }
                 }
+                // operands of the next iteration (the barrier at the loop top orders them before the gathers)
+                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
+                if (t < L::NP) put_colv(lds, t, nown ? sigma * x - q : T(0));
             }
             if (!need_factor) break;  // converged, exhausted, or no refactor pending
         }
@@ -594,13 +694,20 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
 
 // shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins
 #define SQPH_WG_SHAPES(X)        \
-    X(1, 8, 8, 1, 1, 1, 8)       \
-    X(1, 8, 8, 3, 2, 2, 8)       \
-    X(1, 8, 8, 5, 3, 3, 6)       \
-    X(1, 8, 8, 8, 4, 4, 4)       \
+    X(1, 8, 8, 1, 1, 1, 4)       \
+    X(1, 8, 8, 3, 2, 2, 4)       \
+    X(1, 8, 8, 5, 3, 3, 3)       \
+    X(1, 8, 8, 5, 3, 3, 4)       \
+    X(1, 8, 8, 5, 3, 3, 2)       \
+    X(1, 8, 8, 8, 4, 4, 2)       \
     X(2, 16, 8, 7, 7, 4, 2)      \
-    X(4, 16, 16, 8, 4, 4, 4)     \
-    X(4, 16, 16, 13, 7, 7, 2)
+    X(4, 16, 16, 7, 4, 4, 3)     \
+    X(4, 16, 16, 7, 4, 4, 2)     \
+    X(4, 32, 8, 4, 7, 2, 3)      \
+    X(4, 32, 8, 4, 7, 2, 2)      \
+    X(2, 16, 8, 7, 7, 4, 1)      \
+    X(4, 16, 16, 8, 4, 4, 2)     \
+    X(4, 16, 16, 13, 7, 7, 1)
 
 #ifdef SQPH_SIM
 template <typename TIN>
