@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libsqp_hip.so")
+LIB = os.environ.get("SQPH_LIB") or os.path.join(LIBDIR, "libsqp_hip.so")  # SQPH_LIB: A/B-test another build
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
@@ -18,6 +18,8 @@ def sources():
 
 
 def needs_build():
+    if os.environ.get("SQPH_LIB"):
+        return False
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)

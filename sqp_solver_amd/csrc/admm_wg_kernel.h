@@ -52,14 +52,26 @@ template <int N>
 __device__ __forceinline__ double wg_sum(const double *p) {
     double v[N];
     wg_read<N>(p, v);
-    double s0 = v[0], s1 = N > 1 ? v[1] : 0.0;
+    if constexpr (N >= 8 && (N % 4) == 0) {
+        double s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3];  // four independent chains
 #pragma unroll
-    for (int k = 2; k + 1 < N; k += 2) {
-        s0 += v[k];
-        s1 += v[k + 1];
+        for (int k = 4; k < N; k += 4) {
+            s0 += v[k];
+            s1 += v[k + 1];
+            s2 += v[k + 2];
+            s3 += v[k + 3];
+        }
+        return (s0 + s1) + (s2 + s3);
+    } else {
+        double s0 = v[0], s1 = N > 1 ? v[1] : 0.0;
+#pragma unroll
+        for (int k = 2; k + 1 < N; k += 2) {
+            s0 += v[k];
+            s1 += v[k + 1];
+        }
+        if constexpr ((N & 1) && N > 1) s0 += v[N - 1];
+        return s0 + s1;
     }
-    if constexpr ((N & 1) && N > 1) s0 += v[N - 1];
-    return s0 + s1;
 }
 
 template <int NW, int R, int C, int TR, int TC, int TW>
@@ -490,6 +502,9 @@ struct WgKernel {
         if (!need_factor) load_sq_tile<T>(gW, n, r, c, wt);
         const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
         int iter = 1;
+        // countdowns to the next termination check / rho adaptation (0 or disabled: never fires)
+        int next_check = a.check_termination > 0 ? a.check_termination : -1;
+        int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
         for (;;) {
             if (need_factor) {
                 __syncthreads();
@@ -531,8 +546,15 @@ struct WgKernel {
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
             if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
             if (t < L::NP) put_colv(lds, t, nown ? sigma * x - q : T(0));
+#ifdef SQPH_PHASE_TIMING
+            unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define SQPH_TICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
+#else
+#define SQPH_TICK(k)
+#endif
             for (; iter <= a.max_iter; iter++) {
                 __syncthreads();
+                SQPH_TICK(0)
                 {   // stage 1 partials:  B' w (reduced over r)  and  W u (reduced over c)
                     T w[TR], uu[TC];
                     get_rowv(lds, r, w);
@@ -540,13 +562,17 @@ struct WgKernel {
                     stage_AT(bt, w, lds, r, c);
                     stage_W(wt, uu, lds, r, c);
                 }
+                SQPH_TICK(1)
                 __syncthreads();
+                SQPH_TICK(2)
                 if (t < L::NR) {   // y1 = W u + B' w, published in both gather orders
                     const T y1 = nown ? reduce_over_c(lds, t) + reduce_over_r(lds, t) : T(0);
                     put_wrow(lds, r, c, y1);
                     if (t < L::NP) put_colv2(lds, t, y1);
                 }
+                SQPH_TICK(3)
                 __syncthreads();
+                SQPH_TICK(4)
                 {   // stage 2 partials:  z~ = B y1 (reduced over c)  and  x~ = W' y1 (reduced over r)
                     T y1c[TC], y1r[TW];
                     get_colv2(lds, c, y1c);
@@ -554,7 +580,11 @@ struct WgKernel {
                     stage_A(bt, y1c, lds, r, c);
                     stage_WT(wt, y1r, lds, r, c);
                 }
+                SQPH_TICK(5)
                 __syncthreads();
+                SQPH_TICK(6)
+                // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
+                // SIMDs are issue-bound at two waves each (a branch-free variant measured 14 % slower)
                 if (nown) x = alpha * reduce_over_r(lds, t) + oma * x;
                 if (mown) {
                     const T zt = reduce_over_c(lds, t);
@@ -566,8 +596,17 @@ struct WgKernel {
                     z = zn;
                 }
 
-                const bool check = a.check_termination != 0 && (iter % a.check_termination == 0);
-                const bool adapt = a.adaptive_rho && (iter % a.adaptive_rho_interval == 0);
+                // iter % check_termination == 0  /  iter % adaptive_rho_interval == 0 as countdowns (an integer
+                // modulo by a run-time value costs ~20 SALU instructions on the critical path of every iteration)
+                bool check = false, adapt = false;
+                if (--next_check == 0) {
+                    check = true;
+                    next_check = a.check_termination;
+                }
+                if (--next_adapt == 0) {
+                    adapt = true;
+                    next_adapt = a.adaptive_rho_interval;
+                }
                 if (check || adapt) {
                     // update_state + residuals, qp.cpp:316-331, 353-361.  A and P are streamed from global
                     // memory here (the register tiles hold B and W); this block runs every check_termination
@@ -662,7 +701,12 @@ struct WgKernel {
                 // operands of the next iteration (the barrier at the loop top orders them before the gathers)
                 if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
                 if (t < L::NP) put_colv(lds, t, nown ? sigma * x - q : T(0));
+                SQPH_TICK(7)
             }
+#ifdef SQPH_PHASE_TIMING
+            if (t < 8) x = (T)tacc[t];           // debug build only: wave 0's phase ticks instead of x[0..8)
+            if (t >= 64 && t < 72) y = (T)tacc[t - 64];  // wave 1's phase ticks in y[64..72)
+#endif
             if (!need_factor) break;  // converged, exhausted, or no refactor pending
         }
         if (solving) {
