@@ -61,8 +61,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("SQPH_BENCH_DIST1") == "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n, m, B = args.n, args.m, args.batch_per_gpu
@@ -87,7 +89,7 @@ def main():
         solver.setup_solve(P, q, A_cm, l, u, colmajor=True)
 
     gather_bufs = None
-    if world > 1 and not args.no_gather:
+    if use_dist and not args.no_gather:
         # final collection of (x, y, info) records on rank 0 over xGMI (RCCL gather)
         from sqp_solver_amd.dist import ResultGather
 
@@ -101,7 +103,7 @@ def main():
     for _ in range(args.warmup):
         full_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -110,14 +112,14 @@ def main():
     for _ in range(args.steps):
         full_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = solver.collect_kernel_ms()
     solver.enable_timing(False)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -126,7 +128,7 @@ def main():
     info = solver.info()
     iters_local = int(np.minimum(info.iter, st.max_iter).sum())
     n_solved = int((info.status == 0).sum())
-    if world > 1:
+    if use_dist:
         t = torch.tensor([iters_local, n_solved], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         iters_total, solved_total = int(t[0].item()), int(t[1].item())
@@ -176,7 +178,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(solver.kernel_name(), n, m, B, args.mode),
                 "algorithmic_bytes_per_qp": bytes_per_qp,
                 "kernel_ms_avg": avg_kernel_ms,
                 "kernel_launches_timed": len(kernel_ms),
@@ -186,10 +188,26 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        if gather_bufs is not None and rank == 0:
+            # sanity: the gathered record of rank 0's own shard equals its resident state
+            xs = gather_bufs.stacked()[0]
+            assert torch.equal(xs[:B], gather_bufs.local[0]), "gather mismatch"
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def pmc_traffic(kernel, n, m, batch, mode):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 calibration in
+    profiles/r01_fetch_size_calibration.txt). None when no profile of this exact kernel/workload exists."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    return table.get("%s|n=%d|m=%d|batch=%d|%s" % (kernel, n, m, batch, mode))
 
 
 def cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt):

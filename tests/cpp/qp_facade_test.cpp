@@ -1,0 +1,168 @@
+// The reference's GTest cases for the QP solver (tests/qp_solver_test.cpp:43-156 and
+// tests/unsupported/qp_solver_test.cpp) restated against the C++ facade include/sqp_hip/qp.hpp,
+// i.e. host C++ -> C-ABI -> HIP kernels.  Plain asserts; exit code 0 = all passed, 3 = no HIP device.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/sqp_hip/qp.hpp"
+
+using namespace qp_solver;
+
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            exit(1);                                                         \
+        }                                                                    \
+    } while (0)
+
+// the canonical fixture, tests/qp_solver_test.cpp:19-31 (column-major storage like Eigen)
+template <typename Scalar>
+struct SimpleQP : QuadraticProblem<Scalar> {
+    Scalar Pd[4] = {4, 1, 1, 2};
+    Scalar qd[2] = {1, 1};
+    Scalar Ad[6] = {1, 1, 0, 1, 0, 1};  // A = [[1,1],[1,0],[0,1]] column-major
+    Scalar ld[3] = {1, 0, 0};
+    Scalar ud[3] = {1, (Scalar)0.7, (Scalar)0.7};
+    Scalar SOLUTION[2] = {(Scalar)0.3, (Scalar)0.7};
+    SimpleQP() {
+        this->n = 2; this->m = 3;
+        this->P = Pd; this->q = qd; this->A = Ad; this->l = ld; this->u = ud;
+    }
+};
+
+template <typename V, typename Scalar>
+static bool is_approx(const V &a, const Scalar *b, int k, double prec) {  // Eigen's isApprox
+    double d = 0, na = 0, nb = 0;
+    for (int i = 0; i < k; i++) { d += (a[i] - b[i]) * (a[i] - b[i]); na += a[i] * a[i]; nb += b[i] * b[i]; }
+    return std::sqrt(d) <= prec * std::sqrt(na < nb ? na : nb);
+}
+
+static void testSimpleQP() {
+    SimpleQP<double> qp;
+    QPSolver<double> solver;
+    solver.settings().max_iter = 1000;
+    solver.setup(qp);
+    solver.solve(qp);
+    CHECK(is_approx(solver.primal_solution(), qp.SOLUTION, 2, 1e-2));
+    CHECK(solver.info().iter < solver.settings().max_iter);
+    CHECK(solver.info().status == SOLVED);
+    CHECK(solver.info().iter == 125);  // oracle-pinned
+}
+static void testSinglePrecisionFloat() {
+    SimpleQP<float> qp;
+    QPSolver<float> solver;
+    solver.setup(qp);
+    solver.solve(qp);
+    CHECK(is_approx(solver.primal_solution(), qp.SOLUTION, 2, 1e-2));
+    CHECK(solver.info().iter < solver.settings().max_iter);
+    CHECK(solver.info().status == SOLVED);
+}
+static void testConstraintViolation() {
+    SimpleQP<double> qp;
+    QPSolver<double> solver;
+    solver.settings().eps_rel = 1e-4f;
+    solver.settings().eps_abs = 1e-4f;
+    solver.setup(qp);
+    solver.solve(qp);
+    const auto &x = solver.primal_solution();
+    const double Ax[3] = {x[0] + x[1], x[0], x[1]};
+    for (int i = 0; i < 3; i++) {
+        CHECK(Ax[i] - qp.ld[i] >= -1e-3);
+        CHECK(Ax[i] - qp.ud[i] <= 1e-3);
+    }
+}
+static void testAdaptiveRho() {
+    SimpleQP<double> qp;
+    QPSolver<double> solver;
+    solver.settings().adaptive_rho = true;
+    solver.settings().adaptive_rho_interval = 10;
+    solver.setup(qp);
+    solver.solve(qp);
+    CHECK(solver.info().status == SOLVED);
+}
+static void testAdaptiveRhoImprovesConvergence() {
+    SimpleQP<double> qp;
+    QPSolver<double> solver;
+    solver.settings().warm_start = false;
+    solver.settings().max_iter = 1000;
+    solver.settings().rho = 0.1;
+    solver.settings().adaptive_rho = false;
+    solver.setup(qp);
+    solver.solve(qp);
+    const int prev_iter = solver.info().iter;
+    solver.settings().adaptive_rho = true;
+    solver.settings().adaptive_rho_interval = 10;
+    solver.solve(qp);
+    CHECK(solver.info().iter < solver.settings().max_iter);
+    CHECK(solver.info().iter < prev_iter);
+    CHECK(solver.info().status == SOLVED);
+}
+static void TestConstraint() {
+    using Solver = QPSolver<double>;
+    const double T = Solver::LOOSE_BOUNDS_THRESH;
+    const double l[5] = {-10 * T, -1, -10 * T, -3, 42};
+    const double u[5] = {10 * T, 10 * T, 2, 4, 42};
+    const int expect[5] = {Solver::LOOSE_BOUNDS, Solver::INEQUALITY_CONSTRAINT, Solver::INEQUALITY_CONSTRAINT,
+                           Solver::INEQUALITY_CONSTRAINT, Solver::EQUALITY_CONSTRAINT};
+    int type[5];
+    Solver::constr_type_init(5, l, u, type);
+    for (int i = 0; i < 5; i++) CHECK(type[i] == expect[i]);
+}
+static void testLegacyFixedSize() {  // tests/unsupported/qp_solver_test.cpp:29-41 + sparse test's multiple-solve semantics
+    legacy::QP<2, 3, double> qp = {{4, 1, 1, 2}, {1, 1}, {1, 1, 0, 1, 0, 1}, {1, 0, 0}, {1, 0.7, 0.7}};
+    legacy::QPSolver<legacy::QP<2, 3, double>> prob;
+    prob.settings().max_iter = 1000;
+    prob.setup(qp);
+    prob.solve(qp);
+    const double sol[2] = {0.3, 0.7};
+    CHECK(is_approx(prob.primal_solution(), sol, 2, 1e-2));
+    CHECK(prob.iter < prob.settings().max_iter);
+    CHECK(prob.info().status == SOLVED);
+    const int it1 = prob.iter;
+    prob.solve(qp);  // legacy class resets x,z,y when warm_start == false
+    CHECK(prob.info().status == SOLVED && prob.iter == it1);
+}
+static void testBatch() {
+    const int B = 256;
+    BatchQPSolver<double> solver(2, 3, B);
+    SimpleQP<double> qp;
+    std::vector<double> q(2 * B), l(3 * B), u(3 * B);
+    for (int b = 0; b < B; b++) {
+        q[2 * b] = 1 + 0.001 * b; q[2 * b + 1] = 1;
+        for (int i = 0; i < 3; i++) { l[3 * b + i] = qp.ld[i]; u[3 * b + i] = qp.ud[i]; }
+    }
+    auto batch = solver.packed(B, qp.Pd, q.data(), qp.Ad, l.data(), u.data());
+    batch.stride_P = 0;  // P and A shared by the whole batch
+    batch.stride_A = 0;
+    solver.setup_solve(batch);
+    for (int b = 0; b < B; b++) {
+        CHECK(solver.info(b).status == SOLVED);
+        CHECK(std::fabs(solver.primal_solution(b)[0] + solver.primal_solution(b)[1] - 1.0) < 5e-3);
+    }
+}
+
+int main() {
+    try {
+        TestConstraint();  // host-only, no device needed
+        testSimpleQP();
+        testSinglePrecisionFloat();
+        testConstraintViolation();
+        testAdaptiveRho();
+        testAdaptiveRhoImprovesConvergence();
+        testLegacyFixedSize();
+        testBatch();
+    } catch (const std::runtime_error &e) {
+        if (std::string(e.what()).find("no HIP device") != std::string::npos) {
+            fprintf(stderr, "no HIP device: %s\n", e.what());
+            return 3;
+        }
+        fprintf(stderr, "exception: %s\n", e.what());
+        return 2;
+    }
+    printf("qp_facade_test: all passed\n");
+    return 0;
+}

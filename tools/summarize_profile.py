@@ -40,5 +40,24 @@ def main(out):
                     print("   %-28s %.6g" % (c, v / n))
 
 
+def traffic(out):
+    """(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch of the admm kernel (see profiles/r01_fetch_size_calibration.txt)."""
+    vals = {}
+    for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for f in find(os.path.join(out, sub), "*counter_collection.csv"):
+            tot, ids = 0.0, set()
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if "admm" in r.get("Kernel_Name", "") and r["Counter_Name"] == name:
+                        tot += float(r["Counter_Value"])
+                        ids.add(r.get("Dispatch_Id"))
+            if ids:
+                vals[name] = tot / len(ids)
+    if len(vals) == 2:
+        print("\n## HBM traffic per launch: (2*%.0f + %.0f) KB = %.1f MB" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"], (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / 1e6))
+        print("TRAFFIC_BYTES_PER_LAUNCH %d" % int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024))
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    traffic(sys.argv[1])
