@@ -98,9 +98,27 @@ struct WgLayout {
     static constexpr int STAGE_X = NP * Rp;
     static constexpr int O_STAGE_Y = O_STAGE + STAGE_X;    // staging Y: partials reduced over c  [max(NR,MP)][Cp]
     static constexpr int STAGE_Y = mx(NR, MP) * Cp;
-    // the factor scratch (rho | rowbuf | sj) and the block-max scratch alias the staging areas
+    // set-up scratch, aliasing the staging areas:  rho[MP] | rowbuf[NP+2] | sj[NP] | As[R][SSTR] | Wl[NP][SSTR]
+    // As = one block of R rows of A, Wl = W transposed (Wl[j][slot(i')] = W[i'][j]); column groups are
+    // padded to 8 (slot(j) = 8*(j/TC) + j%TC) so a lane's TC consecutive columns are one aligned 64-B read.
+    // (the set-up scratch starts at offset 0: no vector is live in LDS while a factor is being built)
+    static constexpr int SSTR = 8 * C + 2;  // As row stride (padded: the R rows are written by different lanes)
+    static constexpr int WSTR = 8 * C;      // Wl row stride
+    static constexpr int O_RHO = 0;
+    static constexpr int O_ROWBUF = O_RHO + MP;
+    static constexpr int O_SJ = O_ROWBUF + NP + 2;
+    static constexpr int O_AS = ev(O_SJ + NP);
+    static constexpr int O_WL = O_AS + R * SSTR;
+    static constexpr int CH = (C + 1) / 2;  // W is staged half of its columns (CH column groups) at a time
+    static constexpr int SETUP = O_WL + CH * TC * WSTR;
+    static constexpr int O_RED = O_STAGE + MP + 2 * NP + 16;  // workgroup max scratch (residual checks)
     static constexpr int STAGE = mx(STAGE_X + STAGE_Y, MP + 2 * NP + 16 + 8 * NW);
-    static constexpr int TOTAL = O_STAGE + STAGE;
+    // per-element constants of the owners (q, l, u): LDS instead of VGPRs, after everything that is aliased
+    static constexpr int O_QV = ev(mx(O_STAGE + STAGE, SETUP));
+    static constexpr int O_LOV = O_QV + NP;
+    static constexpr int O_UPV = O_LOV + MP;
+    static constexpr int TOTAL = O_UPV + MP;
+    static constexpr int slot(int j) { return 8 * (j / TC) + (j % TC); }
 };
 
 template <typename TIN, int NW, int R, int C, int TR, int TC, int TW>
@@ -213,40 +231,58 @@ struct WgKernel {
         }
     }
 
-    // B = A W' as a register tile: bt[s][k] = sum_j A[R s + r][j] * W[TC c + k][j]   (W lower triangular)
-    // A columns and W rows are streamed from global memory (W was just stored by this workgroup).
-    static __device__ __forceinline__ void build_B(const TIN *__restrict__ gA, const T *gW, int n, int m, int r, int c, T (&bt)[TR][TC]) {
-        int ia[TR], jw[TC];
+    // B = A W' IN PLACE over the A tile (bt[s][k] = sum_j A[R s + r][j] * W[TC c + k][j], W lower triangular).
+    // W is staged once (transposed) in LDS from the register tile, A goes through LDS one block of R rows at
+    // a time — nothing is re-read from global memory.
+    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c) {
+        T *As = lds + L::O_AS, *Wl = lds + L::O_WL;
+        const int myhalf = c / L::CH, cl = c - myhalf * L::CH;  // my column group inside its half
 #pragma unroll
         for (int s = 0; s < TR; s++) {
-            const int i = R * s + r;
-            ia[s] = i < m ? i : 0;
-        }
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < TC; k++) {
-            const int j = TC * c + k;
-            jw[k] = j < n ? j : 0;
-        }
+            for (int k = 0; k < TC; k++) As[r * L::SSTR + 8 * c + k] = at[s][k];
+            T acc[TC];
 #pragma unroll
-        for (int s = 0; s < TR; s++)
-#pragma unroll
-            for (int k = 0; k < TC; k++) bt[s][k] = 0;
+            for (int k = 0; k < TC; k++) acc[k] = 0;
 #pragma unroll 1
-        for (int j = 0; j < (m > 0 ? n : 0); j++) {  // m == 0: no constraint rows, gA may be null
-            T av[TR], wv[TC];
+            for (int half = 0; half < 2; half++) {
+                __syncthreads();
+                // Wl[jl][slot(i')] = W[i'][CH*TC*half + jl] from the lanes whose columns lie in this half
+                if (myhalf == half) {
 #pragma unroll
-            for (int s = 0; s < TR; s++) av[s] = (T)gA[(long)j * m + ia[s]];
+                    for (int u = 0; u < TW; u++) {
+                        const int i = R * u + r;
+                        if (i < L::NP) {
 #pragma unroll
-            for (int k = 0; k < TC; k++) wv[k] = gW[(long)j * n + jw[k]];
+                            for (int k = 0; k < TC; k++) Wl[(TC * cl + k) * L::WSTR + L::slot(i)] = wt[u][k];
+                        }
+                    }
+                }
+                __syncthreads();
+                // W[TC c + k][j] = 0 for j > TC c + k: column groups beyond my own contribute nothing
+                const int cj0 = L::CH * half;
+                int cj1 = cj0 + L::CH - 1;
+                cj1 = cj1 < c ? cj1 : c;
+                cj1 = cj1 < C - 1 ? cj1 : C - 1;
+#pragma unroll 1
+                for (int cj = cj0; cj <= cj1; cj++) {
+                    T av[8];
+                    wg_read<8>(As + r * L::SSTR + 8 * cj, av);
 #pragma unroll
-            for (int s = 0; s < TR; s++)
+                    for (int kj = 0; kj < TC; kj++) {
+                        if (TC * cj + kj >= n) break;
+                        T wv[8];
+                        wg_read<8>(Wl + (TC * (cj - cj0) + kj) * L::WSTR + 8 * c, wv);
 #pragma unroll
-                for (int k = 0; k < TC; k++) bt[s][k] = wg_fma(av[s], wv[k], bt[s][k]);
+                        for (int k = 0; k < TC; k++) acc[k] = wg_fma(av[kj], wv[k], acc[k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TC; k++) at[s][k] = acc[k];
         }
-#pragma unroll
-        for (int s = 0; s < TR; s++)
-#pragma unroll
-            for (int k = 0; k < TC; k++) bt[s][k] = (R * s + r < m && TC * c + k < n) ? bt[s][k] : T(0);
+        __syncthreads();
     }
     // residual check only: A x partials (staged for the reduction over c) and A' y partials (over r), with
     // the A tile streamed column by column from global memory.  The column loop is deliberately NOT
@@ -298,11 +334,13 @@ struct WgKernel {
 
     // ------------------------------------------------------------------ factor (see admm_generic.h factor_schur)
     // Scratch inside the staging area: rho[MP] | rowbuf[NP + 1] | sj[NP]   (doubles)
-    static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const TIN *__restrict__ gA, int n, int m, T sigma,
+    // `at` is the A register tile (rows R s + r, columns TC c + k); it is only read here.
+    static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const T (&at)[TR][TC], int n, int m, T sigma,
                                                   T *lds, int t, int r, int c, T (&wt)[TW][TC]) {
-        T *rho_l = lds + L::O_STAGE;
-        T *rowbuf = rho_l + L::MP;
-        T *sjv = rowbuf + L::NP + 2;
+        T *rho_l = lds + L::O_RHO;
+        T *rowbuf = lds + L::O_ROWBUF;
+        T *sjv = lds + L::O_SJ;
+        T *As = lds + L::O_AS;
         int ir[TW], jc[TC];
 #pragma unroll
         for (int u = 0; u < TW; u++) {
@@ -318,20 +356,34 @@ struct WgKernel {
         for (int u = 0; u < TW; u++)
 #pragma unroll
             for (int k = 0; k < TC; k++) wt[u][k] = 0;
-        // S = A' diag(rho) A : rows of A streamed from global memory (L1/L2 hits after the first touch)
-#pragma unroll 1
-        for (int i = 0; i < m; i++) {
-            const T ri = rho_l[i];
-            T a1[TW], a2[TC];
+        // S = A' diag(rho) A : the A tile goes through LDS one block of R rows at a time (row R s + il of A is
+        // As[il][.]); every lane then reads the TW + TC entries of each row it needs. No global re-reads.
+        int sl[TW];
 #pragma unroll
-            for (int u = 0; u < TW; u++) a1[u] = (T)gA[(long)ir[u] * m + i] * ri;
+        for (int u = 0; u < TW; u++) sl[u] = L::slot(ir[u]);
 #pragma unroll
-            for (int k = 0; k < TC; k++) a2[k] = (T)gA[(long)jc[k] * m + i];
+        for (int s = 0; s < TR; s++) {
+            __syncthreads();
 #pragma unroll
-            for (int u = 0; u < TW; u++)
+            for (int k = 0; k < TC; k++) As[r * L::SSTR + 8 * c + k] = at[s][k];
+            __syncthreads();
+#pragma unroll 2
+            for (int il = 0; il < R; il++) {
+                const int i = R * s + il;
+                if (i >= m) break;
+                const T ri = rho_l[i];
+                const T *row = As + il * L::SSTR;
+                T a2[8], a1[TW];
+                wg_read<8>(row + 8 * c, a2);
 #pragma unroll
-                for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
+                for (int u = 0; u < TW; u++) a1[u] = row[sl[u]] * ri;
+#pragma unroll
+                for (int u = 0; u < TW; u++)
+#pragma unroll
+                    for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
+            }
         }
+        __syncthreads();
         for (int e = t; e < L::NP + 2; e += NT) {
             rowbuf[e] = 0;
             if (e < L::NP) sjv[e] = T(1);
@@ -458,15 +510,23 @@ struct WgKernel {
         // lane t owns x[t], q[t] (t < n) and z[t], y[t], l[t], u[t], rho[t] (t < m)
         const bool nown = t < n, mown = t < m;
         const T INF = T(1) / T(0);
-        T q = nown ? (T)gq[t] : T(0);
+        // q, l, u of the owned elements live in LDS (read once per iteration by the owner): 6 VGPRs that the
+        // 2-waves-per-QP tiles cannot spare (a spilled VGPR costs a scratch round trip per iteration)
+        T *qv = lds + L::O_QV, *lov = lds + L::O_LOV, *upv = lds + L::O_UPV;
+        if (t < L::NP) qv[t] = nown ? (T)gq[t] : T(0);
+        if (t < L::MP) {
+            lov[t] = mown ? (T)gl[t] : -INF;
+            upv[t] = mown ? (T)gu[t] : INF;
+        }
+        __syncthreads();
         T x = 0, z = 0, y = 0;
-        T lo = mown ? (T)gl[t] : -INF, up = mown ? (T)gu[t] : INF;
         T rho = T(1), rinv = T(1);
         int ctype = SQPH_INEQUALITY_CONSTRAINT;
 
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
             rho_s = a.rho0;
             if (mown) {
+                const T lo = lov[t], up = upv[t];
                 if (lo < -a.loose_thresh && up > a.loose_thresh)
                     ctype = SQPH_LOOSE_BOUNDS;
                 else if (up - lo < a.eq_tol)
@@ -496,9 +556,11 @@ struct WgKernel {
         }
 
         T wt[TW][TC];
+        T at[TR][TC];  // the A tile; turned into B = A W' in place once the factor is known
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
+        bool have_A = false;  // `at` currently holds A (as opposed to B)
         if (!need_factor) load_sq_tile<T>(gW, n, r, c, wt);
         const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
         int iter = 1;
@@ -508,16 +570,18 @@ struct WgKernel {
         for (;;) {
             if (need_factor) {
                 __syncthreads();
-                if (t < L::MP) lds[L::O_STAGE + t] = mown ? rho : T(0);
+                if (t < L::MP) lds[L::O_RHO + t] = mown ? rho : T(0);
                 __syncthreads();
                 int n_f = n, m_f = m, r_f = r, c_f = c, t_f = t;
                 const TIN *gA_f = gA, *gP_f = gP;
                 SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(m_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_V(t_f);
                 SQPH_OPAQUE_S(gA_f); SQPH_OPAQUE_S(gP_f);
-                const bool ok = factor(gP_f, gA_f, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt);
+                load_A_tile(gA_f, n_f, m_f, r_f, c_f, at);  // the only read of A from global memory per factorisation
+                const bool ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt);
                 store_sq_tile(gW, n_f, r_f, c_f, wt);
                 __syncthreads();
                 need_factor = false;
+                have_A = true;
                 if (!solving) {
                     info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
                 } else if (!ok) {
@@ -535,17 +599,22 @@ struct WgKernel {
             }
             // B = A W' replaces A in the iteration:  y1 = W u + B' w,  x~ = W' y1,  z~ = B y1   (u = sigma x - q)
             // => two dependent stages per iteration instead of four (A'w -> W -> W' -> A), i.e. 4 barriers, not 8.
-            T bt[TR][TC];
-            {
+            if (!have_A) {  // solve() on a previously set-up instance: the factor came from the workspace
                 int n_t = n, m_t = m, r_t = r, c_t = c;
                 const TIN *gA_t = gA;
-                const T *gW_t = gW;
-                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_S(m_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t); SQPH_OPAQUE_S(gA_t); SQPH_OPAQUE_S(gW_t);
-                build_B(gA_t, gW_t, n_t, m_t, r_t, c_t, bt);  // (re)built after every factor: its registers were free meanwhile
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_S(m_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t); SQPH_OPAQUE_S(gA_t);
+                load_A_tile(gA_t, n_t, m_t, r_t, c_t, at);
             }
+            have_A = false;  // consumed: `at` holds B from here on
+            {
+                int n_t = n, r_t = r, c_t = c;
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
+                build_B_inplace(at, wt, n_t, lds, r_t, c_t);
+            }
+            T (&bt)[TR][TC] = at;
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
             if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
-            if (t < L::NP) put_colv(lds, t, nown ? sigma * x - q : T(0));
+            if (t < L::NP) put_colv(lds, t, nown ? sigma * x - qv[t] : T(0));
 #ifdef SQPH_PHASE_TIMING
             unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define SQPH_TICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
@@ -590,6 +659,7 @@ struct WgKernel {
                     const T zt = reduce_over_c(lds, t);
                     const T zr = alpha * zt + oma * z;
                     T zn = zr + rinv * y;
+                    const T lo = lov[t], up = upv[t];
                     zn = zn < lo ? lo : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
                     zn = zn > up ? up : zn;
                     y = y + rho * (zr - zn);
@@ -643,13 +713,14 @@ struct WgKernel {
                         v[2] = tabs(Ax - z);
                     }
                     if (nown) {
+                        const T q = qv[t];
                         v[3] = tabs(Px);
                         v[4] = tabs(ATy);
                         v[5] = tabs(q);
                         v[6] = tabs(Px + q + ATy);
                     }
                     {   // workgroup-wide NaN-propagating max: butterfly inside each wave, NW values through LDS
-                        T *red = lds + L::O_STAGE + L::MP + 2 * L::NP + 16;
+                        T *red = lds + L::O_RED;
 #pragma unroll
                         for (int e = 0; e < 7; e++) v[e] = wave_nanmax(v[e]);
                         if constexpr (NW > 1) {
@@ -700,7 +771,7 @@ struct WgKernel {
                 }
                 // operands of the next iteration (the barrier at the loop top orders them before the gathers)
                 if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
-                if (t < L::NP) put_colv(lds, t, nown ? sigma * x - q : T(0));
+                if (t < L::NP) put_colv(lds, t, nown ? sigma * x - qv[t] : T(0));
                 SQPH_TICK(7)
             }
 #ifdef SQPH_PHASE_TIMING
@@ -741,17 +812,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
     X(1, 8, 8, 1, 1, 1, 4)       \
     X(1, 8, 8, 3, 2, 2, 4)       \
     X(1, 8, 8, 5, 3, 3, 3)       \
-    X(1, 8, 8, 5, 3, 3, 4)       \
-    X(1, 8, 8, 5, 3, 3, 2)       \
     X(1, 8, 8, 8, 4, 4, 2)       \
     X(2, 16, 8, 7, 7, 4, 2)      \
-    X(4, 16, 16, 7, 4, 4, 3)     \
-    X(4, 16, 16, 7, 4, 4, 2)     \
-    X(4, 32, 8, 4, 7, 2, 3)      \
-    X(4, 32, 8, 4, 7, 2, 2)      \
-    X(2, 16, 8, 7, 7, 4, 1)      \
-    X(4, 16, 16, 8, 4, 4, 2)     \
-    X(4, 16, 16, 13, 7, 7, 1)
+    X(4, 16, 16, 8, 4, 4, 2)
 
 #ifdef SQPH_SIM
 template <typename TIN>
