@@ -117,7 +117,8 @@ struct WgLayout {
     static constexpr int O_QV = ev(mx(O_STAGE + STAGE, SETUP));
     static constexpr int O_LOV = O_QV + NP;
     static constexpr int O_UPV = O_LOV + MP;
-    static constexpr int TOTAL = O_UPV + MP;
+    static constexpr int O_RINV = O_UPV + MP;  // 1/rho of the owned constraint (changes only at a refactorisation)
+    static constexpr int TOTAL = O_RINV + MP;
     static constexpr int slot(int j) { return 8 * (j / TC) + (j % TC); }
 };
 
@@ -512,7 +513,7 @@ struct WgKernel {
         const T INF = T(1) / T(0);
         // q, l, u of the owned elements live in LDS (read once per iteration by the owner): 6 VGPRs that the
         // 2-waves-per-QP tiles cannot spare (a spilled VGPR costs a scratch round trip per iteration)
-        T *qv = lds + L::O_QV, *lov = lds + L::O_LOV, *upv = lds + L::O_UPV;
+        T *qv = lds + L::O_QV, *lov = lds + L::O_LOV, *upv = lds + L::O_UPV, *rinvv = lds + L::O_RINV;
         if (t < L::NP) qv[t] = nown ? (T)gq[t] : T(0);
         if (t < L::MP) {
             lov[t] = mown ? (T)gl[t] : -INF;
@@ -520,19 +521,20 @@ struct WgKernel {
         }
         __syncthreads();
         T x = 0, z = 0, y = 0;
-        T rho = T(1), rinv = T(1);
-        int ctype = SQPH_INEQUALITY_CONSTRAINT;
+        T rho = T(1);
+        if (t < L::MP) rinvv[t] = T(1);  // 1/rho lives in LDS (see O_RINV)
 
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
             rho_s = a.rho0;
             if (mown) {
                 const T lo = lov[t], up = upv[t];
+                int ctype = SQPH_INEQUALITY_CONSTRAINT;
                 if (lo < -a.loose_thresh && up > a.loose_thresh)
                     ctype = SQPH_LOOSE_BOUNDS;
                 else if (up - lo < a.eq_tol)
                     ctype = SQPH_EQUALITY_CONSTRAINT;
                 rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
-                rinv = T(1) / rho;
+                rinvv[t] = T(1) / rho;
                 sct[t] = ctype;
                 srho[t] = rho;
             }
@@ -550,8 +552,7 @@ struct WgKernel {
                 z = sz[t];
                 y = sy[t];
                 rho = srho[t];
-                rinv = T(1) / rho;
-                ctype = sct[t];
+                rinvv[t] = T(1) / rho;
             }
         }
 
@@ -613,7 +614,7 @@ struct WgKernel {
             }
             T (&bt)[TR][TC] = at;
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
-            if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
+            if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
             if (t < L::NP) put_colv(lds, t, nown ? sigma * x - qv[t] : T(0));
 #ifdef SQPH_PHASE_TIMING
             unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
@@ -658,7 +659,7 @@ struct WgKernel {
                 if (mown) {
                     const T zt = reduce_over_c(lds, t);
                     const T zr = alpha * zt + oma * z;
-                    T zn = zr + rinv * y;
+                    T zn = zr + rinvv[t] * y;
                     const T lo = lov[t], up = upv[t];
                     zn = zn < lo ? lo : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
                     zn = zn > up ? up : zn;
@@ -760,8 +761,8 @@ struct WgKernel {
                         if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
                             rho_s = new_rho;
                             if (mown) {
-                                rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
-                                rinv = T(1) / rho;
+                                rho = rho_for_type<T>(sct[t], rho_s, a.rho_min, a.rho_eq_factor);  // type re-read from the state array (rare)
+                                rinvv[t] = T(1) / rho;
                             }
                             info.rho_updates += 1;
                             need_factor = true;
@@ -770,7 +771,7 @@ struct WgKernel {
                     }
                 }
                 // operands of the next iteration (the barrier at the loop top orders them before the gathers)
-                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinv * y) : T(0));
+                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
                 if (t < L::NP) put_colv(lds, t, nown ? sigma * x - qv[t] : T(0));
                 SQPH_TICK(7)
             }
