@@ -1,0 +1,321 @@
+// sqp.hpp — batched host-side SQP driver on top of the GPU QP-subproblem solver (BASELINE config 4).
+//
+// The reference's SQP outer loop (src/sqp.cpp:43-101), QP construction + damped BFGS + posdef repair
+// (src/sqp.cpp:139-208, include/solvers/bfgs.hpp:14-41), second-order correction (src/sqp.cpp:244-276),
+// l1-merit line search (src/sqp.cpp:277-308) and termination (src/sqp.cpp:124-131, 329-343) stay on the
+// host, exactly as BASELINE.json's north_star asks; what changes is that N problem instances advance in
+// lock-step and all their QP subproblems of an outer iteration go to the GPU in ONE sqph_setup_solve call
+// (finished instances are compacted out of the batch).  Per instance the arithmetic is the reference's.
+//
+//   reference                                         here
+//   sqp::NonLinearProblem<Scalar>  sqp.hpp:62-76       sqp::NonLinearProblem<Scalar> (raw pointers, Jc column-major)
+//   sqp::sqp_settings_t<Scalar>    sqp.hpp:13-31       sqp::sqp_settings_t<Scalar>
+//   sqp::Info / Status             sqp.hpp:33-38       sqp::Info / Status
+//   sqp::SQP<Scalar>::solve        sqp.cpp:26-41       sqp::BatchSQP<Scalar>::solve (N instances)
+#pragma once
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "qp.hpp"
+
+namespace sqp {
+
+template <typename Scalar_ = double>
+struct NonLinearProblem {
+    using Scalar = Scalar_;
+    int num_var = 0;
+    int num_constr = 0;
+    virtual void objective(const Scalar *x, Scalar &obj) = 0;
+    virtual void objective_linearized(const Scalar *x, Scalar *grad, Scalar &obj) = 0;
+    virtual void constraint(const Scalar *x, Scalar *c, Scalar *l, Scalar *u) = 0;
+    // Jc: num_constr x num_var, column-major
+    virtual void constraint_linearized(const Scalar *x, Scalar *Jc, Scalar *c, Scalar *l, Scalar *u) = 0;
+    virtual ~NonLinearProblem() {}
+};
+
+template <typename Scalar>
+struct sqp_settings_t {
+    Scalar tau = 0.5;
+    Scalar eta = 0.25;
+    Scalar rho = 0.5;
+    Scalar eps_prim = 1e-4;
+    Scalar eps_dual = 1e-4;
+    int max_iter = 100;
+    int line_search_max_iter = 20;
+    bool second_order_correction = false;
+};
+
+typedef enum { SOLVED, MAX_ITER_EXCEEDED, INVALID_SETTINGS } Status;
+
+struct Info {
+    int iter = 0;
+    int qp_solver_iter = 0;
+    Status status = MAX_ITER_EXCEEDED;
+};
+
+template <typename Scalar_>
+class BatchSQP {
+   public:
+    using Scalar = Scalar_;
+    using Problem = NonLinearProblem<Scalar>;
+    using Settings = sqp_settings_t<Scalar>;
+    static constexpr Scalar DIV_BY_ZERO_REGUL = std::numeric_limits<Scalar>::epsilon();
+
+    BatchSQP(int num_var, int num_constr, int batch, int device = 0)
+        : n_(num_var), m_(num_constr), batch_(batch), qp_(num_var, num_constr, batch, device), inst_(batch) {
+        // QP settings of the reference's SQP constructor, src/sqp.cpp:15-23
+        auto &s = qp_.settings();
+        s.warm_start = true;
+        s.check_termination = 10;
+        s.eps_abs = 1e-4;
+        s.eps_rel = 1e-4;
+        s.max_iter = 100;
+        s.adaptive_rho = true;
+        s.adaptive_rho_interval = 50;
+        s.alpha = 1.6;
+        const size_t n = n_, m = m_ > 0 ? m_ : 1, B = batch;
+        P_.resize(B * n * n); q_.resize(B * n); A_.resize(B * m * n); l_.resize(B * m); u_.resize(B * m);
+        for (auto &I : inst_) I.init(n_, m_);
+    }
+
+    Settings &settings() { return settings_; }
+    qp_solver::QPSolverSettings<Scalar> &qp_settings() { return qp_.settings(); }
+
+    // probs[i] is the NLP of instance i (several entries may point to one stateless object).
+    // X0: [batch][num_var], Lambda0: [batch][num_constr] (nullptr = zeros, as SQP::solve(prob) does).
+    void solve(const std::vector<Problem *> &probs, const Scalar *X0, const Scalar *Lambda0) {
+        const int n = n_, m = m_;
+        std::vector<int> live;
+        for (int i = 0; i < batch_; i++) {
+            Inst &I = inst_[i];
+            for (int k = 0; k < n; k++) I.x[k] = X0 ? X0[(size_t)i * n + k] : Scalar(0);
+            for (int k = 0; k < m; k++) I.lambda[k] = Lambda0 ? Lambda0[(size_t)i * m + k] : Scalar(0);
+            I.info = Info();
+            live.push_back(i);
+        }
+        int iter;
+        for (iter = 1; iter <= settings_.max_iter && !live.empty(); iter++) {
+            // ---- solve_qp (src/sqp.cpp:139-199) for every live instance: build the QP on the host ...
+            for (size_t k = 0; k < live.size(); k++) {
+                Inst &I = inst_[live[k]];
+                Problem &prob = *probs[live[k]];
+                I.info.iter = iter;
+                prob.objective_linearized(I.x.data(), I.grad_obj.data(), I.obj);
+                prob.constraint_linearized(I.x.data(), I.Jac.data(), I.constr.data(), I.l.data(), I.u.data());
+                for (int a = 0; a < n; a++) I.delta_grad_L[a] = -I.grad_L[a];
+                for (int j = 0; j < n; j++) {
+                    Scalar acc = 0;
+                    for (int a = 0; a < m; a++) acc += I.Jac[(size_t)j * m + a] * I.lambda[a];
+                    I.grad_L[j] = I.grad_obj[j] + acc;
+                }
+                if (iter == 1) {
+                    for (int j = 0; j < n; j++)
+                        for (int a = 0; a < n; a++) I.Hess[(size_t)j * n + a] = (a == j) ? Scalar(1) : Scalar(0);
+                } else {
+                    for (int a = 0; a < n; a++) I.delta_grad_L[a] += I.grad_L[a];
+                    bfgs_update(I);
+                }
+                if (!is_posdef(I)) {  // src/sqp.cpp:172-181
+                    Scalar tau = 1e-3;
+                    while (!is_posdef(I)) {
+                        for (int a = 0; a < n; a++) I.Hess[(size_t)a * n + a] += tau;
+                        tau *= 10;
+                    }
+                }
+                for (int a = 0; a < m; a++) {
+                    I.ql[a] = I.l[a] - I.constr[a];
+                    I.qu[a] = I.u[a] - I.constr[a];
+                }
+                pack(k, I);
+            }
+            // ---- ... and run_solve_qp (src/sqp.cpp:210-242) for all of them in one launch
+            run_qp(live);
+            if (settings_.second_order_correction) {  // src/sqp.cpp:244-276
+                for (size_t k = 0; k < live.size(); k++) {
+                    Inst &I = inst_[live[k]];
+                    Problem &prob = *probs[live[k]];
+                    for (int a = 0; a < n; a++) I.x_step[a] = I.x[a] + I.p[a];
+                    prob.constraint(I.x_step.data(), I.c_step.data(), I.l.data(), I.u.data());
+                    for (int a = 0; a < m; a++) {
+                        Scalar acc = 0;
+                        for (int j = 0; j < n; j++) acc += I.Jac[(size_t)j * m + a] * I.p[j];
+                        const Scalar d = I.c_step[a] - acc;
+                        I.ql[a] = I.l[a] - d;
+                        I.qu[a] = I.u[a] - d;
+                    }
+                    pack(k, I);
+                }
+                run_qp(live);
+            }
+            // ---- step, line search, termination (src/sqp.cpp:76-96)
+            std::vector<int> still;
+            for (size_t k = 0; k < live.size(); k++) {
+                Inst &I = inst_[live[k]];
+                Problem &prob = *probs[live[k]];
+                for (int a = 0; a < m; a++) I.p_lambda[a] -= I.lambda[a];
+                const Scalar alpha = line_search(I, prob);
+                for (int a = 0; a < n; a++) I.x[a] += alpha * I.p[a];
+                for (int a = 0; a < m; a++) I.lambda[a] += alpha * I.p_lambda[a];
+                for (int a = 0; a < n; a++) I.step_prev[a] = alpha * I.p[a];
+                const Scalar primal_step_norm = alpha * inf_norm(I.p), dual_step_norm = alpha * inf_norm(I.p_lambda);
+                if (primal_step_norm <= settings_.eps_prim && dual_step_norm <= settings_.eps_dual &&
+                    max_constraint_violation(I, prob) <= settings_.eps_prim) {
+                    I.info.status = SOLVED;
+                } else {
+                    still.push_back(live[k]);
+                }
+            }
+            live.swap(still);
+        }
+        for (int i : live) {  // exhausted: src/sqp.cpp:98-100 (iter == max_iter + 1)
+            inst_[i].info.status = MAX_ITER_EXCEEDED;
+            inst_[i].info.iter = settings_.max_iter + 1;
+        }
+    }
+
+    const Scalar *primal_solution(int i) const { return inst_[i].x.data(); }
+    const Scalar *dual_solution(int i) const { return inst_[i].lambda.data(); }
+    const Info &info(int i) const { return inst_[i].info; }
+    int qp_launches() const { return launches_; }
+
+   private:
+    struct Inst {
+        std::vector<Scalar> x, lambda, step_prev, grad_L, delta_grad_L, Hess, grad_obj, Jac, constr, l, u;
+        std::vector<Scalar> p, p_lambda, ql, qu, x_step, c_step, work, Bs, r;
+        Scalar obj = 0;
+        Info info;
+        void init(int n, int m) {
+            const size_t mm = m > 0 ? m : 1;
+            x.assign(n, 0); lambda.assign(mm, 0); step_prev.assign(n, 0); grad_L.assign(n, 0); delta_grad_L.assign(n, 0);
+            Hess.assign((size_t)n * n, 0); grad_obj.assign(n, 0); Jac.assign(mm * n, 0); constr.assign(mm, 0); l.assign(mm, 0); u.assign(mm, 0);
+            p.assign(n, 0); p_lambda.assign(mm, 0); ql.assign(mm, 0); qu.assign(mm, 0); x_step.assign(n, 0); c_step.assign(mm, 0);
+            work.assign((size_t)n * n, 0); Bs.assign(n, 0); r.assign(n, 0);
+        }
+    };
+
+    void pack(size_t k, const Inst &I) {
+        const size_t n = n_, m = m_;
+        std::copy(I.Hess.begin(), I.Hess.end(), P_.begin() + k * n * n);
+        std::copy(I.grad_obj.begin(), I.grad_obj.end(), q_.begin() + k * n);
+        std::copy(I.Jac.begin(), I.Jac.begin() + m * n, A_.begin() + k * m * n);
+        std::copy(I.ql.begin(), I.ql.begin() + m, l_.begin() + k * m);
+        std::copy(I.qu.begin(), I.qu.begin() + m, u_.begin() + k * m);
+    }
+    void run_qp(const std::vector<int> &live) {
+        qp_.setup_solve(qp_.packed((int)live.size(), P_.data(), q_.data(), A_.data(), l_.data(), u_.data()));
+        launches_++;
+        for (size_t k = 0; k < live.size(); k++) {
+            Inst &I = inst_[live[k]];
+            const auto &qi = qp_.info((int)k);
+            I.info.qp_solver_iter += qi.iter;
+            if (qi.status == qp_solver::NUMERICAL_ISSUES) continue;  // prim/dual left untouched, src/sqp.cpp:226-229
+            for (int a = 0; a < n_; a++) I.p[a] = qp_.primal_solution((int)k)[a];
+            for (int a = 0; a < m_; a++) I.p_lambda[a] = qp_.dual_solution((int)k)[a];
+        }
+    }
+    // Eigen::LLT-style test, src/sqp.cpp:115-122
+    bool is_posdef(Inst &I) const {
+        const int n = n_;
+        std::vector<Scalar> &w = I.work;
+        w = I.Hess;
+        for (int k = 0; k < n; k++) {
+            Scalar x = w[(size_t)k * n + k];
+            for (int j = 0; j < k; j++) x -= w[(size_t)j * n + k] * w[(size_t)j * n + k];
+            if (!(x > Scalar(0))) return false;
+            x = std::sqrt(x);
+            w[(size_t)k * n + k] = x;
+            for (int i = k + 1; i < n; i++) {
+                Scalar v = w[(size_t)k * n + i];
+                for (int j = 0; j < k; j++) v -= w[(size_t)j * n + i] * w[(size_t)j * n + k];
+                w[(size_t)k * n + i] = v / x;
+            }
+        }
+        return true;
+    }
+    // damped BFGS, include/solvers/bfgs.hpp:14-41
+    void bfgs_update(Inst &I) const {
+        const int n = n_;
+        const std::vector<Scalar> &s = I.step_prev, &y = I.delta_grad_L;
+        Scalar sBs = 0, sy = 0, sr;
+        for (int i = 0; i < n; i++) {
+            Scalar a = 0;
+            for (int j = 0; j < n; j++) a += I.Hess[(size_t)j * n + i] * s[j];
+            I.Bs[i] = a;
+        }
+        for (int i = 0; i < n; i++) {
+            sBs += s[i] * I.Bs[i];
+            sy += s[i] * y[i];
+        }
+        if (sy < 0.2 * sBs) {
+            const Scalar theta = 0.8 * sBs / (sBs - sy);
+            for (int i = 0; i < n; i++) I.r[i] = theta * y[i] + (1 - theta) * I.Bs[i];
+            sr = theta * sy + (1 - theta) * sBs;
+        } else {
+            for (int i = 0; i < n; i++) I.r[i] = y[i];
+            sr = sy;
+        }
+        if (sr < std::numeric_limits<Scalar>::epsilon()) return;
+        for (int j = 0; j < n; j++)
+            for (int i = 0; i < n; i++) I.Hess[(size_t)j * n + i] += -I.Bs[i] * I.Bs[j] / sBs + I.r[i] * I.r[j] / sr;
+    }
+    Scalar constraint_norm(const Inst &I) const {  // src/sqp.cpp:310-318
+        Scalar c_l1 = DIV_BY_ZERO_REGUL, a = 0, b = 0;
+        for (int i = 0; i < m_; i++) a += (I.l[i] - I.constr[i]) > Scalar(0) ? (I.l[i] - I.constr[i]) : Scalar(0);
+        for (int i = 0; i < m_; i++) b += (I.constr[i] - I.u[i]) > Scalar(0) ? (I.constr[i] - I.u[i]) : Scalar(0);
+        c_l1 += a;
+        c_l1 += b;
+        return c_l1;
+    }
+    Scalar line_search(Inst &I, Problem &prob) const {  // src/sqp.cpp:277-308
+        const int n = n_;
+        const Scalar constr_l1 = constraint_norm(I);
+        Scalar gp = 0, pHp = 0;
+        for (int i = 0; i < n; i++) gp += I.grad_obj[i] * I.p[i];
+        for (int i = 0; i < n; i++) {
+            Scalar a = 0;
+            for (int j = 0; j < n; j++) a += I.Hess[(size_t)j * n + i] * I.p[j];
+            pHp += I.p[i] * a;
+        }
+        const Scalar mu = (gp + 0.5 * pHp) / ((1 - settings_.rho) * constr_l1);
+        const Scalar phi_l1 = I.obj + mu * constr_l1;
+        const Scalar Dp_phi_l1 = gp - mu * constr_l1;
+        Scalar alpha = 1.0;
+        for (int i = 1; i < settings_.line_search_max_iter; i++) {
+            Scalar obj_step;
+            for (int k = 0; k < n; k++) I.x_step[k] = I.x[k] + alpha * I.p[k];
+            prob.objective(I.x_step.data(), obj_step);
+            prob.constraint(I.x_step.data(), I.constr.data(), I.l.data(), I.u.data());
+            const Scalar phi_l1_step = obj_step + mu * constraint_norm(I);
+            if (phi_l1_step <= phi_l1 + alpha * settings_.eta * Dp_phi_l1) break;
+            alpha = settings_.tau * alpha;
+        }
+        return alpha;
+    }
+    Scalar inf_norm(const std::vector<Scalar> &v) const {
+        Scalar r = 0;
+        for (size_t i = 0; i < v.size(); i++) r = std::fabs(v[i]) > r ? std::fabs(v[i]) : r;
+        return r;
+    }
+    Scalar max_constraint_violation(Inst &I, Problem &prob) const {  // src/sqp.cpp:329-343
+        Scalar c_max = 0;
+        prob.constraint(I.x.data(), I.constr.data(), I.l.data(), I.u.data());
+        if (m_ > 0) {
+            Scalar a = -std::numeric_limits<Scalar>::infinity(), b = a;
+            for (int i = 0; i < m_; i++) a = (I.l[i] - I.constr[i]) > a ? (I.l[i] - I.constr[i]) : a;
+            for (int i = 0; i < m_; i++) b = (I.constr[i] - I.u[i]) > b ? (I.constr[i] - I.u[i]) : b;
+            c_max = std::fmax(c_max, a);
+            c_max = std::fmax(c_max, b);
+        }
+        return c_max;
+    }
+
+    int n_, m_, batch_;
+    int launches_ = 0;
+    Settings settings_;
+    qp_solver::BatchQPSolver<Scalar> qp_;
+    std::vector<Inst> inst_;
+    std::vector<Scalar> P_, q_, A_, l_, u_;
+};
+
+}  // namespace sqp

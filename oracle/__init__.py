@@ -73,7 +73,7 @@ def build(force=False):
     """Compile oracle/libqp_oracle.so with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("qp_oracle.c", "qp_oracle_impl.h", "qp_oracle.h")
+        for f in ("qp_oracle.c", "qp_oracle_impl.h", "qp_oracle.h", "sqp_oracle.c", "sqp_oracle.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libqp_oracle.so"] + (["-B"] if force else []))
     return _LIB_PATH
