@@ -14,6 +14,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 /* sqp_settings_t defaults, sqp.hpp:13-23 */
@@ -219,6 +220,13 @@ void sqpo_solve(const sqpo_problem *prob, const sqpo_settings *settings, const d
         for (int i = 0; i < n; i++) s->step_prev[i] = alpha * s->p[i];
         s->primal_step_norm = alpha * inf_norm(s->p, n);
         s->dual_step_norm = alpha * inf_norm(s->p_lambda, m);
+        if (getenv("SQPO_TRACE")) {
+            fprintf(stderr, "sqpo iter %d alpha %.3e obj %.6e p", iter, alpha, s->obj);
+            for (int i = 0; i < n; i++) fprintf(stderr, " %.9g", s->p[i]);
+            fprintf(stderr, " | x");
+            for (int i = 0; i < n; i++) fprintf(stderr, " %.9g", s->x[i]);
+            fprintf(stderr, "\n");
+        }
         /* termination_criteria, sqp.cpp:124-131 + max_constraint_violation 329-343 */
         double c_max = 0;
         prob->constraint(prob->user, s->x, s->constr, s->l, s->u);
