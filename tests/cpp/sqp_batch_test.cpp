@@ -4,6 +4,7 @@
 //   2. through sqp::BatchSQP (include/sqp_hip/sqp.hpp): host SQP logic, all QP subproblems of an outer
 //      iteration solved by ONE libsqp_hip launch — compared per instance with the oracle.
 // `sqp_batch_test.bin oracle` runs part 1 only (no GPU needed).  Exit 0 = passed, 3 = no HIP device.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -223,7 +224,9 @@ static int batch_vs_oracle(const char *name, NLP &prob, int batch, const std::ve
     solver.settings().max_iter = 100;
     solver.settings().second_order_correction = soc;
     std::vector<NLP *> probs(batch, &prob);
+    const auto t0 = std::chrono::steady_clock::now();
     solver.solve(probs, X0.data(), L0.data());
+    const auto t1 = std::chrono::steady_clock::now();
     int solved = 0, strict = 0, loose = 0, near_solution = 0, bad = 0, osolved = 0, onear_solution = 0;
     double worst_x = 0, worst_l = 0;
     for (int i = 0; i < batch; i++) {
@@ -254,6 +257,11 @@ static int batch_vs_oracle(const char *name, NLP &prob, int batch, const std::ve
     }
     printf("batch  %-28s N %5d launches %4d solved %5d near-solution %5d | strict %5d (max|dx| %.2e max|dlambda| %.2e) loose %d split %d | oracle solved %d near-solution %d\n",
            name, batch, solver.qp_launches(), solved, near_solution, strict, worst_x, worst_l, loose, bad, osolved, onear_solution);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (batch > 1)
+        printf("       wall: batched driver %.1f ms (%.0f instances/s), serial oracle %.1f ms (%.0f instances/s, 1 thread)\n",
+               std::chrono::duration<double, std::milli>(t1 - t0).count(), batch / std::chrono::duration<double>(t1 - t0).count(),
+               std::chrono::duration<double, std::milli>(t2 - t1).count(), batch / std::chrono::duration<double>(t2 - t1).count());
     CHECK(bad <= max_split * batch);
     CHECK(std::abs(solved - osolved) <= max_split * batch);
     CHECK(std::abs(near_solution - onear_solution) <= max_split * batch);
