@@ -101,6 +101,24 @@ typedef struct sqph_qp_batch {
     long long stride_P, stride_q, stride_A, stride_l, stride_u; /* elements; 0 = shared */
 } sqph_qp_batch;
 
+/* The same batch with the constraint matrix in CSR (BASELINE config 5; the reference's sparse variant keeps P and A as
+ * Eigen::SparseMatrix, include/unsupported/qp_solver.hpp:17-32,363-394 — same ADMM, sparse KKT storage).  P stays dense.
+ * Row i of QP b holds entries A_colind/A_val[rowptr[i] .. rowptr[i+1]) (0-based; duplicates within a row are summed).
+ * stride_rowptr = 0 and stride_colind = 0 share one sparsity pattern across the batch (stride_val then = nnz). */
+typedef struct sqph_csr_batch {
+    int batch;
+    int memspace;
+    const void *P;        /* n x n dense, col-major */
+    const void *q;        /* n */
+    const int *A_rowptr;  /* m + 1 */
+    const int *A_colind;  /* nnz (<= stride_colind when per-QP) */
+    const void *A_val;    /* nnz */
+    const void *l;        /* m */
+    const void *u;        /* m */
+    long long stride_P, stride_q, stride_rowptr, stride_colind, stride_val, stride_l, stride_u; /* elements; 0 = shared */
+    long long nnz_max;    /* capacity of one QP's colind/val arrays (= nnz for a shared pattern) */
+} sqph_csr_batch;
+
 typedef struct sqph_solver sqph_solver;
 
 /* Behaviour flags for sqph_create */
@@ -133,6 +151,12 @@ int sqph_setup(sqph_solver *s, const sqph_qp_batch *qp);       /* QPSolver::setu
 int sqph_update_qp(sqph_solver *s, const sqph_qp_batch *qp);   /* QPSolver::update_qp             */
 int sqph_solve(sqph_solver *s, const sqph_qp_batch *qp);       /* QPSolver::solve                 */
 int sqph_setup_solve(sqph_solver *s, const sqph_qp_batch *qp); /* setup()+solve(), single launch  */
+
+/* CSR-A variants of the four calls above (legacy sparse QPSolver, unsupported/qp_solver.hpp:215-330). */
+int sqph_setup_csr(sqph_solver *s, const sqph_csr_batch *qp);
+int sqph_update_qp_csr(sqph_solver *s, const sqph_csr_batch *qp);
+int sqph_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);
+int sqph_setup_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);
 
 /* Copy out primal x [batch][n], dual y [batch][m], z [batch][m] and info [batch]; any pointer
  * may be NULL. With SQPH_HOST this call synchronises the stream before returning. */

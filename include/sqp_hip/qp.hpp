@@ -124,6 +124,25 @@ class BatchQPSolver {
     void solve(const Batch &b) { call(sqph_solve, b, "sqph_solve"); }
     void setup_solve(const Batch &b) { call(sqph_setup_solve, b, "sqph_setup_solve"); }  // what SQP::run_solve_qp does (src/sqp.cpp:221-222)
 
+    // The same calls with the constraint matrices in CSR (legacy sparse class, unsupported/qp_solver.hpp:17-32; BASELINE
+    // config 5).  Per-QP arrays: rowptr [m+1], colind/val [nnz_max]; packed_csr lays QPs back to back.
+    struct CsrBatch {
+        int batch;
+        int memspace;
+        const Scalar *P, *q;
+        const int *rowptr, *colind;
+        const Scalar *val, *l, *u;
+        long long stride_P, stride_q, stride_rowptr, stride_colind, stride_val, stride_l, stride_u, nnz_max;
+    };
+    CsrBatch packed_csr(int batch, const Scalar *P, const Scalar *q, const int *rowptr, const int *colind, const Scalar *val, long long nnz_max,
+                        const Scalar *l, const Scalar *u, int memspace = SQPH_HOST) const {
+        return CsrBatch{batch, memspace, P, q, rowptr, colind, val, l, u, (long long)n_ * n_, n_, m_ + 1, nnz_max, nnz_max, m_, m_, nnz_max};
+    }
+    void setup_csr(const CsrBatch &b) { call_csr(sqph_setup_csr, b, "sqph_setup_csr"); }
+    void update_qp_csr(const CsrBatch &b) { call_csr(sqph_update_qp_csr, b, "sqph_update_qp_csr"); }
+    void solve_csr(const CsrBatch &b) { call_csr(sqph_solve_csr, b, "sqph_solve_csr"); }
+    void setup_solve_csr(const CsrBatch &b) { call_csr(sqph_setup_solve_csr, b, "sqph_setup_solve_csr"); }
+
     // results of the last call (host copies, fetched lazily)
     const Scalar *primal_solution(int b) { fetch(); return &x_[(size_t)b * n_]; }
     const Scalar *dual_solution(int b) { fetch(); return &y_[(size_t)b * m_]; }
@@ -133,6 +152,28 @@ class BatchQPSolver {
     int m() const { return m_; }
 
    private:
+    template <typename F>
+    void call_csr(F fn, const CsrBatch &b, const char *what) {
+        push_settings();
+        sqph_csr_batch c;
+        c.batch = b.batch; c.memspace = b.memspace;
+        c.P = b.P; c.q = b.q; c.A_rowptr = b.rowptr; c.A_colind = b.colind; c.A_val = b.val; c.l = b.l; c.u = b.u;
+        c.stride_P = b.stride_P; c.stride_q = b.stride_q; c.stride_rowptr = b.stride_rowptr; c.stride_colind = b.stride_colind;
+        c.stride_val = b.stride_val; c.stride_l = b.stride_l; c.stride_u = b.stride_u; c.nnz_max = b.nnz_max;
+        detail::check(fn(h_, &c), h_, what);
+        last_batch_ = b.batch;
+        fetched_ = false;
+    }
+    void push_settings() {
+        sqph_settings st;
+        st.rho = settings_.rho; st.sigma = settings_.sigma; st.alpha = settings_.alpha;
+        st.eps_rel = settings_.eps_rel; st.eps_abs = settings_.eps_abs;
+        st.max_iter = settings_.max_iter; st.check_termination = settings_.check_termination;
+        st.warm_start = settings_.warm_start; st.adaptive_rho = settings_.adaptive_rho;
+        st.adaptive_rho_tolerance = settings_.adaptive_rho_tolerance;
+        st.adaptive_rho_interval = settings_.adaptive_rho_interval; st.verbose = settings_.verbose;
+        detail::check(sqph_set_settings(h_, &st), h_, "sqph_set_settings");
+    }
     template <typename F>
     void call(F fn, const Batch &b, const char *what) {
         sqph_settings st;

@@ -20,6 +20,7 @@ SYMBOLS = [
     "sqph_get_solution", "sqph_set_state", "sqph_device_state", "sqph_synchronize", "sqph_kernel_name",
     "sqph_enable_timing", "sqph_last_kernel_ms", "sqph_collect_kernel_ms", "sqph_last_error", "sqph_global_error",
     "sqph_constr_type_init", "sqph_algorithmic_bytes", "sqph_version",
+    "sqph_setup_csr", "sqph_update_qp_csr", "sqph_solve_csr", "sqph_setup_solve_csr",
 ]
 
 
@@ -64,6 +65,20 @@ class QPBatch(ctypes.Structure):
     ]
 
 
+class CsrBatch(ctypes.Structure):
+    """sqph_csr_batch: the same batch with A in CSR (reference include/unsupported/qp_solver.hpp:17-32)."""
+
+    _fields_ = [
+        ("batch", ctypes.c_int), ("memspace", ctypes.c_int),
+        ("P", ctypes.c_void_p), ("q", ctypes.c_void_p),
+        ("A_rowptr", ctypes.c_void_p), ("A_colind", ctypes.c_void_p), ("A_val", ctypes.c_void_p),
+        ("l", ctypes.c_void_p), ("u", ctypes.c_void_p),
+        ("stride_P", ctypes.c_longlong), ("stride_q", ctypes.c_longlong), ("stride_rowptr", ctypes.c_longlong),
+        ("stride_colind", ctypes.c_longlong), ("stride_val", ctypes.c_longlong),
+        ("stride_l", ctypes.c_longlong), ("stride_u", ctypes.c_longlong), ("nnz_max", ctypes.c_longlong),
+    ]
+
+
 _lib = None
 
 
@@ -92,6 +107,8 @@ def load(build_if_missing=True):
     L.sqph_get_settings.argtypes = [vp, ctypes.POINTER(Settings)]
     for name in ("sqph_setup", "sqph_update_qp", "sqph_solve", "sqph_setup_solve"):
         getattr(L, name).argtypes = [vp, ctypes.POINTER(QPBatch)]
+    for name in ("sqph_setup_csr", "sqph_update_qp_csr", "sqph_solve_csr", "sqph_setup_solve_csr"):
+        getattr(L, name).argtypes = [vp, ctypes.POINTER(CsrBatch)]
     L.sqph_get_solution.argtypes = [vp, i, i, vp, vp, vp, vp]
     L.sqph_set_state.argtypes = [vp, i, i, vp, vp, vp]
     L.sqph_device_state.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]

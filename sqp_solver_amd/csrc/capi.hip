@@ -44,6 +44,28 @@ __global__ void cvt_f32_to_f64(const float *__restrict__ src, double *__restrict
     if (i < n) dst[i] = (double)src[i];
 }
 
+// CSR -> dense column-major expansion of the constraint matrices (one thread per (QP, row): duplicates within a row
+// are summed in storage order, so the result is deterministic).  `dst` must be zero-filled.
+template <typename TIN>
+__global__ void csr_expand(int batch, int n, int m, const int *__restrict__ rowptr, const int *__restrict__ colind,
+                           const TIN *__restrict__ val, long long s_rowptr, long long s_colind, long long s_val,
+                           TIN *__restrict__ dst, int *__restrict__ bad) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)batch * m) return;
+    const int b = (int)(t / m), i = (int)(t - (long long)b * m);
+    const int *rp = rowptr + b * s_rowptr;
+    const int *ci = colind + b * s_colind;
+    const TIN *v = val + b * s_val;
+    TIN *d = dst + (long long)b * m * n;
+    const int e0 = rp[i], e1 = rp[i + 1];
+    if (e0 < 0 || e1 < e0) { atomicOr(bad, 1); return; }
+    for (int e = e0; e < e1; e++) {
+        const int j = ci[e];
+        if (j < 0 || j >= n) { atomicOr(bad, 2); continue; }
+        d[(long long)j * m + i] += v[e];
+    }
+}
+
 }  // namespace
 
 struct sqph_solver {
@@ -57,6 +79,10 @@ struct sqph_solver {
     void *Sinv = nullptr, *At = nullptr;
     // device staging for host-memspace problem data
     void *sP = nullptr, *sq = nullptr, *sA = nullptr, *sl = nullptr, *su = nullptr;
+    // CSR entry points: staged index/value arrays (host memspace) and the expanded dense A
+    void *cRow = nullptr, *cCol = nullptr, *cVal = nullptr, *cA = nullptr;
+    int *cBad = nullptr;
+    size_t cCol_cap = 0, cVal_cap = 0;
     std::string err;
     const char *kernel_name = "none";
     bool timing = false;
@@ -187,7 +213,7 @@ void sqph_destroy(sqph_solver *s) {
     DeviceGuard g(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     else (void)hipDeviceSynchronize();
-    void *ptrs[] = {s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su};
+    void *ptrs[] = {s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su, s->cRow, s->cCol, s->cVal, s->cA, s->cBad};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &p : s->evs) {
@@ -437,9 +463,120 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what) {
     return launch_typed<double>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su);
 }
 
+// CSR entry points: expand A on the device, then the dense path.
+int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what) {
+    if (!s) return SQPH_ERR_INVALID;
+    if (!c) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: qp is null", what);
+    if (c->batch < 0 || c->batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: batch %d exceeds capacity %d", what, c->batch, s->cap);
+    if (c->batch == 0) return SQPH_OK;
+    if (c->memspace != SQPH_HOST && c->memspace != SQPH_DEVICE) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: bad memspace %d", what, c->memspace);
+    sqph_qp_batch d{};
+    d.batch = c->batch; d.memspace = c->memspace;
+    d.P = c->P; d.q = c->q; d.l = c->l; d.u = c->u;
+    d.stride_P = c->stride_P; d.stride_q = c->stride_q; d.stride_l = c->stride_l; d.stride_u = c->stride_u;
+    if (s->m == 0) return run(s, &d, mode, what);
+    if (!c->A_rowptr || (c->nnz_max > 0 && (!c->A_colind || !c->A_val))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null CSR pointer", what);
+    if (c->stride_rowptr < 0 || c->stride_colind < 0 || c->stride_val < 0 || c->nnz_max < 0)
+        SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: negative stride / nnz_max", what);
+    if ((c->stride_colind && c->stride_colind < c->nnz_max) || (c->stride_val && c->stride_val < c->nnz_max))
+        SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: stride_colind/stride_val smaller than nnz_max", what);
+    if ((c->stride_rowptr == 0) != (c->stride_colind == 0)) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: rowptr and colind must both be shared or both per-QP", what);
+    if (c->stride_rowptr && c->stride_rowptr < s->m + 1) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: stride_rowptr smaller than m+1", what);
+    if (c->stride_val == 0 && c->stride_rowptr != 0) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: shared values need a shared pattern", what);
+
+    DeviceGuard g(s->device);
+    const size_t e = dsize(s->dtype), B = (size_t)c->batch, n = s->n, m = s->m;
+    const int *rowptr = c->A_rowptr, *colind = c->A_colind;
+    const void *val = c->A_val;
+    long long s_row = c->stride_rowptr, s_col = c->stride_colind, s_val = c->stride_val;
+    if (c->memspace == SQPH_HOST) {
+        const size_t nrow = s_row ? B * (size_t)s_row : m + 1;
+        const size_t ncol = s_col ? B * (size_t)s_col : (size_t)c->nnz_max;
+        const size_t nval = s_val ? B * (size_t)s_val : (size_t)c->nnz_max;
+        if (!s->cRow) SQPH_HIP(s, hipMalloc(&s->cRow, (size_t)s->cap * (m + 1) * sizeof(int)));
+        if (s_row && (size_t)s_row != m + 1) {
+            SQPH_HIP(s, hipMemcpy2DAsync(s->cRow, (m + 1) * sizeof(int), rowptr, (size_t)s_row * sizeof(int), (m + 1) * sizeof(int), B,
+                                         hipMemcpyHostToDevice, s->stream));
+            s_row = (long long)(m + 1);
+        } else {
+            SQPH_HIP(s, hipMemcpyAsync(s->cRow, rowptr, (s_row ? B * (m + 1) : m + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        }
+        (void)nrow;
+        if (ncol > s->cCol_cap) {
+            if (s->cCol) (void)hipFree(s->cCol);
+            s->cCol = nullptr;
+            SQPH_HIP(s, hipMalloc(&s->cCol, (ncol ? ncol : 1) * sizeof(int)));
+            s->cCol_cap = ncol;
+        }
+        if (nval > s->cVal_cap) {
+            if (s->cVal) (void)hipFree(s->cVal);
+            s->cVal = nullptr;
+            SQPH_HIP(s, hipMalloc(&s->cVal, (nval ? nval : 1) * e));
+            s->cVal_cap = nval;
+        }
+        if (ncol) SQPH_HIP(s, hipMemcpyAsync(s->cCol, colind, ncol * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        if (nval) SQPH_HIP(s, hipMemcpyAsync(s->cVal, val, nval * e, hipMemcpyHostToDevice, s->stream));
+        rowptr = (const int *)s->cRow; colind = (const int *)s->cCol; val = s->cVal;
+    }
+    const bool shared = s_val == 0;
+    const size_t nexp = shared ? 1 : B;
+    if (!s->cA) SQPH_HIP(s, hipMalloc(&s->cA, (size_t)s->cap * m * n * e));
+    if (!s->cBad) SQPH_HIP(s, hipMalloc((void **)&s->cBad, sizeof(int)));
+    SQPH_HIP(s, hipMemsetAsync(s->cA, 0, nexp * m * n * e, s->stream));
+    SQPH_HIP(s, hipMemsetAsync(s->cBad, 0, sizeof(int), s->stream));
+    const unsigned blocks = (unsigned)((nexp * m + 255) / 256);
+    if (s->dtype == SQPH_F32)
+        hipLaunchKernelGGL((csr_expand<float>), dim3(blocks), dim3(256), 0, s->stream, (int)nexp, (int)n, (int)m, rowptr, colind,
+                           (const float *)val, s_row, s_col, s_val, (float *)s->cA, s->cBad);
+    else
+        hipLaunchKernelGGL((csr_expand<double>), dim3(blocks), dim3(256), 0, s->stream, (int)nexp, (int)n, (int)m, rowptr, colind,
+                           (const double *)val, s_row, s_col, s_val, (double *)s->cA, s->cBad);
+    SQPH_HIP(s, hipGetLastError());
+    int bad = 0;
+    SQPH_HIP(s, hipMemcpyAsync(&bad, s->cBad, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    SQPH_HIP(s, hipStreamSynchronize(s->stream));
+    if (bad) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed CSR (%s)", what, (bad & 1) ? "row pointers not monotone" : "column index out of range");
+
+    // dense remainder of the problem: stage host arrays through the regular path, A is already on the device
+    if (c->memspace == SQPH_HOST) {
+        sqph_qp_batch h = d;  // P, q, l, u from the host; a dummy A pointer is staged below
+        // stage P,q,l,u by hand (the dense entry would also copy A)
+        struct Item { const void *src; void **dst; size_t elems; long long *stride; };
+        long long sP = d.stride_P, sq = d.stride_q, sl = d.stride_l, su = d.stride_u;
+        Item items[4] = {{d.P, &s->sP, n * n, &sP}, {d.q, &s->sq, n, &sq}, {d.l, &s->sl, m, &sl}, {d.u, &s->su, m, &su}};
+        if (!d.P || !d.q || !d.l || !d.u) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null problem pointer", what);
+        if (sP < 0 || sq < 0 || sl < 0 || su < 0) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: negative stride", what);
+        for (auto &it : items) {
+            if (!*it.dst) SQPH_HIP(s, hipMalloc(it.dst, (size_t)s->cap * it.elems * e));
+            if (*it.stride == 0) {
+                SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, it.elems * e, hipMemcpyHostToDevice, s->stream));
+            } else if ((size_t)*it.stride == it.elems) {
+                SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, B * it.elems * e, hipMemcpyHostToDevice, s->stream));
+            } else {
+                SQPH_HIP(s, hipMemcpy2DAsync(*it.dst, it.elems * e, it.src, (size_t)*it.stride * e, it.elems * e, B, hipMemcpyHostToDevice, s->stream));
+                *it.stride = (long long)it.elems;
+            }
+        }
+        SQPH_HIP(s, hipStreamSynchronize(s->stream));
+        h.memspace = SQPH_DEVICE;
+        h.P = s->sP; h.q = s->sq; h.l = s->sl; h.u = s->su;
+        h.stride_P = sP; h.stride_q = sq; h.stride_l = sl; h.stride_u = su;
+        d = h;
+    }
+    d.A = s->cA;
+    d.stride_A = shared ? 0 : (long long)(m * n);
+    return run(s, &d, mode, what);
+}
+
 }  // namespace
 
 extern "C" {
+int sqph_setup_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s, qp, sqph::MODE_SETUP, "sqph_setup_csr"); }
+int sqph_update_qp_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s, qp, sqph::MODE_UPDATE, "sqph_update_qp_csr"); }
+int sqph_solve_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s, qp, sqph::MODE_SOLVE, "sqph_solve_csr"); }
+int sqph_setup_solve_csr(sqph_solver *s, const sqph_csr_batch *qp) {
+    return run_csr(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE, "sqph_setup_solve_csr");
+}
 int sqph_setup(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_SETUP, "sqph_setup"); }
 int sqph_update_qp(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_UPDATE, "sqph_update_qp"); }
 int sqph_solve(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_SOLVE, "sqph_solve"); }

@@ -86,6 +86,47 @@ def random_qp_batch_torch(batch, n, m, seed=20250228, dtype=None, device="cuda",
     return P, q, A_cm, l, u
 
 
+def random_csr_qp_batch(batch, n, m, density=0.05, seed=20250233, dtype=np.float64, shared_pattern=False):
+    """BASELINE config 5: the same distribution with A sparse — `density` of the entries kept, at least
+    one per row.  Returns P [B,n,n], q, rowptr int32 [B,m+1], colind int32 [B,nnz_max], val [B,nnz_max] (rows of each
+    QP stored back to back, zero-padded to nnz_max), l, u and the dense A [B,m,n] the CSR arrays encode."""
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((batch, n, n))
+    P = G @ np.transpose(G, (0, 2, 1)) / n + 0.1 * np.eye(n)[None]
+    P = 0.5 * (P + np.transpose(P, (0, 2, 1)))
+    q = rng.standard_normal((batch, n))
+    pb = 1 if shared_pattern else batch
+    mask = rng.uniform(0, 1, (pb, m, n)) < density
+    forced = rng.integers(0, n, (pb, m))
+    mask[np.arange(pb)[:, None], np.arange(m)[None, :], forced] = True
+    if shared_pattern:
+        mask = np.broadcast_to(mask, (batch, m, n))
+    A = rng.standard_normal((batch, m, n)) * mask
+    x0 = rng.standard_normal((batch, n))
+    c = np.einsum("bij,bj->bi", A, x0)
+    l = c - rng.uniform(0, 1, (batch, m))
+    u = c + rng.uniform(0, 1, (batch, m))
+    h = _row_classes(batch, m)
+    eq, one, loose = h < 10, (h >= 10) & (h < 20), (h >= 20) & (h < 22)
+    l = np.where(eq, c, l)
+    u = np.where(eq, c, u)
+    u = np.where(one, np.inf, u)
+    l = np.where(loose, -1e20, l)
+    u = np.where(loose, 1e20, u)
+    counts = mask.sum(axis=2)
+    rowptr = np.zeros((batch, m + 1), dtype=np.int32)
+    rowptr[:, 1:] = np.cumsum(counts, axis=1)
+    nnz_max = int(rowptr[:, -1].max())
+    colind = np.zeros((batch, nnz_max), dtype=np.int32)
+    val = np.zeros((batch, nnz_max), dtype=dtype)
+    for b in range(batch):
+        ii, jj = np.nonzero(mask[b])  # row-major order == CSR order
+        colind[b, : len(jj)] = jj
+        val[b, : len(jj)] = A[b, ii, jj]
+    cast = lambda a: np.ascontiguousarray(a, dtype=dtype)  # noqa: E731
+    return cast(P), cast(q), rowptr, colind, val, cast(l), cast(u), cast(A)
+
+
 SIMPLE_QP = dict(  # the reference's canonical fixture, tests/qp_solver_test.cpp:19-31
     P=np.array([[4.0, 1.0], [1.0, 2.0]]), q=np.array([1.0, 1.0]),
     A=np.array([[1.0, 1.0], [1.0, 0.0], [0.0, 1.0]]), l=np.array([1.0, 0.0, 0.0]), u=np.array([1.0, 0.7, 0.7]),

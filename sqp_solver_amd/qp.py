@@ -211,6 +211,106 @@ class QPSolverBatch:
         """setup(); solve() in one kernel launch (what SQP::run_solve_qp does, src/sqp.cpp:221-222)."""
         self._call(self._L.sqph_setup_solve, "sqph_setup_solve", P, q, A, l, u, colmajor)
 
+    # ------------------------------------------------------------------ CSR-A variants (BASELINE config 5)
+    def _csr_desc(self, P, q, rowptr, colind, val, l, u):
+        """P [B,n,n] or [n,n] (row- or column-major is irrelevant only for symmetric P: pass logical P), q [B,n],
+        rowptr int32 [B,m+1] or [m+1], colind int32 [B,nnz_max] or [nnz], val [B,nnz_max] or [nnz], l/u [B,m]."""
+        n, m = self.n, self.m
+        items = {}
+        dev = None
+        batch = None
+
+        def prep_idx(a, inner):
+            if _is_torch(a):
+                import torch
+
+                if a.dtype != torch.int32:
+                    raise TypeError("CSR index tensors must be int32")
+                if a.is_cuda:
+                    a = a.contiguous()
+                    shared = a.dim() == 1
+                    return a, a.data_ptr(), 0 if shared else a.shape[-1], True, None if shared else a.shape[0]
+                a = a.numpy()
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+            shared = a.ndim == 1
+            return a, a.ctypes.data, 0 if shared else a.shape[-1], False, None if shared else a.shape[0]
+
+        def prep_val(a):
+            if _is_torch(a) and a.is_cuda:
+                import torch
+
+                tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+                if a.dtype != tdt:
+                    raise TypeError("tensor dtype %s does not match solver dtype %s" % (a.dtype, self.dtype))
+                a = a.contiguous()
+                shared = a.dim() == 1
+                return a, a.data_ptr(), 0 if shared else a.shape[-1], True, None if shared else a.shape[0]
+            if _is_torch(a):
+                a = a.numpy()
+            a = np.ascontiguousarray(np.asarray(a, dtype=self.dtype))
+            shared = a.ndim == 1
+            return a, a.ctypes.data, 0 if shared else a.shape[-1], False, None if shared else a.shape[0]
+
+        for name, arr, shp in (("P", P, (n, n)), ("q", q, (n,)), ("l", l, (m,)), ("u", u, (m,))):
+            if tuple(arr.shape[-len(shp):]) != tuple(shp):
+                raise ValueError("%s has shape %s, expected [...,%s]" % (name, tuple(arr.shape), shp))
+            items[name] = self._prep_one(arr, shp, False)
+        items["rowptr"] = prep_idx(rowptr, m + 1)
+        items["colind"] = prep_idx(colind, None)
+        items["val"] = prep_val(val)
+        if items["rowptr"][0].shape[-1] != m + 1:
+            raise ValueError("rowptr must have m+1 entries per QP")
+        for name, it in items.items():
+            if dev is None:
+                dev = it[3]
+            elif dev != it[3]:
+                raise ValueError("mixing host and device problem arrays is not supported")
+            if it[4] is not None:
+                if batch is None:
+                    batch = it[4]
+                elif batch != it[4]:
+                    raise ValueError("inconsistent batch sizes")
+        if batch is None:
+            batch = self.batch
+        if batch > self.batch:
+            raise ValueError("batch %d exceeds capacity %d" % (batch, self.batch))
+        d = _capi.CsrBatch()
+        d.batch = batch
+        d.memspace = _capi.DEVICE if dev else _capi.HOST
+        for name in ("P", "q", "l", "u"):
+            setattr(d, name, items[name][1])
+            setattr(d, "stride_" + name, items[name][2])
+        d.A_rowptr, d.stride_rowptr = items["rowptr"][1], items["rowptr"][2]
+        d.A_colind, d.stride_colind = items["colind"][1], items["colind"][2]
+        d.A_val, d.stride_val = items["val"][1], items["val"][2]
+        d.nnz_max = int(items["colind"][0].shape[-1])
+        if int(items["val"][0].shape[-1]) != d.nnz_max:
+            raise ValueError("colind and val must have the same per-QP length")
+        self._keep = [items[k][0] for k in items]
+        if dev:
+            import torch
+
+            self.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._last_batch = batch
+        return d
+
+    def _call_csr(self, fn, what, P, q, rowptr, colind, val, l, u):
+        self._push_settings()
+        d = self._csr_desc(P, q, rowptr, colind, val, l, u)
+        self._check(fn(self._h, ctypes.byref(d)), what)
+
+    def setup_csr(self, P, q, rowptr, colind, val, l, u):
+        self._call_csr(self._L.sqph_setup_csr, "sqph_setup_csr", P, q, rowptr, colind, val, l, u)
+
+    def update_qp_csr(self, P, q, rowptr, colind, val, l, u):
+        self._call_csr(self._L.sqph_update_qp_csr, "sqph_update_qp_csr", P, q, rowptr, colind, val, l, u)
+
+    def solve_csr(self, P, q, rowptr, colind, val, l, u):
+        self._call_csr(self._L.sqph_solve_csr, "sqph_solve_csr", P, q, rowptr, colind, val, l, u)
+
+    def setup_solve_csr(self, P, q, rowptr, colind, val, l, u):
+        self._call_csr(self._L.sqph_setup_solve_csr, "sqph_setup_solve_csr", P, q, rowptr, colind, val, l, u)
+
     def _fetch(self, want):
         B = self._last_batch or self.batch
         out = {}

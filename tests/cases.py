@@ -376,3 +376,96 @@ def kkt_property(x, y, z, P, q, A, l, u, eps_abs, eps_rel):
     ep = eps_abs + eps_rel * np.maximum(nz(Ax), nz(z))
     ed = eps_abs + eps_rel * np.maximum(nz(Px), np.maximum(nz(ATy), nz(q)))
     return rp, rd, ep, ed
+
+
+# ------------------------------------------------------------------ CSR-A entry points (BASELINE config 5)
+def dense_to_csr(A):
+    """[B,m,n] or [m,n] dense -> rowptr, colind, val (per QP, zero-padded to the batch's max nnz)."""
+    A = np.asarray(A)
+    if A.ndim == 2:
+        ii, jj = np.nonzero(A)
+        rowptr = np.zeros(A.shape[0] + 1, dtype=np.int32)
+        np.add.at(rowptr, ii + 1, 1)
+        return np.cumsum(rowptr).astype(np.int32), jj.astype(np.int32), A[ii, jj]
+    parts = [dense_to_csr(a) for a in A]
+    nnz = max(len(p[1]) for p in parts)
+    rowptr = np.stack([p[0] for p in parts])
+    colind = np.zeros((len(parts), max(nnz, 1)), dtype=np.int32)
+    val = np.zeros((len(parts), max(nnz, 1)), dtype=A.dtype)
+    for b, p in enumerate(parts):
+        colind[b, : len(p[1])] = p[1]
+        val[b, : len(p[2])] = p[2]
+    return rowptr, colind, val
+
+
+def csr_reference_cases(make):
+    """tests/qp_solver_sparse_test.cpp:34-98 (legacy sparse class): SimpleQP, multiple solve, update_qp with P = I, q = 0."""
+    P, q, A, l, u = simple()
+    rp, ci, v = dense_to_csr(A[0])
+    s = make(2, 3, 1, legacy_cold_start=True)
+    s.settings.max_iter = 1000
+    s.settings.adaptive_rho = 1
+    s.setup_csr(P, q, rp, ci, v, l, u)
+    s.solve_csr(P, q, rp, ci, v, l, u)
+    x, y, z, info = s.solution()
+    assert is_approx(x[0], S["solution"], 1e-2)
+    assert info.status[0] == SOLVED and info.iter[0] < 1000
+    so = oracle.QPSolver(legacy=True)
+    so.settings.max_iter, so.settings.adaptive_rho = 1000, 1
+    so.setup(P[0], q[0], A[0], l[0], u[0])
+    so.solve(P[0], q[0], A[0], l[0], u[0])
+    assert info.iter[0] == so.info.iter
+    assert relerr(x[0], so.primal_solution()) < TOL_F64 and relerr(y[0], so.dual_solution()) < TOL_F64
+    # testCanMultipleSolve
+    s.solve_csr(P, q, rp, ci, v, l, u)
+    assert s.info().status[0] == SOLVED
+    # testCanUpdateQP: P = I, q = 0 -> [0.5, 0.5]
+    P2, q2 = np.eye(2)[None], np.zeros((1, 2))
+    s.update_qp_csr(P2, q2, rp, ci, v, l, u)
+    s.solve_csr(P2, q2, rp, ci, v, l, u)
+    x, y, z, info = s.solution()
+    assert is_approx(x[0], np.array([0.5, 0.5]), 1e-2) and info.status[0] == SOLVED
+
+
+def csr_parity(make, n, m, batch, iters=50, density=0.05, seed=3, shared_pattern=False, **kw):
+    """CSR entry point vs the oracle on the dense matrix the CSR arrays encode."""
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    P, q, rp, ci, v, l, u, A = random_csr_qp_batch(batch, n, m, density=density, seed=seed, shared_pattern=shared_pattern)
+    if shared_pattern:
+        rp, ci = rp[0], ci[0]
+    s = make(n, m, batch, **kw)
+    s.settings.max_iter = iters
+    s.settings.check_termination = 0
+    s.setup_solve_csr(P, q, rp, ci, v, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle_settings(s.settings))
+    ex, ey, ez = relerr(x, xo), relerr(y, yo), relerr(z, zo)
+    assert ex < TOL_F64 and ey < TOL_F64 and ez < TOL_F64, (ex, ey, ez)
+    assert (info.iter == io["iter"]).all()
+    # default termination on the same problems
+    s2 = make(n, m, batch, **kw)
+    s2.setup_solve_csr(P, q, rp, ci, v, l, u)
+    x, y, z, info = s2.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle_settings(s2.settings))
+    assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all()
+    assert relerr(x, xo) < TOL_F64 and relerr(y, yo) < TOL_F64
+    return ex, ey
+
+
+def csr_malformed(make):
+    import pytest
+
+    from sqp_solver_amd.qp import SqphError
+
+    P, q, A, l, u = simple()
+    rp, ci, v = dense_to_csr(A[0])
+    s = make(2, 3, 1)
+    bad_ci = ci.copy()
+    bad_ci[0] = 7
+    with pytest.raises(SqphError, match="column index"):
+        s.setup_solve_csr(P, q, rp, bad_ci, v, l, u)
+    bad_rp = rp.copy()
+    bad_rp[1], bad_rp[2] = rp[2], rp[1] - 1
+    with pytest.raises(SqphError, match="row pointers"):
+        s.setup_solve_csr(P, q, bad_rp, ci, v, l, u)

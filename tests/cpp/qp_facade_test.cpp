@@ -145,6 +145,27 @@ static void testBatch() {
     }
 }
 
+static void testSparseCsr() {  // tests/qp_solver_sparse_test.cpp:34-98 through the CSR entry points (legacy semantics)
+    SimpleQP<double> qp;
+    const int rowptr[4] = {0, 2, 3, 4}, colind[4] = {0, 1, 0, 1};
+    const double val[4] = {1, 1, 1, 1};
+    BatchQPSolver<double> prob(2, 3, 1, 0, SQPH_FLAG_LEGACY_COLD_START);
+    prob.settings().max_iter = 1000;
+    prob.settings().adaptive_rho = true;
+    auto b = prob.packed_csr(1, qp.Pd, qp.qd, rowptr, colind, val, 4, qp.ld, qp.ud);
+    prob.setup_csr(b);
+    prob.solve_csr(b);
+    CHECK(is_approx(prob.primal_solution(0), qp.SOLUTION, 2, 1e-2));
+    CHECK(prob.info(0).iter < prob.settings().max_iter && prob.info(0).status == SOLVED);
+    prob.solve_csr(b);  // testCanMultipleSolve
+    CHECK(prob.info(0).status == SOLVED);
+    const double Pid[4] = {1, 0, 0, 1}, q0[2] = {0, 0}, sol2[2] = {0.5, 0.5};  // testCanUpdateQP
+    auto b2 = prob.packed_csr(1, Pid, q0, rowptr, colind, val, 4, qp.ld, qp.ud);
+    prob.update_qp_csr(b2);
+    prob.solve_csr(b2);
+    CHECK(is_approx(prob.primal_solution(0), sol2, 2, 1e-2) && prob.info(0).status == SOLVED);
+}
+
 int main() {
     try {
         TestConstraint();  // host-only, no device needed
@@ -155,6 +176,7 @@ int main() {
         testAdaptiveRhoImprovesConvergence();
         testLegacyFixedSize();
         testBatch();
+        testSparseCsr();
     } catch (const std::runtime_error &e) {
         if (std::string(e.what()).find("no HIP device") != std::string::npos) {
             fprintf(stderr, "no HIP device: %s\n", e.what());

@@ -75,6 +75,19 @@ def test_large_generic_shape():
     cases.parity_fixed_iters(make_gpu, 120, 260, 4, iters=40)
 
 
+def test_csr_reference_cases():
+    """tests/qp_solver_sparse_test.cpp through the CSR entry points"""
+    cases.csr_reference_cases(make_gpu)
+    cases.csr_malformed(make_gpu)
+
+
+@pytest.mark.parametrize("n,m,batch,density,shared", [(20, 40, 16, 0.2, False), (50, 100, 16, 0.1, False), (30, 45, 8, 0.3, True),
+                                                       (200, 400, 4, 0.05, False)])
+def test_csr_parity(n, m, batch, density, shared):
+    """BASELINE config 5 shapes (n=200, m=400, 5 % dense CSR A) and smaller ones against the oracle on the densified A"""
+    cases.csr_parity(make_gpu, n, m, batch, density=density, shared_pattern=shared, iters=50)
+
+
 def test_golden_fixtures():
     import golden_io
 
