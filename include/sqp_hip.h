@@ -131,7 +131,9 @@ enum {
     SQPH_FLAG_FORCE_GENERIC = 2,
     /* prefer the single-wave register-butterfly kernels (admm_tile_kernel.h) over the workgroup-tiled
      * ones (admm_wg_kernel.h); kept for A/B measurements */
-    SQPH_FLAG_WAVE_TILE = 4
+    SQPH_FLAG_WAVE_TILE = 4,
+    /* CSR entry points: always expand A to dense on the device instead of using the native sparse kernel */
+    SQPH_FLAG_CSR_EXPAND = 8
 };
 
 void sqph_default_settings(sqph_settings *s);

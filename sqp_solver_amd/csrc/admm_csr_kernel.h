@@ -1,0 +1,756 @@
+// Sparse-A ADMM kernel (BASELINE config 5: n = 200, m = 400, CSR A): ONE 1024-lane workgroup (16 wavefronts) per QP.
+//
+// At n = 200 the Schur factor W (S^-1 = W'W, lower triangular, 20,100 doubles) no longer fits LDS next to anything
+// else, but it fits the CU's register file: the 1024 lanes form a 32 x 32 grid, lane (r,c) keeps the entries
+//     w[a][b] = W[r + 32a][c + 32b]      b <= a < TT       (2-D cyclic, lower tile-triangle only: 28 doubles at TT = 7)
+// in VGPRs for the whole solve.  A stays sparse and lives in LDS twice: CSR (values + 16-bit columns) for A x and a
+// CSC index (row | position-in-CSR, 32 bit) for A'w, so the iteration is the four-product chain of the reference
+//     t = (sigma x - q) + A' w        CSC, 4 lanes per column
+//     y1 = W t                        register tile, partial sums over c staged in LDS, summed by 4 lanes per output
+//     x~ = W' y1                      same tile, partial sums over r
+//     z~ = A x~                       CSR, 2 lanes per row
+// (the B = A W' trick of the dense kernels would densify A).  Set-up in the same launch: CSC index by counting sort,
+// S = P_sym + sigma I + A'RA accumulated column panel by column panel in LDS from the sparse rows (cost ~ nnz * row
+// length, not m n^2), moved into the register tile, Jacobi-scaled and eliminated in registers ([S | I] -> W in place,
+// one LDS broadcast vector and one barrier per pivot).  Numerics: identical formulas to admm_generic.h
+// (reference src/qp.cpp:84-144 on the Schur-ordered system), fp64 arithmetic, TIN inputs.
+//
+// Requirements checked by the host (csr_try_launch): n <= 32*TT, m <= 512, CSR rows sorted by column without
+// duplicates, nnz small enough for LDS; anything else takes the expand-to-dense path.
+#pragma once
+#include "admm_generic.h"  // SQPH_DYN_SMEM
+#include "admm_wg_kernel.h"  // wg_read, SQPH_OPAQUE_*
+#include "block_ops.h"
+#include "kargs.h"
+#include "wave_ops.h"
+
+namespace sqph {
+
+template <typename TIN>
+struct CsrArgs {
+    const int *rowptr, *colind;
+    const TIN *val;
+    long long s_rowptr, s_colind, s_val;
+    int nnz_cap;  // per-QP capacity of colind/val == LDS slots reserved
+};
+
+// LDS map.  Everything whose size depends only on the tile edge TT sits first at compile-time offsets; the arrays
+// sized by m and by the nnz capacity follow (five run-time offsets).  Used by the host (launch size) and the kernel.
+template <int TT>
+struct CsrLayout {
+    static constexpr int NP = 32 * TT;
+    static constexpr int CS = ((TT + 1) & ~1) + 2;  // stride of one lane-group's slice of a gathered vector (16-B aligned)
+    static constexpr int SP = 33;                   // stride of one output's 32 partial sums (odd: conflict-free column writes)
+    static constexpr int LDP = NP + 1;              // S panel column stride
+    static constexpr int ev(int x) { return (x + 1) & ~1; }
+    // offsets in doubles
+    static constexpr int o_stage = 0;
+    static constexpr int o_tcol = ev(NP * SP > 32 * LDP ? NP * SP : 32 * LDP);
+    static constexpr int o_yrow = o_tcol + 32 * CS;
+    static constexpr int o_xt = o_yrow + 32 * CS;
+    static constexpr int o_g = o_xt + NP;
+    static constexpr int o_sj = o_g + 2 * NP + 2;
+    static constexpr int o_ds = o_sj + NP;
+    static constexpr int o_red = o_ds + NP;
+    static constexpr int o_colptr_d = o_red + 8 * 16;          // (NP+1) ints
+    static constexpr int o_ccur_d = o_colptr_d + ev(NP + 2) / 2;  // NP ints
+    static constexpr int o_w = o_ccur_d + NP / 2;
+    // offsets in 32-bit words
+    static constexpr int o_colptr = 2 * o_colptr_d, o_ccur = 2 * o_ccur_d;
+    int o_rho, o_val;          // doubles
+    int o_rowptr, o_csc, o_col;  // 32-bit words
+    size_t bytes;
+    __host__ __device__ static CsrLayout make(int m, int nnz_cap) {
+        CsrLayout L;
+        const int MP = (m + 1) & ~1;
+        int d = o_w + MP;
+        L.o_rho = d; d += MP;
+        L.o_val = d; d += nnz_cap;
+        int w = 2 * d;
+        L.o_csc = w; w += nnz_cap;
+        L.o_rowptr = w; w += m + 1;
+        L.o_col = w; w += (nnz_cap + 1) / 2;
+        L.bytes = (size_t)w * 4 + 16;
+        return L;
+    }
+};
+
+#ifdef SQPH_SIM
+inline int lds_atomic_inc(int *p) { return (*p)++; }
+#else
+__device__ __forceinline__ int lds_atomic_inc(int *p) { return atomicAdd(p, 1); }
+#endif
+
+template <typename TIN, int TT>
+struct CsrKernel {
+    using T = double;
+    static constexpr int NT = 1024, NP = 32 * TT, NE = TT * (TT + 1) / 2;
+    static constexpr int idx(int a, int b) { return a * (a + 1) / 2 + b; }
+
+    // ---------------------------------------------------------------- register-tile products -> staging
+    // W t : lane (r,c) sums over its columns; partial for output row r+32a goes to st[(r+32a)*SP + c]
+    static __device__ __forceinline__ void stage_W(const T (&w)[NE], const T *tcol, T *st, int r, int c, int CS, int SP) {
+        T tv[TT];
+        wg_read<TT>(tcol + c * CS, tv);
+#pragma unroll
+        for (int a = 0; a < TT; a++) {
+            T acc = 0;
+#pragma unroll
+            for (int b = 0; b <= a; b++) acc = wg_fma(w[idx(a, b)], tv[b], acc);
+            st[(r + 32 * a) * SP + c] = acc;
+        }
+    }
+    // W' y : lane (r,c) sums over its rows; partial for output column c+32b goes to st[(c+32b)*SP + r]
+    static __device__ __forceinline__ void stage_WT(const T (&w)[NE], const T *yrow, T *st, int r, int c, int CS, int SP) {
+        T yv[TT];
+        wg_read<TT>(yrow + r * CS, yv);
+#pragma unroll
+        for (int b = 0; b < TT; b++) {
+            T acc = 0;
+#pragma unroll
+            for (int a = b; a < TT; a++) acc = wg_fma(w[idx(a, b)], yv[a], acc);
+            st[(c + 32 * b) * SP + r] = acc;
+        }
+    }
+    // sum of the 32 partials of output j by the 4 lanes 4j..4j+3 (every lane of the quad gets the total)
+    static __device__ __forceinline__ T quad_sum(const T *st, int j, int ql, int SP) {
+        const T *p = st + j * SP + 8 * ql;
+        T s0 = p[0] + p[4], s1 = p[1] + p[5], s2 = p[2] + p[6], s3 = p[3] + p[7];
+        T s = (s0 + s1) + (s2 + s3);
+        s += xchg<1>(s);
+        s += xchg<2>(s);
+        return s;
+    }
+
+    // ---------------------------------------------------------------- sparse products (matrices in LDS)
+    // (A v)_i by the lane pair 2i, 2i+1; v plain-indexed in LDS.  Every lane of the wave must call this.
+    static __device__ __forceinline__ T csr_row_dot(const int *rowptr, const unsigned short *col, const T *val, const T *v, int i,
+                                                    int pl, bool active) {
+        T a0 = 0, a1 = 0;
+        if (active) {
+            const int e1 = rowptr[i + 1];
+            int e = rowptr[i] + pl;
+            for (; e + 2 < e1; e += 4) {
+                a0 = wg_fma(val[e], v[col[e]], a0);
+                a1 = wg_fma(val[e + 2], v[col[e + 2]], a1);
+            }
+            if (e < e1) a0 = wg_fma(val[e], v[col[e]], a0);
+        }
+        T s = a0 + a1;
+        s += xchg<1>(s);
+        return s;
+    }
+    // (A' v)_j by the lane quad 4j..4j+3; v plain-indexed in LDS.  Every lane of the wave must call this.
+    static __device__ __forceinline__ T csc_col_dot(const int *colptr, const unsigned *csc, const T *val, const T *v, int j, int ql,
+                                                    bool active) {
+        T a0 = 0, a1 = 0;
+        if (active) {
+            const int e1 = colptr[j + 1];
+            int e = colptr[j] + ql;
+            for (; e + 4 < e1; e += 8) {
+                const unsigned p0 = csc[e], p1 = csc[e + 4];
+                a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
+                a1 = wg_fma(val[p1 & 0xffffu], v[p1 >> 16], a1);
+            }
+            if (e < e1) {
+                const unsigned p0 = csc[e];
+                a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
+            }
+        }
+        T s = a0 + a1;
+        s += xchg<1>(s);
+        s += xchg<2>(s);
+        return s;
+    }
+
+    // ---------------------------------------------------------------- set-up
+    // CSR of this QP -> LDS, CSC index by counting sort (entries of a column ordered by row: deterministic sums)
+    static __device__ void load_sparse(const CsrArgs<TIN> &ca, int qp, int n, int m, const CsrLayout<TT> &L, unsigned char *smem) {
+        const int t = threadIdx.x;
+        T *lds = reinterpret_cast<T *>(smem);
+        int *li = reinterpret_cast<int *>(smem);
+        int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr, *ccur = li + L.o_ccur;
+        unsigned *csc = reinterpret_cast<unsigned *>(li + L.o_csc);
+        unsigned short *col = reinterpret_cast<unsigned short *>(li + L.o_col);
+        T *val = lds + L.o_val;
+        const int *grp = ca.rowptr + (long long)qp * ca.s_rowptr;
+        const int *gci = ca.colind + (long long)qp * ca.s_colind;
+        const TIN *gv = ca.val + (long long)qp * ca.s_val;
+        for (int i = t; i <= m; i += NT) rowptr[i] = grp[i];
+        for (int j = t; j <= L.NP; j += NT) colptr[j] = 0;
+        __syncthreads();
+        const int nnz = rowptr[m];
+        for (int e = t; e < nnz; e += NT) {
+            const int j = gci[e];
+            col[e] = (unsigned short)j;
+            val[e] = (T)gv[e];
+            lds_atomic_inc(&colptr[j + 1]);  // integer counts: order-independent
+        }
+        __syncthreads();
+        // exclusive scan of the column counts (n <= 224 values): wave 0, 4 per lane
+        if (t < 64) {
+            int v[4], s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = 4 * t + k;
+                v[k] = (j < L.NP) ? colptr[j + 1] : 0;
+                s += v[k];
+            }
+            int incl = s;  // inclusive scan over the 64 lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = sim_or_shfl_up(incl, d);
+                if ((t & 63) >= d) incl += o;
+            }
+            int run = incl - s;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = 4 * t + k;
+                if (j < L.NP) {
+                    colptr[j + 1] = run + v[k];
+                    ccur[j] = run;
+                }
+                run += v[k];
+            }
+        }
+        __syncthreads();
+        // fill: slot order inside a column is arbitrary here ...
+        for (int i = t; i < m; i += NT) {
+            for (int e = rowptr[i]; e < rowptr[i + 1]; e++) {
+                const int j = col[e];
+                const int slot = lds_atomic_inc(&ccur[j]);
+                csc[slot] = ((unsigned)i << 16) | (unsigned)e;
+            }
+        }
+        __syncthreads();
+        // ... and made canonical by sorting every column on (row, position)
+        for (int j = t; j < n; j += NT) {
+            const int e0 = colptr[j], e1 = colptr[j + 1];
+            for (int e = e0 + 1; e < e1; e++) {
+                const unsigned key = csc[e];
+                int f = e - 1;
+                while (f >= e0 && csc[f] > key) {
+                    csc[f + 1] = csc[f];
+                    f--;
+                }
+                csc[f + 1] = key;
+            }
+        }
+        __syncthreads();
+    }
+
+#ifdef SQPH_SIM
+    static inline int sim_or_shfl_up(int v, int d) {
+        const int lane = (int)(threadIdx.x & 63);
+        const uint64_t r = ::sqph_sim::wave_exchange((uint64_t)(uint32_t)v, lane >= d ? lane - d : lane);
+        return (int)(uint32_t)r;
+    }
+#else
+    static __device__ __forceinline__ int sim_or_shfl_up(int v, int d) { return __shfl_up(v, d); }
+#endif
+
+    // S = P_sym + sigma I + A' diag(rho) A  ->  register tile (lower tile-triangle), one 32-column panel at a time.
+    // Half-wave r owns column j = 32p + r of the panel: for every CSC entry (i, pos) of that column, in row order,
+    // its 32 lanes add rho_i A_ij * (row i of A) into the panel column (distinct k per lane: rows are duplicate-free).
+    static __device__ __forceinline__ void form_S(const TIN *__restrict__ gP, int n, T sigma, const CsrLayout<TT> &L, unsigned char *smem,
+                                                  int r, int c, T (&w)[NE]) {
+        const int t = threadIdx.x;
+        T *lds = reinterpret_cast<T *>(smem);
+        const int *li = reinterpret_cast<const int *>(smem);
+        const int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr;
+        const unsigned *csc = reinterpret_cast<const unsigned *>(li + L.o_csc);
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(li + L.o_col);
+        const T *val = lds + L.o_val, *rho = lds + L.o_rho;
+        T *Sp = lds + L.o_stage;
+        const int LDP = L.LDP;
+#pragma unroll
+        for (int p = 0; p < TT; p++) {
+            __syncthreads();
+            for (int e = t; e < 32 * LDP; e += NT) Sp[e] = 0;
+            __syncthreads();
+            const int j = 32 * p + r;
+            if (j < n) {
+                const int e1 = colptr[j + 1];
+                for (int e = colptr[j]; e < e1; e++) {
+                    const unsigned pk = csc[e];
+                    const int i = (int)(pk >> 16);
+                    const T coef = rho[i] * val[pk & 0xffffu];
+                    const int f1 = rowptr[i + 1];
+                    for (int f = rowptr[i] + c; f < f1; f += 32) {
+                        const int k = col[f];
+                        if (k >= j) Sp[r * LDP + k] = wg_fma(coef, val[f], Sp[r * LDP + k]);
+                    }
+                }
+            }
+            __syncthreads();
+            // + lower triangle of P (only it reaches the reference's factor, Eigen::LDLT<.,Lower>, qp.hpp:129) + sigma I
+            for (int e = t; e < 32 * n; e += NT) {
+                const int jj = e / n, k = e - jj * n;
+                const int jc = 32 * p + jj;
+                if (jc < n && k >= jc) Sp[jj * LDP + k] += (T)gP[(long)jc * n + k] + (k == jc ? sigma : T(0));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = p; a < TT; a++) w[idx(a, p)] = Sp[c * LDP + r + 32 * a];  // rows >= n of the panel are zero
+        }
+        __syncthreads();
+    }
+
+    // In-register factorisation of the tile: Jacobi scaling, forward elimination of [S | I] in place (admm_generic.h:
+    // factor_schur), final scaling to W = D^-1/2 L^-1 D_J^-1/2.  One broadcast vector g per pivot k:
+    //   g[j] = W-part of row k (j < k) | d + 1 (j = k) | column k of the trailing matrix (j > k)
+    // and every entry (i,j), i > k, j <= i, gets  e -= (g[i]/d) * g[j].   Returns false on a bad pivot (block-uniform).
+    static __device__ __forceinline__ bool eliminate(int n, const CsrLayout<TT> &L, T *lds, int r, int c, T (&w)[NE]) {
+        T *g = lds + L.o_g, *sj = lds + L.o_sj, *dsv = lds + L.o_ds;
+        const int NPl = L.NP;
+        const int t = threadIdx.x;
+        // diagonal -> sj
+        if (t < NPl) sj[t] = T(1);
+        __syncthreads();
+        if (r == c) {
+#pragma unroll
+            for (int a = 0; a < TT; a++)
+                if (r + 32 * a < n) sj[r + 32 * a] = w[idx(a, a)];
+        }
+        __syncthreads();
+        bool bad = false;
+        for (int j = t & 63; j < n; j += 64) {
+            const T d = sj[j];
+            if (!(d > T(0)) || !(d * T(0) == T(0))) bad = true;
+        }
+        {   // block-uniform verdict
+            T *red = lds + L.o_red;
+            T f = bad ? T(1) : T(0);
+            f = wave_nanmax(f);
+            if ((t & 63) == 0) red[t >> 6] = f;
+            __syncthreads();
+            T any = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) any = nanmax(any, red[k]);
+            __syncthreads();
+            if (any != T(0)) return false;
+        }
+        if (t < n) sj[t] = T(1) / (T)sqrt((double)sj[t]);
+        __syncthreads();
+        {
+            T sr[TT], sc[TT];
+#pragma unroll
+            for (int a = 0; a < TT; a++) {
+                sr[a] = (r + 32 * a < n) ? sj[r + 32 * a] : T(0);
+                sc[a] = (c + 32 * a < n) ? sj[c + 32 * a] : T(0);
+            }
+#pragma unroll
+            for (int a = 0; a < TT; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++) w[idx(a, b)] = w[idx(a, b)] * sr[a] * sc[b];
+        }
+        for (int k = 0; k < n; k++) {
+            const int ak = k >> 5, rk = k & 31;
+            T *gk = g + (k & 1) * (NPl + 1);
+            // publish g for pivot k
+            if (c == rk) {  // my column group holds column k: entries (a, ak), rows i = r + 32a > k
+#pragma unroll
+                for (int b = 0; b < TT; b++) {
+                    if (b == ak) {
+#pragma unroll
+                        for (int a = b; a < TT; a++) {
+                            const int i = r + 32 * a;
+                            if (i > k) gk[i] = w[idx(a, b)];
+                        }
+                    }
+                }
+            }
+            if (r == rk) {  // my row group holds row k: entries (ak, b), columns j = c + 32b < k, and the pivot
+#pragma unroll
+                for (int a = 0; a < TT; a++) {
+                    if (a == ak) {
+#pragma unroll
+                        for (int b = 0; b <= a; b++) {
+                            const int j = c + 32 * b;
+                            if (j < k) gk[j] = w[idx(a, b)];
+                            if (j == k) {
+                                gk[j] = w[idx(a, b)] + T(1);
+                                gk[NPl] = w[idx(a, b)];
+                                dsv[k] = w[idx(a, b)];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const T d = gk[NPl];
+            if (!(d > T(0)) || !(d * T(0) == T(0))) return false;  // block-uniform: every lane reads the same word
+            const T dinv = T(1) / d;
+            T gc[TT];
+#pragma unroll
+            for (int b = 0; b < TT; b++) gc[b] = gk[c + 32 * b];
+#pragma unroll
+            for (int a = 0; a < TT; a++) {
+                if (a >= ak) {  // block-uniform
+                    const int i = r + 32 * a;
+                    T li = gk[i] * dinv;
+                    if (a == ak) li = (r > rk) ? li : T(0);
+#pragma unroll
+                    for (int b = 0; b <= a; b++) w[idx(a, b)] = wg_fma(-li, gc[b], w[idx(a, b)]);
+                }
+            }
+            // entries of g for columns/rows outside [0,n) are never written: zero from the initial clear below
+        }
+        __syncthreads();
+        {
+            T rs[TT], sc[TT];
+#pragma unroll
+            for (int a = 0; a < TT; a++) {
+                rs[a] = (r + 32 * a < n) ? T(1) / (T)sqrt((double)dsv[r + 32 * a]) : T(0);
+                sc[a] = (c + 32 * a < n) ? sj[c + 32 * a] : T(0);
+            }
+#pragma unroll
+            for (int a = 0; a < TT; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++) {
+                    const int i = r + 32 * a, j = c + 32 * b;
+                    const T v = (i > j) ? w[idx(a, b)] * rs[a] : (i == j ? rs[a] : T(0));
+                    w[idx(a, b)] = v * sc[b];
+                }
+        }
+        __syncthreads();
+        return true;
+    }
+
+    // tile <-> global workspace (the factor survives between setup() and solve() calls there), col-major n x n
+    static __device__ __forceinline__ void store_tile(T *__restrict__ gW, int n, int r, int c, const T (&w)[NE]) {
+#pragma unroll
+        for (int a = 0; a < TT; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) {
+                const int i = r + 32 * a, j = c + 32 * b;
+                if (i < n && j < n && i >= j) gW[(long)j * n + i] = w[idx(a, b)];
+            }
+    }
+    static __device__ __forceinline__ void load_tile(const T *__restrict__ gW, int n, int r, int c, T (&w)[NE]) {
+#pragma unroll
+        for (int a = 0; a < TT; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) {
+                const int i = r + 32 * a, j = c + 32 * b;
+                w[idx(a, b)] = (i < n && j < n && i >= j) ? gW[(long)j * n + i] : T(0);
+            }
+    }
+
+    // P x with the full P (both triangles, qp.cpp:324), streamed from global memory: lane (r,c) takes rows c + 32a
+    // (coalesced) and columns r + 32b; partial sums over r staged like stage_WT.  x in row-gather order in yrow.
+    static __device__ __forceinline__ void stage_P_gmem(const TIN *__restrict__ gP, int n, const T *yrow, T *st, int r, int c, int CS,
+                                                        int SP) {
+        T xv[TT];
+        wg_read<TT>(yrow + r * CS, xv);
+        for (int a = 0; a < TT; a++) {
+            const int i = c + 32 * a;
+            T acc = 0;
+            if (i < n) {
+#pragma unroll
+                for (int b = 0; b < TT; b++) {
+                    const int j = r + 32 * b;
+                    if (j < n) acc = wg_fma((T)gP[(long)j * n + i], xv[b], acc);
+                }
+            }
+            st[(c + 32 * a) * SP + r] = acc;
+        }
+    }
+
+    static __device__ void run(const KArgs<T, TIN> &a, const CsrArgs<TIN> &ca, unsigned char *smem) {
+        const int t = threadIdx.x;
+        const int c = t & 31, r = t >> 5;
+        const int qp = blockIdx.x;
+        if (qp >= a.batch) return;
+        const int n = a.n, m = a.m;
+        const CsrLayout<TT> L = CsrLayout<TT>::make(m, ca.nnz_cap);
+        using LL = CsrLayout<TT>;
+        T *lds = reinterpret_cast<T *>(smem);
+        int *li = reinterpret_cast<int *>(smem);
+        const int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr;
+        const unsigned *csc = reinterpret_cast<const unsigned *>(li + L.o_csc);
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(li + L.o_col);
+        const T *val = lds + L.o_val;
+        T *st = lds + L.o_stage, *tcol = lds + L.o_tcol, *yrow = lds + L.o_yrow, *xt = lds + L.o_xt, *wv = lds + L.o_w;
+        const int CS = L.CS, SP = L.SP;
+
+        const TIN *gP = a.P + (long)qp * a.sP;
+        const TIN *gq = a.q + (long)qp * a.sq;
+        const TIN *gl = a.l + (long)qp * a.sl;
+        const TIN *gu = a.u + (long)qp * a.su;
+        T *sx = a.x + (long)qp * n;
+        T *sz = a.z + (long)qp * m;
+        T *sy = a.y + (long)qp * m;
+        T *srho = a.rho_vec + (long)qp * m;
+        int *sct = a.ctype + (long)qp * m;
+        T *gW = a.Sinv + (long)qp * 2 * n * n;
+
+        sqph_info info = a.info[qp];
+        T rho_s = a.rho[qp];
+        const int mode = a.mode;
+        if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
+            return;  // qp.cpp:68-71 (block-uniform)
+
+        // element owners: the lane quad 4j..4j+3 tracks x_j, q_j; the lane pair 2i, 2i+1 tracks z_i, y_i, l_i, u_i, rho_i
+        const int jn = t >> 2, ql = t & 3, im = t >> 1, pl = t & 1;
+        const bool nown = jn < n, mown = im < m;
+        const T INF = T(1) / T(0);
+        const T q = nown ? (T)gq[jn] : T(0);
+        const T lo = mown ? (T)gl[im] : -INF, up = mown ? (T)gu[im] : INF;
+        T x = 0, z = 0, y = 0, rho = T(1), rinv = T(1);
+
+        if (mode & (MODE_SETUP | MODE_UPDATE)) {
+            rho_s = a.rho0;
+            if (mown) {
+                int ctype = SQPH_INEQUALITY_CONSTRAINT;
+                if (lo < -a.loose_thresh && up > a.loose_thresh)
+                    ctype = SQPH_LOOSE_BOUNDS;
+                else if (up - lo < a.eq_tol)
+                    ctype = SQPH_EQUALITY_CONSTRAINT;
+                rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
+                rinv = T(1) / rho;
+                if (pl == 0) {
+                    sct[im] = ctype;
+                    srho[im] = rho;
+                }
+            }
+            info.rho_updates += 1;
+            if (!(mode & MODE_SETUP)) {
+                if (nown) x = sx[jn];
+                if (mown) {
+                    z = sz[im];
+                    y = sy[im];
+                }
+            }
+        } else {
+            if (nown) x = sx[jn];
+            if (mown) {
+                z = sz[im];
+                y = sy[im];
+                rho = srho[im];
+                rinv = T(1) / rho;
+            }
+        }
+
+        load_sparse(ca, qp, n, m, L, smem);
+
+        T w[NE];
+        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
+        bool solving = false;
+        bool state_dirty = (mode & MODE_SETUP) != 0;
+        if (!need_factor) load_tile(gW, n, r, c, w);
+        const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
+        int iter = 1;
+        int next_check = a.check_termination > 0 ? a.check_termination : -1;
+        int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
+        for (;;) {
+            if (need_factor) {
+                __syncthreads();
+                if (mown && pl == 0) lds[L.o_rho + im] = rho;
+                for (int e = t; e < 2 * (L.NP + 1); e += NT) lds[L.o_g + e] = 0;
+                __syncthreads();
+                int n_f = n, r_f = r, c_f = c;
+                const TIN *gP_f = gP;
+                SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_S(gP_f);
+                form_S(gP_f, n_f, sigma, L, smem, r_f, c_f, w);
+                const bool ok = eliminate(n_f, L, lds, r_f, c_f, w);
+                store_tile(gW, n_f, r_f, c_f, w);
+                __syncthreads();
+                need_factor = false;
+                if (!solving) {
+                    info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
+                } else if (!ok) {
+                    info.status = SQPH_NUMERICAL_ISSUES;  // qp.cpp:139-142
+                    break;
+                } else {
+                    iter++;
+                }
+            }
+            if (!(mode & MODE_SOLVE) || info.status == SQPH_NUMERICAL_ISSUES || info.status == SQPH_UNINITIALIZED) break;
+            if (!solving) {
+                solving = true;
+                state_dirty = true;
+                if ((mode & MODE_COLD_RESET) && !a.warm_start) x = z = y = 0;
+            }
+            // w = R (z - R^-1 y)  [rhs tail of qp.cpp:275 pre-multiplied by R], plain-indexed for the CSC gather
+            __syncthreads();
+            if (mown && pl == 0) wv[im] = rho * (z - rinv * y);
+            for (; iter <= a.max_iter; iter++) {
+                __syncthreads();
+                {   // t = (sigma x - q) + A' w, published in column-gather order
+                    const T s = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
+                    if (ql == 0 && jn < L.NP) tcol[(jn & 31) * CS + (jn >> 5)] = nown ? (sigma * x - q) + s : T(0);
+                }
+                __syncthreads();
+                stage_W(w, tcol, st, r, c, CS, SP);
+                __syncthreads();
+                {   // y1 = W t, published in row-gather order
+                    const T y1 = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
+                    if (ql == 0 && jn < L.NP) yrow[(jn & 31) * CS + (jn >> 5)] = nown ? y1 : T(0);
+                }
+                __syncthreads();
+                stage_WT(w, yrow, st, r, c, CS, SP);
+                __syncthreads();
+                {   // x~ = W' y1: plain-indexed for the CSR gather; x relaxation (qp.cpp:96)
+                    const T xtj = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
+                    if (ql == 0 && jn < L.NP) xt[jn] = nown ? xtj : T(0);
+                    if (nown) x = alpha * xtj + oma * x;
+                }
+                __syncthreads();
+                {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
+                    const T zt = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
+                    if (mown) {
+                        const T zr = alpha * zt + oma * z;
+                        T zn = zr + rinv * y;
+                        zn = zn < lo ? lo : zn;
+                        zn = zn > up ? up : zn;
+                        y = y + rho * (zr - zn);
+                        z = zn;
+                    }
+                }
+                bool check = false, adapt = false;
+                if (--next_check == 0) {
+                    check = true;
+                    next_check = a.check_termination;
+                }
+                if (--next_adapt == 0) {
+                    adapt = true;
+                    next_adapt = a.adaptive_rho_interval;
+                }
+                if (check || adapt) {
+                    // update_state + residuals, qp.cpp:316-331, 353-361
+                    __syncthreads();
+                    if (ql == 0 && jn < L.NP) {
+                        xt[jn] = nown ? x : T(0);
+                        yrow[(jn & 31) * CS + (jn >> 5)] = nown ? x : T(0);
+                    }
+                    if (mown && pl == 0) wv[im] = y;
+                    __syncthreads();
+                    const T Ax = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
+                    const T ATy = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
+                    {
+                        int n_c = n, r_c = r, c_c = c;
+                        const TIN *gP_c = gP;
+                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gP_c);
+                        stage_P_gmem(gP_c, n_c, yrow, st, r_c, c_c, CS, SP);
+                    }
+                    __syncthreads();
+                    const T Px = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
+                    T v[7] = {0, 0, 0, 0, 0, 0, 0};
+                    if (mown) {
+                        v[0] = tabs(Ax);
+                        v[1] = tabs(z);
+                        v[2] = tabs(Ax - z);
+                    }
+                    if (nown) {
+                        v[3] = tabs(Px);
+                        v[4] = tabs(ATy);
+                        v[5] = tabs(q);
+                        v[6] = tabs(Px + q + ATy);
+                    }
+                    {
+                        T *red = lds + L.o_red;
+#pragma unroll
+                        for (int e = 0; e < 7; e++) v[e] = wave_nanmax(v[e]);
+                        if ((t & 63) == 0) {
+#pragma unroll
+                            for (int e = 0; e < 7; e++) red[e * 16 + (t >> 6)] = v[e];
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int e = 0; e < 7; e++) {
+                            T mval = red[e * 16];
+#pragma unroll
+                            for (int k = 1; k < 16; k++) mval = nanmax(mval, red[e * 16 + k]);
+                            v[e] = mval;
+                        }
+                        __syncthreads();
+                    }
+                    const T nrm_prim = nanmax(v[0], v[1]);
+                    const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
+                    info.res_prim = (double)v[2];
+                    info.res_dual = (double)v[6];
+                    if (check) {
+                        if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                            info.status = SQPH_SOLVED;
+                            break;
+                        }
+                    }
+                    if (adapt) {
+                        const T eps = a.regul;
+                        const T rp_norm = v[2] / (nrm_prim + eps);
+                        const T rd_norm = v[6] / (nrm_dual + eps);
+                        T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
+                        new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
+                        new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
+                        info.rho_estimate = (double)new_rho;
+                        if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
+                            rho_s = new_rho;
+                            if (mown) {
+                                rho = rho_for_type<T>(sct[im], rho_s, a.rho_min, a.rho_eq_factor);
+                                rinv = T(1) / rho;
+                            }
+                            info.rho_updates += 1;
+                            need_factor = true;
+                            break;  // leave WITHOUT advancing iter; the factor block does it
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (mown && pl == 0) wv[im] = rho * (z - rinv * y);
+            }
+            if (!need_factor) break;
+        }
+        if (solving) {
+            if (iter > a.max_iter) info.status = SQPH_MAX_ITER_EXCEEDED;
+            info.iter = iter;
+        }
+        if (state_dirty) {
+            if (nown && ql == 0) sx[jn] = x;
+            if (mown && pl == 0) {
+                sz[im] = z;
+                sy[im] = y;
+                srho[im] = rho;
+            }
+        }
+        if (t == 0) {
+            a.info[qp] = info;
+            a.rho[qp] = rho_s;
+        }
+    }
+};
+
+template <typename TIN>
+struct CsrLaunch {
+    KArgs<double, TIN> a;
+    CsrArgs<TIN> ca;
+};
+
+template <typename TIN, int TT>
+__global__ __launch_bounds__(1024) void admm_csr_kernel(CsrLaunch<TIN> p) {
+    SQPH_DYN_SMEM(smem_raw);
+    CsrKernel<TIN, TT>::run(p.a, p.ca, smem_raw);
+}
+
+// tile edges compiled into the library (n <= 32*TT): first fit wins
+#define SQPH_CSR_SHAPES(X) X(4) X(7)
+// additional small edges for the host SIMT emulation in the CPU test-suite
+#define SQPH_CSR_SIM_SHAPES(X) X(1) X(2) X(4) X(7)
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_csr(const KArgs<double, TIN> &a, const CsrArgs<TIN> &ca) {
+    if (a.m > 512) return -1;
+#define SQPH_SIM_CASE(TT_)                                                                                              \
+    if (a.n <= 32 * TT_) {                                                                                              \
+        const CsrLayout<TT_> L = CsrLayout<TT_>::make(a.m, ca.nnz_cap);                                                      \
+        ::sqph_sim::launch(admm_csr_kernel<TIN, TT_>, dim3(a.batch), dim3(1024), L.bytes, CsrLaunch<TIN>{a, ca});       \
+        return 0;                                                                                                       \
+    }
+    SQPH_CSR_SIM_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
+
+}  // namespace sqph

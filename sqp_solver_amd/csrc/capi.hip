@@ -14,6 +14,7 @@
 
 #include "../../include/sqp_hip.h"
 #include "admm_generic.h"
+#include "admm_csr_kernel.h"
 #include "admm_tile.h"
 #include "kargs.h"
 
@@ -64,6 +65,31 @@ __global__ void csr_expand(int batch, int n, int m, const int *__restrict__ rowp
         if (j < 0 || j >= n) { atomicOr(bad, 2); continue; }
         d[(long long)j * m + i] += v[e];
     }
+}
+
+// Structural check of a CSR batch for the native sparse kernel: bit 0 = row pointers malformed, bit 1 = column index
+// out of range, bit 2 = a row is not strictly increasing in its column indices (legal, but takes the expand path).
+__global__ void csr_check(int batch, int n, int m, long long nnz_cap, const int *__restrict__ rowptr, const int *__restrict__ colind,
+                          long long s_rowptr, long long s_colind, int *__restrict__ flags) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)batch * m) return;
+    const int b = (int)(t / m), i = (int)(t - (long long)b * m);
+    const int *rp = rowptr + b * s_rowptr;
+    const int *ci = colind + b * s_colind;
+    const int e0 = rp[i], e1 = rp[i + 1];
+    int f = 0;
+    if (e0 < 0 || e1 < e0 || e1 > nnz_cap || (i == 0 && e0 != 0)) {
+        f = 1;
+    } else {
+        int prev = -1;
+        for (int e = e0; e < e1; e++) {
+            const int j = ci[e];
+            if (j < 0 || j >= n) f |= 2;
+            if (j <= prev) f |= 4;
+            prev = j;
+        }
+    }
+    if (f) atomicOr(flags, f);
 }
 
 }  // namespace
@@ -358,9 +384,17 @@ namespace {
 
 // Scalar constants of the reference class (qp.hpp:136-141) and the settings are rounded through the
 // interface Scalar (TIN) first, then widened to the fp64 the kernels compute in.
+struct CsrDesc {  // device-resident CSR arrays of the native sparse path
+    const int *rowptr, *colind;
+    const void *val;
+    long long s_rowptr, s_colind, s_val;
+    int nnz_cap, TT;
+};
+
 template <typename TIN>
 int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *P, const void *q, const void *A,
-                 const void *l, const void *u, long long sP, long long sq, long long sA, long long sl, long long su) {
+                 const void *l, const void *u, long long sP, long long sq, long long sA, long long sl, long long su,
+                 const CsrDesc *csr = nullptr) {
     using namespace sqph;
     using T = double;
     KArgs<T, TIN> a{};
@@ -391,7 +425,24 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     }
 
     bool launched = false;
-    if (!(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
+    if (csr) {
+        CsrLaunch<TIN> p;
+        p.a = a;
+        p.ca = CsrArgs<TIN>{csr->rowptr, csr->colind, (const TIN *)csr->val, csr->s_rowptr, csr->s_colind, csr->s_val, csr->nnz_cap};
+#define SQPH_CSR_CASE(TT_)                                                                                                          \
+    if (!launched && csr->TT == TT_) {                                                                                              \
+        const CsrLayout<TT_> L = CsrLayout<TT_>::make(s->m, csr->nnz_cap);                                                          \
+        SQPH_HIP(s, hipFuncSetAttribute((const void *)admm_csr_kernel<TIN, TT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.bytes)); \
+        hipLaunchKernelGGL((admm_csr_kernel<TIN, TT_>), dim3(qp->batch), dim3(1024), L.bytes, s->stream, p);                        \
+        SQPH_HIP(s, hipGetLastError());                                                                                             \
+        s->kernel_name = "csr_t" #TT_;                                                                                              \
+        launched = true;                                                                                                            \
+    }
+        SQPH_CSR_SHAPES(SQPH_CSR_CASE)
+#undef SQPH_CSR_CASE
+        if (!launched) SQPH_FAIL(s, SQPH_ERR_UNSUPPORTED, "no sparse kernel for tile edge %d", csr->TT);
+    }
+    if (!launched && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
         int rc = 0;
         if (!(s->flags & SQPH_FLAG_WAVE_TILE)) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = tile_try_launch<T, TIN>(a, s->stream, &s->kernel_name);
@@ -421,12 +472,12 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     return SQPH_OK;
 }
 
-int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what) {
+int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, const CsrDesc *csr = nullptr) {
     if (!s) return SQPH_ERR_INVALID;
     if (!qp) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: qp is null", what);
     if (qp->batch < 0 || qp->batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: batch %d exceeds capacity %d", what, qp->batch, s->cap);
     if (qp->batch == 0) return SQPH_OK;
-    if (!qp->P || !qp->q || (s->m > 0 && (!qp->A || !qp->l || !qp->u))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null problem pointer", what);
+    if (!qp->P || !qp->q || (s->m > 0 && ((!csr && !qp->A) || !qp->l || !qp->u))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null problem pointer", what);
     if (qp->stride_P < 0 || qp->stride_q < 0 || qp->stride_A < 0 || qp->stride_l < 0 || qp->stride_u < 0)
         SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: negative stride", what);
     if (qp->memspace != SQPH_HOST && qp->memspace != SQPH_DEVICE) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: bad memspace %d", what, qp->memspace);
@@ -439,7 +490,7 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what) {
     if (qp->memspace == SQPH_HOST) {
         // stage host data: one H2D per array into packed device buffers owned by the solver
         struct Item { const void *src; void **dst; size_t elems; long long *stride; };
-        Item items[5] = {{qp->P, &s->sP, n * n, &sP}, {qp->q, &s->sq, n, &sq}, {qp->A, &s->sA, m * n, &sA},
+        Item items[5] = {{qp->P, &s->sP, n * n, &sP}, {qp->q, &s->sq, n, &sq}, {qp->A, &s->sA, csr ? 0 : m * n, &sA},
                          {qp->l, &s->sl, m, &sl}, {qp->u, &s->su, m, &su}};
         for (auto &it : items) {
             if (it.elems == 0) continue;
@@ -459,8 +510,8 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what) {
         // only after the stream reaches them; make the borrow end with the call.
         SQPH_HIP(s, hipStreamSynchronize(s->stream));
     }
-    if (s->dtype == SQPH_F32) return launch_typed<float>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su);
-    return launch_typed<double>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su);
+    if (s->dtype == SQPH_F32) return launch_typed<float>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su, csr);
+    return launch_typed<double>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su, csr);
 }
 
 // CSR entry points: expand A on the device, then the dense path.
@@ -517,6 +568,36 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
         if (ncol) SQPH_HIP(s, hipMemcpyAsync(s->cCol, colind, ncol * sizeof(int), hipMemcpyHostToDevice, s->stream));
         if (nval) SQPH_HIP(s, hipMemcpyAsync(s->cVal, val, nval * e, hipMemcpyHostToDevice, s->stream));
         rowptr = (const int *)s->cRow; colind = (const int *)s->cCol; val = s->cVal;
+    }
+    // native sparse kernel (admm_csr_kernel.h) where it applies: shapes beyond the dense register-tiled kernels, rows
+    // sorted and duplicate-free, CSR + CSC index + vectors within one CU's LDS
+    if (!(s->flags & (SQPH_FLAG_CSR_EXPAND | SQPH_FLAG_FORCE_GENERIC)) && !(m <= 128 && n <= 64) && m <= 512 && n <= 224 &&
+        c->nnz_max >= 1 && c->nnz_max <= 65535) {
+        int TT = 0;
+        size_t lds_bytes = 0;
+#define SQPH_CSR_PICK(TT_)                                                              \
+    if (!TT && (int)n <= 32 * TT_) {                                                    \
+        TT = TT_;                                                                       \
+        lds_bytes = sqph::CsrLayout<TT_>::make((int)m, (int)c->nnz_max).bytes;          \
+    }
+        SQPH_CSR_SHAPES(SQPH_CSR_PICK)
+#undef SQPH_CSR_PICK
+        if (TT && lds_bytes <= 160 * 1024) {
+            if (!s->cBad) SQPH_HIP(s, hipMalloc((void **)&s->cBad, sizeof(int)));
+            SQPH_HIP(s, hipMemsetAsync(s->cBad, 0, sizeof(int), s->stream));
+            const size_t npat = s_row ? B : 1;
+            hipLaunchKernelGGL(csr_check, dim3((unsigned)((npat * m + 255) / 256)), dim3(256), 0, s->stream, (int)npat, (int)n, (int)m,
+                               (long long)c->nnz_max, rowptr, colind, s_row, s_col, s->cBad);
+            SQPH_HIP(s, hipGetLastError());
+            int bad = 0;
+            SQPH_HIP(s, hipMemcpyAsync(&bad, s->cBad, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+            SQPH_HIP(s, hipStreamSynchronize(s->stream));
+            if (bad & 3) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed CSR (%s)", what, (bad & 1) ? "row pointers not monotone" : "column index out of range");
+            if (!(bad & 4)) {
+                CsrDesc cd{rowptr, colind, val, s_row, s_col, s_val ? s_val : 0, (int)c->nnz_max, TT};
+                return run(s, &d, mode, what, &cd);
+            }
+        }
     }
     const bool shared = s_val == 0;
     const size_t nexp = shared ? 1 : B;

@@ -8,6 +8,7 @@
 #include "../../sqp_solver_amd/csrc/admm_generic.h"
 #include "../../sqp_solver_amd/csrc/admm_tile_kernel.h"
 #include "../../sqp_solver_amd/csrc/admm_wg_kernel.h"
+#include "../../sqp_solver_amd/csrc/admm_csr_kernel.h"
 
 extern "C" {
 
@@ -63,5 +64,16 @@ int sim_run(const SimArgs *s, int variant, int dtype, int nt) {
     if (variant == 1) return dtype == SQPH_F32 ? sqph::sim_run_tile<double, float>(convert<float>(*s)) : sqph::sim_run_tile<double, double>(convert<double>(*s));
     if (variant == 2) return dtype == SQPH_F32 ? sqph::sim_run_wg<float>(convert<float>(*s)) : sqph::sim_run_wg<double>(convert<double>(*s));
     return -1;
+}
+
+// the sparse-A kernel (admm_csr_kernel.h): A comes as CSR, s->A is ignored
+int sim_run_csr(const SimArgs *s, const int *rowptr, const int *colind, const void *val, long long s_rowptr, long long s_colind,
+                long long s_val, int nnz_cap, int dtype) {
+    if (dtype == SQPH_F32) {
+        sqph::CsrArgs<float> ca{rowptr, colind, (const float *)val, s_rowptr, s_colind, s_val, nnz_cap};
+        return sqph::sim_run_csr<float>(convert<float>(*s), ca);
+    }
+    sqph::CsrArgs<double> ca{rowptr, colind, (const double *)val, s_rowptr, s_colind, s_val, nnz_cap};
+    return sqph::sim_run_csr<double>(convert<double>(*s), ca);
 }
 }

@@ -12,7 +12,7 @@ SIMDIR = os.path.join(HERE, "sim")
 LIB = os.path.join(SIMDIR, "libsqph_sim.so")
 
 MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET = 1, 2, 4, 8
-GENERIC, TILE, WG = 0, 1, 2
+GENERIC, TILE, WG, CSR = 0, 1, 2, 3
 
 
 class SimArgs(ctypes.Structure):
@@ -40,6 +40,9 @@ def lib():
         _lib = ctypes.CDLL(LIB)
         _lib.sim_run.argtypes = [ctypes.POINTER(SimArgs), ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.sim_run.restype = ctypes.c_int
+        _lib.sim_run_csr.argtypes = [ctypes.POINTER(SimArgs), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                                     ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+        _lib.sim_run_csr.restype = ctypes.c_int
     return _lib
 
 
@@ -69,8 +72,10 @@ class SimSolverBatch:
         self.Sinv = np.zeros((batch, 2 * n * n), np.float64)
         self.At = np.zeros((batch, mm * n), np.float64)
 
-    def _run(self, mode, P, q, A, l, u):
+    def _run(self, mode, P, q, A, l, u, csr=None):
         n, m = self.n, self.m
+        if csr is not None:
+            A = np.zeros((np.asarray(P).shape[0], m, n)) if np.asarray(P).ndim == 3 else np.zeros((m, n))
         if m == 0:
             B0 = np.asarray(P).shape[0] if np.asarray(P).ndim == 3 else self.batch
             A = np.zeros((B0, 0, n)) if A is None else A
@@ -97,6 +102,19 @@ class SimSolverBatch:
         a.rho_tol = s.adaptive_rho_tolerance
         a.max_iter, a.check_termination, a.warm_start = s.max_iter, s.check_termination, s.warm_start
         a.adaptive_rho, a.adaptive_rho_interval = s.adaptive_rho, s.adaptive_rho_interval
+        if csr is not None:
+            rp, ci, v = csr
+            rp = np.ascontiguousarray(rp, np.int32)
+            ci = np.ascontiguousarray(ci, np.int32)
+            v = np.ascontiguousarray(v, self.dtype)
+            shared = rp.ndim == 1
+            rc = lib().sim_run_csr(ctypes.byref(a), rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 0 if shared else rp.shape[-1],
+                                   0 if shared else ci.shape[-1], 0 if v.ndim == 1 else v.shape[-1], ci.shape[-1],
+                                   1 if self.dtype == np.float32 else 0)
+            if rc != 0:
+                raise RuntimeError("sim_run_csr failed rc=%d" % rc)
+            self._last = B
+            return
         rc = lib().sim_run(ctypes.byref(a), self.variant, 1 if self.dtype == np.float32 else 0, self.nt)
         if rc != 0:
             raise RuntimeError("sim_run failed rc=%d" % rc)
@@ -113,6 +131,18 @@ class SimSolverBatch:
 
     def setup_solve(self, P, q, A, l, u):
         self._run(MODE_SETUP | MODE_SOLVE, P, q, A, l, u)
+
+    def setup_csr(self, P, q, rp, ci, v, l, u):
+        self._run(MODE_SETUP, P, q, None, l, u, csr=(rp, ci, v))
+
+    def update_qp_csr(self, P, q, rp, ci, v, l, u):
+        self._run(MODE_UPDATE, P, q, None, l, u, csr=(rp, ci, v))
+
+    def solve_csr(self, P, q, rp, ci, v, l, u):
+        self._run(MODE_SOLVE, P, q, None, l, u, csr=(rp, ci, v))
+
+    def setup_solve_csr(self, P, q, rp, ci, v, l, u):
+        self._run(MODE_SETUP | MODE_SOLVE, P, q, None, l, u, csr=(rp, ci, v))
 
     def primal_solution(self):
         return self.x[: self._last].astype(self.dtype)

@@ -81,11 +81,56 @@ def test_csr_reference_cases():
     cases.csr_malformed(make_gpu)
 
 
+def make_gpu_csr_expand(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
+    from sqp_solver_amd import QPSolverBatch
+
+    return QPSolverBatch(n, m, batch, dtype=dtype, device=0, legacy_cold_start=legacy_cold_start, csr_expand=True)
+
+
+@pytest.mark.parametrize("make", [make_gpu, make_gpu_csr_expand], ids=["native", "expand"])
 @pytest.mark.parametrize("n,m,batch,density,shared", [(20, 40, 16, 0.2, False), (50, 100, 16, 0.1, False), (30, 45, 8, 0.3, True),
-                                                       (200, 400, 4, 0.05, False)])
-def test_csr_parity(n, m, batch, density, shared):
-    """BASELINE config 5 shapes (n=200, m=400, 5 % dense CSR A) and smaller ones against the oracle on the densified A"""
-    cases.csr_parity(make_gpu, n, m, batch, density=density, shared_pattern=shared, iters=50)
+                                                       (100, 180, 6, 0.08, False), (70, 300, 5, 0.1, True), (200, 400, 4, 0.05, False),
+                                                       (224, 512, 3, 0.03, False)])
+def test_csr_parity(n, m, batch, density, shared, make):
+    """BASELINE config 5 shapes (n=200, m=400, 5 % dense CSR A) and smaller ones against the oracle on the densified A;
+    shapes beyond the dense register-tiled kernels take the native sparse kernel (admm_csr_kernel.h)"""
+    cases.csr_parity(make, n, m, batch, density=density, shared_pattern=shared, iters=50)
+
+
+def test_csr_native_kernel_is_used_and_handles_termination_paths():
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    n, m, B = 200, 400, 6
+    P, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=0.05, seed=9)
+    for kw in (dict(), dict(adaptive_rho=1), dict(adaptive_rho=1, adaptive_rho_interval=10, alpha=1.6, eps_abs=1e-5, eps_rel=1e-5)):
+        s = make_gpu(n, m, B)
+        for k, val in kw.items():
+            setattr(s.settings, k, val)
+        s.setup_solve_csr(P, q, rp, ci, v, l, u)
+        assert s.kernel_name() == "csr_t7"
+        x, y, z, info = s.solution()
+        xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings))
+        assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all() and (info.rho_updates == io["rho_updates"]).all()
+        assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
+    # setup, then solve twice (warm), then update_qp with new values on the same pattern
+    s = make_gpu(n, m, B)
+    so = [oracle.QPSolver() for _ in range(B)]
+    s.setup_csr(P, q, rp, ci, v, l, u)
+    s.solve_csr(P, q, rp, ci, v, l, u)
+    s.solve_csr(P, q + 0.1, rp, ci, v, l, u)
+    v2 = v * 1.25
+    s.update_qp_csr(P, q, rp, ci, v2, l, u)
+    s.solve_csr(P, q, rp, ci, v2, l, u)
+    x, y, z, info = s.solution()
+    for b in range(B):
+        o = so[b]
+        o.setup(P[b], q[b], A[b], l[b], u[b])
+        o.solve(P[b], q[b], A[b], l[b], u[b])
+        o.solve(P[b], q[b] + 0.1, A[b], l[b], u[b])
+        o.update_qp(P[b], q[b], 1.25 * A[b], l[b], u[b])
+        o.solve(P[b], q[b], 1.25 * A[b], l[b], u[b])
+        assert info.iter[b] == o.info.iter and info.status[b] == o.info.status
+        assert cases.relerr(x[b], o.primal_solution()) < cases.TOL_F64 and cases.relerr(y[b], o.dual_solution()) < cases.TOL_F64
 
 
 def test_golden_fixtures():
