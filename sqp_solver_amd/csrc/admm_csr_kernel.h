@@ -532,7 +532,15 @@ struct CsrKernel {
             }
         }
 
+#ifdef SQPH_PHASE_TIMING
+        unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+        const unsigned long long tstart = tprev;
+#define SQPH_CTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
+#else
+#define SQPH_CTICK(k)
+#endif
         load_sparse(ca, qp, n, m, L, smem);
+        SQPH_CTICK(0)
 
         T w[NE];
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
@@ -552,8 +560,11 @@ struct CsrKernel {
                 int n_f = n, r_f = r, c_f = c;
                 const TIN *gP_f = gP;
                 SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_S(gP_f);
+                SQPH_CTICK(10)
                 form_S(gP_f, n_f, sigma, L, smem, r_f, c_f, w);
+                SQPH_CTICK(1)
                 const bool ok = eliminate(n_f, L, lds, r_f, c_f, w);
+                SQPH_CTICK(2)
                 store_tile(gW, n_f, r_f, c_f, w);
                 __syncthreads();
                 need_factor = false;
@@ -575,28 +586,35 @@ struct CsrKernel {
             // w = R (z - R^-1 y)  [rhs tail of qp.cpp:275 pre-multiplied by R], plain-indexed for the CSC gather
             __syncthreads();
             if (mown && pl == 0) wv[im] = rho * (z - rinv * y);
+            SQPH_CTICK(10)
             for (; iter <= a.max_iter; iter++) {
                 __syncthreads();
+                SQPH_CTICK(8)
                 {   // t = (sigma x - q) + A' w, published in column-gather order
                     const T s = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
                     if (ql == 0 && jn < L.NP) tcol[(jn & 31) * CS + (jn >> 5)] = nown ? (sigma * x - q) + s : T(0);
                 }
                 __syncthreads();
+                SQPH_CTICK(3)
                 stage_W(w, tcol, st, r, c, CS, SP);
                 __syncthreads();
+                SQPH_CTICK(4)
                 {   // y1 = W t, published in row-gather order
                     const T y1 = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
                     if (ql == 0 && jn < L.NP) yrow[(jn & 31) * CS + (jn >> 5)] = nown ? y1 : T(0);
                 }
                 __syncthreads();
+                SQPH_CTICK(5)
                 stage_WT(w, yrow, st, r, c, CS, SP);
                 __syncthreads();
+                SQPH_CTICK(6)
                 {   // x~ = W' y1: plain-indexed for the CSR gather; x relaxation (qp.cpp:96)
                     const T xtj = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
                     if (ql == 0 && jn < L.NP) xt[jn] = nown ? xtj : T(0);
                     if (nown) x = alpha * xtj + oma * x;
                 }
                 __syncthreads();
+                SQPH_CTICK(7)
                 {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
                     const T zt = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
                     if (mown) {
@@ -705,6 +723,10 @@ struct CsrKernel {
             if (iter > a.max_iter) info.status = SQPH_MAX_ITER_EXCEEDED;
             info.iter = iter;
         }
+#ifdef SQPH_PHASE_TIMING
+        tacc[9] = __builtin_amdgcn_s_memtime() - tstart;
+        if (t < 48 && (t & 3) == 0) x = (T)tacc[t >> 2];  // debug build only: wave 0's phase ticks instead of x[0..12)
+#endif
         if (state_dirty) {
             if (nown && ql == 0) sx[jn] = x;
             if (mown && pl == 0) {
