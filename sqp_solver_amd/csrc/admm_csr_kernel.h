@@ -57,14 +57,18 @@ struct CsrLayout {
     static constexpr int o_w = o_ccur_d + NP / 2;
     // offsets in 32-bit words
     static constexpr int o_colptr = 2 * o_colptr_d, o_ccur = 2 * o_ccur_d;
-    int o_rho, o_val;          // doubles
-    int o_rowptr, o_csc, o_col;  // 32-bit words
+    static constexpr int o_qv = o_w;  // owner constants q [NP] ...
+    int o_lo, o_up, o_rinv, o_wv, o_rho, o_val;  // ... l, u, 1/rho [MP each]; w [MP] (= rho during a factorisation); CSR values
+    int o_rowptr, o_csc, o_col;                  // 32-bit words
     size_t bytes;
     __host__ __device__ static CsrLayout make(int m, int nnz_cap) {
         CsrLayout L;
         const int MP = (m + 1) & ~1;
-        int d = o_w + MP;
-        L.o_rho = d; d += MP;
+        int d = o_qv + NP;
+        L.o_lo = d; d += MP;
+        L.o_up = d; d += MP;
+        L.o_rinv = d; d += MP;
+        L.o_wv = d; L.o_rho = d; d += MP;
         L.o_val = d; d += nnz_cap;
         int w = 2 * d;
         L.o_csc = w; w += nnz_cap;
@@ -76,9 +80,18 @@ struct CsrLayout {
 };
 
 #ifdef SQPH_SIM
+#define SQPH_LANE(tl) const int tl = (int)threadIdx.x
+#else
+#define SQPH_LANE(tl) int tl = (int)threadIdx.x; SQPH_OPAQUE_V(tl)
+#endif
+
+#ifdef SQPH_SIM
 inline int lds_atomic_inc(int *p) { return (*p)++; }
+inline int uniform_int(int v) { return v; }
 #else
 __device__ __forceinline__ int lds_atomic_inc(int *p) { return atomicAdd(p, 1); }
+// a value known to be workgroup-uniform that the compiler holds in a VGPR (e.g. returned by an out-of-line function)
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
 template <typename TIN, int TT>
@@ -165,7 +178,7 @@ struct CsrKernel {
 
     // ---------------------------------------------------------------- set-up
     // CSR of this QP -> LDS, CSC index by counting sort (entries of a column ordered by row: deterministic sums)
-    static __device__ void load_sparse(const CsrArgs<TIN> &ca, int qp, int n, int m, const CsrLayout<TT> &L, unsigned char *smem) {
+    static __device__ __forceinline__ void load_sparse(const CsrArgs<TIN> &ca, int qp, int n, int m, const CsrLayout<TT> &L, unsigned char *smem) {
         const int t = threadIdx.x;
         T *lds = reinterpret_cast<T *>(smem);
         int *li = reinterpret_cast<int *>(smem);
@@ -253,8 +266,8 @@ struct CsrKernel {
     // Half-wave r owns column j = 32p + r of the panel: for every CSC entry (i, pos) of that column, in row order,
     // its 32 lanes add rho_i A_ij * (row i of A) into the panel column (distinct k per lane: rows are duplicate-free).
     static __device__ __forceinline__ void form_S(const TIN *__restrict__ gP, int n, T sigma, const CsrLayout<TT> &L, unsigned char *smem,
-                                                  int r, int c, T (&w)[NE]) {
-        const int t = threadIdx.x;
+                                                  int t, T (&w)[NE]) {
+        const int c = t & 31, r = t >> 5;
         T *lds = reinterpret_cast<T *>(smem);
         const int *li = reinterpret_cast<const int *>(smem);
         const int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr;
@@ -300,10 +313,10 @@ struct CsrKernel {
     // factor_schur), final scaling to W = D^-1/2 L^-1 D_J^-1/2.  One broadcast vector g per pivot k:
     //   g[j] = W-part of row k (j < k) | d + 1 (j = k) | column k of the trailing matrix (j > k)
     // and every entry (i,j), i > k, j <= i, gets  e -= (g[i]/d) * g[j].   Returns false on a bad pivot (block-uniform).
-    static __device__ __forceinline__ bool eliminate(int n, const CsrLayout<TT> &L, T *lds, int r, int c, T (&w)[NE]) {
+    static __device__ __forceinline__ bool eliminate(int n, const CsrLayout<TT> &L, T *lds, int t, T (&w)[NE]) {
         T *g = lds + L.o_g, *sj = lds + L.o_sj, *dsv = lds + L.o_ds;
         const int NPl = L.NP;
-        const int t = threadIdx.x;
+        const int c = t & 31, r = t >> 5;
         // diagonal -> sj
         if (t < NPl) sj[t] = T(1);
         __syncthreads();
@@ -344,6 +357,7 @@ struct CsrKernel {
 #pragma unroll
                 for (int b = 0; b <= a; b++) w[idx(a, b)] = w[idx(a, b)] * sr[a] * sc[b];
         }
+        bool good = true;
         for (int k = 0; k < n; k++) {
             const int ak = k >> 5, rk = k & 31;
             T *gk = g + (k & 1) * (NPl + 1);
@@ -379,20 +393,21 @@ struct CsrKernel {
             }
             __syncthreads();
             const T d = gk[NPl];
-            if (!(d > T(0)) || !(d * T(0) == T(0))) return false;  // block-uniform: every lane reads the same word
+            // a bad pivot is only recorded (block-uniform: every lane reads the same word); leaving the loop from here
+            // costs the whole tile its registers (the extra exit made the allocator spill 120 VGPRs)
+            if (!(d > T(0)) || !(d * T(0) == T(0))) good = false;
             const T dinv = T(1) / d;
             T gc[TT];
 #pragma unroll
             for (int b = 0; b < TT; b++) gc[b] = gk[c + 32 * b];
+            // branch-free on purpose: rows i <= k get l_i = 0 (a conditional update keeps old and new tile rows alive
+            // side by side and spilled the tile)
 #pragma unroll
             for (int a = 0; a < TT; a++) {
-                if (a >= ak) {  // block-uniform
-                    const int i = r + 32 * a;
-                    T li = gk[i] * dinv;
-                    if (a == ak) li = (r > rk) ? li : T(0);
+                const int i = r + 32 * a;
+                const T li = (i > k) ? -(gk[i] * dinv) : T(0);
 #pragma unroll
-                    for (int b = 0; b <= a; b++) w[idx(a, b)] = wg_fma(-li, gc[b], w[idx(a, b)]);
-                }
+                for (int b = 0; b <= a; b++) w[idx(a, b)] = wg_fma(li, gc[b], w[idx(a, b)]);
             }
             // entries of g for columns/rows outside [0,n) are never written: zero from the initial clear below
         }
@@ -414,7 +429,7 @@ struct CsrKernel {
                 }
         }
         __syncthreads();
-        return true;
+        return good;
     }
 
     // tile <-> global workspace (the factor survives between setup() and solve() calls there), col-major n x n
@@ -458,8 +473,6 @@ struct CsrKernel {
     }
 
     static __device__ void run(const KArgs<T, TIN> &a, const CsrArgs<TIN> &ca, unsigned char *smem) {
-        const int t = threadIdx.x;
-        const int c = t & 31, r = t >> 5;
         const int qp = blockIdx.x;
         if (qp >= a.batch) return;
         const int n = a.n, m = a.m;
@@ -471,7 +484,8 @@ struct CsrKernel {
         const unsigned *csc = reinterpret_cast<const unsigned *>(li + L.o_csc);
         const unsigned short *col = reinterpret_cast<const unsigned short *>(li + L.o_col);
         const T *val = lds + L.o_val;
-        T *st = lds + L.o_stage, *tcol = lds + L.o_tcol, *yrow = lds + L.o_yrow, *xt = lds + L.o_xt, *wv = lds + L.o_w;
+        T *st = lds + L.o_stage, *tcol = lds + L.o_tcol, *yrow = lds + L.o_yrow, *xt = lds + L.o_xt, *wv = lds + L.o_wv;
+        T *qv = lds + L.o_qv, *lov = lds + L.o_lo, *upv = lds + L.o_up, *rinvv = lds + L.o_rinv;
         const int CS = L.CS, SP = L.SP;
 
         const TIN *gP = a.P + (long)qp * a.sP;
@@ -491,25 +505,36 @@ struct CsrKernel {
         if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
             return;  // qp.cpp:68-71 (block-uniform)
 
-        // element owners: the lane quad 4j..4j+3 tracks x_j, q_j; the lane pair 2i, 2i+1 tracks z_i, y_i, l_i, u_i, rho_i
+        // element owners: the lane quad 4j..4j+3 tracks x_j; the lane pair 2i, 2i+1 tracks z_i, y_i, rho_i.
+        // Lane indices are re-derived from a laundered thread id in every phase (SQPH_LANE): kept live across the solve
+        // they and the LDS addresses computed from them crowd the W tile out of the 128 VGPRs a lane has.
+        T x = 0, z = 0, y = 0, rho = T(1);
+        {
+        SQPH_LANE(t);
         const int jn = t >> 2, ql = t & 3, im = t >> 1, pl = t & 1;
         const bool nown = jn < n, mown = im < m;
-        const T INF = T(1) / T(0);
-        const T q = nown ? (T)gq[jn] : T(0);
-        const T lo = mown ? (T)gl[im] : -INF, up = mown ? (T)gu[im] : INF;
-        T x = 0, z = 0, y = 0, rho = T(1), rinv = T(1);
+        // q, l, u, 1/rho of the owned elements live in LDS (read once per iteration): the register budget of a
+        // 1024-lane workgroup is 128 VGPRs per lane and the W tile takes 56 of them
+        if (ql == 0 && jn < L.NP) qv[jn] = nown ? (T)gq[jn] : T(0);
+        if (pl == 0 && mown) {
+            lov[im] = (T)gl[im];
+            upv[im] = (T)gu[im];
+            rinvv[im] = T(1);
+        }
+        __syncthreads();
 
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
             rho_s = a.rho0;
             if (mown) {
+                const T lo = lov[im], up = upv[im];
                 int ctype = SQPH_INEQUALITY_CONSTRAINT;
                 if (lo < -a.loose_thresh && up > a.loose_thresh)
                     ctype = SQPH_LOOSE_BOUNDS;
                 else if (up - lo < a.eq_tol)
                     ctype = SQPH_EQUALITY_CONSTRAINT;
                 rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
-                rinv = T(1) / rho;
                 if (pl == 0) {
+                    rinvv[im] = T(1) / rho;
                     sct[im] = ctype;
                     srho[im] = rho;
                 }
@@ -528,8 +553,9 @@ struct CsrKernel {
                 z = sz[im];
                 y = sy[im];
                 rho = srho[im];
-                rinv = T(1) / rho;
+                if (pl == 0) rinvv[im] = T(1) / rho;
             }
+        }
         }
 
 #ifdef SQPH_PHASE_TIMING
@@ -546,7 +572,10 @@ struct CsrKernel {
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
-        if (!need_factor) load_tile(gW, n, r, c, w);
+        if (!need_factor) {
+            SQPH_LANE(t);
+            load_tile(gW, n, t >> 5, t & 31, w);
+        }
         const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
         int iter = 1;
         int next_check = a.check_termination > 0 ? a.check_termination : -1;
@@ -554,19 +583,42 @@ struct CsrKernel {
         for (;;) {
             if (need_factor) {
                 __syncthreads();
-                if (mown && pl == 0) lds[L.o_rho + im] = rho;
+                // nothing but the tile should be live while it is being built: the iterates are parked in the state
+                // arrays (where they end up anyway) and picked up again afterwards
+                SQPH_LANE(t);
+                const int jn = t >> 2, ql = t & 3, im = t >> 1, pl = t & 1;
+                const bool nown = jn < n, mown = im < m;
+                if (nown && ql == 0) sx[jn] = x;
+                if (mown && pl == 0) {
+                    sz[im] = z;
+                    sy[im] = y;
+                    srho[im] = rho;
+                    lds[L.o_rho + im] = rho;
+                }
                 for (int e = t; e < 2 * (L.NP + 1); e += NT) lds[L.o_g + e] = 0;
                 __syncthreads();
-                int n_f = n, r_f = r, c_f = c;
-                const TIN *gP_f = gP;
-                SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_S(gP_f);
                 SQPH_CTICK(10)
-                form_S(gP_f, n_f, sigma, L, smem, r_f, c_f, w);
-                SQPH_CTICK(1)
-                const bool ok = eliminate(n_f, L, lds, r_f, c_f, w);
-                SQPH_CTICK(2)
-                store_tile(gW, n_f, r_f, c_f, w);
+                bool ok;
+                {
+                    int n_f = n;
+                    const TIN *gP_f = gP;
+                    SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(gP_f);
+                    SQPH_LANE(tf);
+                    form_S(gP_f, n_f, sigma, L, smem, tf, w);
+                    SQPH_CTICK(1)
+                    ok = eliminate(n_f, L, lds, tf, w);
+                    SQPH_CTICK(2)
+                    store_tile(gW, n_f, tf >> 5, tf & 31, w);
+                }
                 __syncthreads();
+                {   // pick the parked iterates up again
+                    SQPH_LANE(t2);
+                    const int jn_f = t2 >> 2, im_f = t2 >> 1;
+                    x = jn_f < n ? sx[jn_f] : T(0);
+                    z = im_f < m ? sz[im_f] : T(0);
+                    y = im_f < m ? sy[im_f] : T(0);
+                    rho = im_f < m ? srho[im_f] : T(1);
+                }
                 need_factor = false;
                 if (!solving) {
                     info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
@@ -585,30 +637,50 @@ struct CsrKernel {
             }
             // w = R (z - R^-1 y)  [rhs tail of qp.cpp:275 pre-multiplied by R], plain-indexed for the CSC gather
             __syncthreads();
-            if (mown && pl == 0) wv[im] = rho * (z - rinv * y);
+            {
+                SQPH_LANE(t);
+                const int im = t >> 1;
+                if (im < m && (t & 1) == 0) wv[im] = rho * (z - rinvv[im] * y);
+            }
             SQPH_CTICK(10)
             for (; iter <= a.max_iter; iter++) {
                 __syncthreads();
                 SQPH_CTICK(8)
+                // every phase re-derives its lane indices from a laundered thread id: kept live across the loop, the LDS
+                // addresses they feed would not fit next to the tile (they were spilled to scratch and reloaded per phase)
                 {   // t = (sigma x - q) + A' w, published in column-gather order
+                    SQPH_LANE(tl);
+                    const int jn = tl >> 2, ql = tl & 3;
+                    const bool nown = jn < n;
                     const T s = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
-                    if (ql == 0 && jn < L.NP) tcol[(jn & 31) * CS + (jn >> 5)] = nown ? (sigma * x - q) + s : T(0);
+                    if (ql == 0 && jn < L.NP) tcol[(jn & 31) * CS + (jn >> 5)] = nown ? (sigma * x - qv[jn]) + s : T(0);
                 }
                 __syncthreads();
                 SQPH_CTICK(3)
-                stage_W(w, tcol, st, r, c, CS, SP);
+                {
+                    SQPH_LANE(tl);
+                    stage_W(w, tcol, st, tl >> 5, tl & 31, CS, SP);
+                }
                 __syncthreads();
                 SQPH_CTICK(4)
                 {   // y1 = W t, published in row-gather order
+                    SQPH_LANE(tl);
+                    const int jn = tl >> 2, ql = tl & 3;
                     const T y1 = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
-                    if (ql == 0 && jn < L.NP) yrow[(jn & 31) * CS + (jn >> 5)] = nown ? y1 : T(0);
+                    if (ql == 0 && jn < L.NP) yrow[(jn & 31) * CS + (jn >> 5)] = jn < n ? y1 : T(0);
                 }
                 __syncthreads();
                 SQPH_CTICK(5)
-                stage_WT(w, yrow, st, r, c, CS, SP);
+                {
+                    SQPH_LANE(tl);
+                    stage_WT(w, yrow, st, tl >> 5, tl & 31, CS, SP);
+                }
                 __syncthreads();
                 SQPH_CTICK(6)
                 {   // x~ = W' y1: plain-indexed for the CSR gather; x relaxation (qp.cpp:96)
+                    SQPH_LANE(tl);
+                    const int jn = tl >> 2, ql = tl & 3;
+                    const bool nown = jn < n;
                     const T xtj = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
                     if (ql == 0 && jn < L.NP) xt[jn] = nown ? xtj : T(0);
                     if (nown) x = alpha * xtj + oma * x;
@@ -616,14 +688,19 @@ struct CsrKernel {
                 __syncthreads();
                 SQPH_CTICK(7)
                 {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
+                    SQPH_LANE(tl);
+                    const int im = tl >> 1, pl = tl & 1;
+                    const bool mown = im < m;
                     const T zt = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
                     if (mown) {
                         const T zr = alpha * zt + oma * z;
-                        T zn = zr + rinv * y;
+                        T zn = zr + rinvv[im] * y;
+                        const T lo = lov[im], up = upv[im];
                         zn = zn < lo ? lo : zn;
                         zn = zn > up ? up : zn;
                         y = y + rho * (zr - zn);
                         z = zn;
+                        if (pl == 0) wv[im] = rho * (z - rinvv[im] * y);  // next iteration's w (read after the loop-top barrier)
                     }
                 }
                 bool check = false, adapt = false;
@@ -638,6 +715,9 @@ struct CsrKernel {
                 if (check || adapt) {
                     // update_state + residuals, qp.cpp:316-331, 353-361
                     __syncthreads();
+                    SQPH_LANE(tl);
+                    const int t = tl, jn = tl >> 2, ql = tl & 3, im = tl >> 1, pl = tl & 1;
+                    const bool nown = jn < n, mown = im < m;
                     if (ql == 0 && jn < L.NP) {
                         xt[jn] = nown ? x : T(0);
                         yrow[(jn & 31) * CS + (jn >> 5)] = nown ? x : T(0);
@@ -647,9 +727,9 @@ struct CsrKernel {
                     const T Ax = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
                     const T ATy = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
                     {
-                        int n_c = n, r_c = r, c_c = c;
+                        int n_c = n, r_c = tl >> 5, c_c = tl & 31;
                         const TIN *gP_c = gP;
-                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gP_c);
+                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_S(gP_c);
                         stage_P_gmem(gP_c, n_c, yrow, st, r_c, c_c, CS, SP);
                     }
                     __syncthreads();
@@ -661,6 +741,7 @@ struct CsrKernel {
                         v[2] = tabs(Ax - z);
                     }
                     if (nown) {
+                        const T q = qv[jn];
                         v[3] = tabs(Px);
                         v[4] = tabs(ATy);
                         v[5] = tabs(q);
@@ -706,7 +787,7 @@ struct CsrKernel {
                             rho_s = new_rho;
                             if (mown) {
                                 rho = rho_for_type<T>(sct[im], rho_s, a.rho_min, a.rho_eq_factor);
-                                rinv = T(1) / rho;
+                                if (pl == 0) rinvv[im] = T(1) / rho;
                             }
                             info.rho_updates += 1;
                             need_factor = true;
@@ -714,8 +795,8 @@ struct CsrKernel {
                         }
                     }
                     __syncthreads();
+                    if (mown && pl == 0) wv[im] = rho * (z - rinvv[im] * y);  // the check borrowed wv for y
                 }
-                if (mown && pl == 0) wv[im] = rho * (z - rinv * y);
             }
             if (!need_factor) break;
         }
@@ -725,11 +806,13 @@ struct CsrKernel {
         }
 #ifdef SQPH_PHASE_TIMING
         tacc[9] = __builtin_amdgcn_s_memtime() - tstart;
-        if (t < 48 && (t & 3) == 0) x = (T)tacc[t >> 2];  // debug build only: wave 0's phase ticks instead of x[0..12)
+        if (threadIdx.x < 48 && (threadIdx.x & 3) == 0) x = (T)tacc[threadIdx.x >> 2];  // debug build only: wave 0's phase ticks instead of x[0..12)
 #endif
+        SQPH_LANE(t);
         if (state_dirty) {
-            if (nown && ql == 0) sx[jn] = x;
-            if (mown && pl == 0) {
+            const int jn = t >> 2, im = t >> 1;
+            if (jn < n && (t & 3) == 0) sx[jn] = x;
+            if (im < m && (t & 1) == 0) {
                 sz[im] = z;
                 sy[im] = y;
                 srho[im] = rho;
