@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import cases
+import oracle
 import simlib
 
 
@@ -117,3 +118,33 @@ def test_wg_state_paths():
     cases.shared_matrices(make_wg)
     cases.edge_shapes(make_wg)
     cases.warm_start_and_resolve(make_wg, n=50, m=100, batch=2)
+
+
+# ------------------------------------------------------------------ the sparse-A kernel (admm_csr_kernel.h), 1024 lanes per QP
+def make_csr(n, m, batch, dtype=np.float64, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.CSR, **kw)
+
+
+def test_csr_kernel_reference_cases():
+    """tests/qp_solver_sparse_test.cpp (SimpleQP, multiple solve, update_qp) through the sparse kernel, tile edge 1"""
+    cases.csr_reference_cases(make_csr)
+
+
+@pytest.mark.parametrize("n,m,density,shared", [(12, 20, 0.3, False), (40, 60, 0.15, True)], ids=["t1", "t2"])
+def test_csr_kernel_parity(n, m, density, shared):
+    cases.csr_parity(make_csr, n, m, 1, iters=30, density=density, shared_pattern=shared)
+
+
+def test_csr_kernel_adaptive_rho_refactors_in_kernel():
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    n, m = 14, 24
+    P, q, rp, ci, v, l, u, A = random_csr_qp_batch(2, n, m, density=0.3, seed=4)
+    s = make_csr(n, m, 2)
+    s.settings.adaptive_rho, s.settings.adaptive_rho_interval, s.settings.eps_abs, s.settings.eps_rel = 1, 10, 1e-5, 1e-5
+    s.setup_solve_csr(P, q, rp, ci, v, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings))
+    assert (io["rho_updates"] > 1).any()  # the case does exercise a refactorisation
+    assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all() and (info.rho_updates == io["rho_updates"]).all()
+    assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
