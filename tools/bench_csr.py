@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--check", type=int, default=4, help="QPs compared with the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="time the CPU oracle (all host cores) on this many QPs")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     P, q, rp, ci, v, l, u, A, nnz = make(a.batch, a.n, a.m, a.density, 20250233, dev)
@@ -85,6 +86,20 @@ def main():
         xo, yo, zo, io = oracle.solve_batch(h(P), h(q), h(A), h(l), h(u), st)
         rel = lambda p, r: float(np.max(np.abs(p - r).max(axis=1) / np.abs(r).max(axis=1)))  # noqa: E731
         out["parity_max_rel_err_x"], out["parity_max_rel_err_y"] = rel(x[:k], xo), rel(y[:k], yo)
+    if a.cpu_sample:
+        import os
+
+        import oracle
+
+        k = min(a.cpu_sample, a.batch)
+        h = lambda t: t[:k].cpu().numpy()  # noqa: E731
+        st = oracle.default_settings(max_iter=a.iters, check_termination=0)
+        args = [h(P), h(q), h(A), h(l), h(u)]
+        t0 = time.perf_counter()
+        oracle.solve_batch(*args, st)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": k / dt, "unit": "QP/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "%d QPs, oracle/qp_oracle.c (dense (n+m)^2 KKT LDL'), OpenMP over QPs, %.1f s" % (k, dt)}
     print(json.dumps(out))
 
 
