@@ -25,6 +25,16 @@
 
 #include "../sqp_hip.h"
 
+// Eigen is optional: when its headers are on the include path the problem struct can be built straight from the
+// reference's five `const Eigen::Matrix*` (include/solvers/qp.hpp:29-33).  (Not compiled in this repository's own
+// test environment, which has no Eigen.)
+#if defined(__has_include)
+#if __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#define SQP_HIP_HAVE_EIGEN 1
+#endif
+#endif
+
 namespace qp_solver {
 
 typedef enum { SOLVED, MAX_ITER_EXCEEDED, UNSOLVED, NUMERICAL_ISSUES, UNINITIALIZED } QPSolverStatus;
@@ -37,6 +47,15 @@ struct QuadraticProblem {
     const Scalar *A = nullptr;
     const Scalar *l = nullptr;
     const Scalar *u = nullptr;
+
+    QuadraticProblem() = default;
+#ifdef SQP_HIP_HAVE_EIGEN
+    using Matrix = Eigen::Matrix<Scalar, Eigen::Dynamic, Eigen::Dynamic>;  // column-major, as qp.hpp:21
+    using Vector = Eigen::Matrix<Scalar, Eigen::Dynamic, 1>;
+    // borrowed, like the reference: the Eigen objects must outlive setup()/solve()
+    QuadraticProblem(const Matrix *P_, const Vector *q_, const Matrix *A_, const Vector *l_, const Vector *u_)
+        : n((int)P_->rows()), m((int)A_->rows()), P(P_->data()), q(q_->data()), A(A_->data()), l(l_->data()), u(u_->data()) {}
+#endif
 };
 
 template <typename Scalar>
