@@ -45,6 +45,18 @@ __global__ void cvt_f32_to_f64(const float *__restrict__ src, double *__restrict
     if (i < n) dst[i] = (double)src[i];
 }
 
+// gather up to four device segments (8-byte words) into one contiguous buffer: one D2H instead of four
+__global__ void pack_words(const unsigned long long *s0, size_t n0, const unsigned long long *s1, size_t n1, const unsigned long long *s2,
+                           size_t n2, const unsigned long long *s3, size_t n3, unsigned long long *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n0) dst[i] = s0[i];
+    else if (i < n0 + n1) dst[i] = s1[i - n0];
+    else if (i < n0 + n1 + n2) dst[i] = s2[i - n0 - n1];
+    else if (i < n0 + n1 + n2 + n3) dst[i] = s3[i - n0 - n1 - n2];
+}
+
+constexpr size_t SMALL_CALL_BYTES = 4u << 20;
+
 // CSR -> dense column-major expansion of the constraint matrices (one thread per (QP, row): duplicates within a row
 // are summed in storage order, so the result is deterministic).  `dst` must be zero-filled.
 template <typename TIN>
@@ -109,6 +121,12 @@ struct sqph_solver {
     void *cRow = nullptr, *cCol = nullptr, *cVal = nullptr, *cA = nullptr;
     int *cBad = nullptr;
     size_t cCol_cap = 0, cVal_cap = 0;
+    // small host-memspace calls (the SQP driver's n = 2..50 subproblems): one pinned staging buffer each way, one
+    // H2D / D2H per call instead of one per array
+    void *hpin = nullptr, *dpin = nullptr, *hout = nullptr, *dout = nullptr;
+    size_t hpin_cap = 0, hout_cap = 0;
+    hipEvent_t pin_ev = nullptr;
+    bool pin_busy = false;
     std::string err;
     const char *kernel_name = "none";
     bool timing = false;
@@ -242,6 +260,11 @@ void sqph_destroy(sqph_solver *s) {
     void *ptrs[] = {s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su, s->cRow, s->cCol, s->cVal, s->cA, s->cBad};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->hpin) (void)hipHostFree(s->hpin);
+    if (s->hout) (void)hipHostFree(s->hout);
+    if (s->dpin) (void)hipFree(s->dpin);
+    if (s->dout) (void)hipFree(s->dout);
+    if (s->pin_ev) (void)hipEventDestroy(s->pin_ev);
     for (auto &p : s->evs) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -328,6 +351,43 @@ int sqph_get_solution(sqph_solver *s, int batch, int memspace, void *x, void *y,
     const hipMemcpyKind kind = memspace == SQPH_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     struct Item { void *dst; const void *src; size_t elems; };
     const Item items[3] = {{x, s->x, B * s->n}, {y, s->y, B * s->m}, {z, s->z, B * s->m}};
+    {
+        const size_t w0 = x ? B * s->n : 0, w1 = y ? B * s->m : 0, w2 = z ? B * s->m : 0, w3 = info ? B * (sizeof(sqph_info) / 8) : 0;
+        const size_t words = w0 + w1 + w2 + w3;
+        if (memspace == SQPH_HOST && words > 0 && words * 8 <= SMALL_CALL_BYTES) {
+            if (words * 8 > s->hout_cap) {
+                if (s->hout) (void)hipHostFree(s->hout);
+                if (s->dout) (void)hipFree(s->dout);
+                s->hout = s->dout = nullptr;
+                s->hout_cap = 0;
+                const size_t cap = words * 8 < 65536 ? 65536 : words * 8;
+                SQPH_HIP(s, hipHostMalloc(&s->hout, cap, hipHostMallocDefault));
+                SQPH_HIP(s, hipMalloc(&s->dout, cap));
+                s->hout_cap = cap;
+            }
+            hipLaunchKernelGGL(pack_words, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s->stream,
+                               (const unsigned long long *)s->x, w0, (const unsigned long long *)s->y, w1,
+                               (const unsigned long long *)s->z, w2, (const unsigned long long *)s->info, w3, (unsigned long long *)s->dout);
+            SQPH_HIP(s, hipGetLastError());
+            SQPH_HIP(s, hipMemcpyAsync(s->hout, s->dout, words * 8, hipMemcpyDeviceToHost, s->stream));
+            SQPH_HIP(s, hipStreamSynchronize(s->stream));
+            const double *h = (const double *)s->hout;
+            void *dsts[3] = {x, y, z};
+            const size_t ws[3] = {w0, w1, w2};
+            for (int k = 0; k < 3; k++) {
+                if (!ws[k]) continue;
+                if (s->dtype == SQPH_F64) {
+                    memcpy(dsts[k], h, ws[k] * 8);
+                } else {  // QPSolver<float>: state is kept in fp64 on the device, narrowed on the way out
+                    float *d = (float *)dsts[k];
+                    for (size_t i = 0; i < ws[k]; i++) d[i] = (float)h[i];
+                }
+                h += ws[k];
+            }
+            if (w3) memcpy(info, h, w3 * 8);
+            return SQPH_OK;
+        }
+    }
     for (const Item &it : items) {
         if (!it.dst || it.elems == 0) continue;
         if (s->dtype == SQPH_F64) {
@@ -487,7 +547,52 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
     long long sP = qp->stride_P, sq = qp->stride_q, sA = qp->stride_A, sl = qp->stride_l, su = qp->stride_u;
     const size_t e = dsize(s->dtype);
     const size_t n = s->n, m = s->m;
+    bool staged = false;
     if (qp->memspace == SQPH_HOST) {
+        // small calls: pack everything into one pinned buffer, one H2D
+        struct PItem { const void *src; size_t elems; long long *stride; const void **out; size_t off, bytes; };
+        PItem pit[5] = {{qp->P, n * n, &sP, &P, 0, 0}, {qp->q, n, &sq, &q, 0, 0}, {qp->A, csr ? 0 : m * n, &sA, &A, 0, 0},
+                        {qp->l, m, &sl, &l, 0, 0}, {qp->u, m, &su, &u, 0, 0}};
+        size_t total = 0;
+        for (auto &it : pit) {
+            it.bytes = it.elems * e * (*it.stride == 0 ? 1 : (size_t)qp->batch);
+            it.off = total;
+            total += (it.bytes + 15) & ~(size_t)15;
+        }
+        if (total > 0 && total <= SMALL_CALL_BYTES) {
+            if (total > s->hpin_cap) {
+                if (s->pin_busy) SQPH_HIP(s, hipEventSynchronize(s->pin_ev));
+                s->pin_busy = false;
+                if (s->hpin) (void)hipHostFree(s->hpin);
+                if (s->dpin) (void)hipFree(s->dpin);
+                s->hpin = s->dpin = nullptr;
+                s->hpin_cap = 0;
+                const size_t cap = total < 65536 ? 65536 : total;
+                SQPH_HIP(s, hipHostMalloc(&s->hpin, cap, hipHostMallocDefault));
+                SQPH_HIP(s, hipMalloc(&s->dpin, cap));
+                s->hpin_cap = cap;
+            }
+            if (!s->pin_ev) SQPH_HIP(s, hipEventCreateWithFlags(&s->pin_ev, hipEventDisableTiming));
+            if (s->pin_busy) SQPH_HIP(s, hipEventSynchronize(s->pin_ev));  // the previous call's H2D has consumed the buffer
+            for (auto &it : pit) {
+                if (it.elems == 0) continue;
+                char *dstp = (char *)s->hpin + it.off;
+                if (*it.stride == 0 || (size_t)*it.stride == it.elems) {
+                    memcpy(dstp, it.src, it.bytes);
+                } else {
+                    for (int b = 0; b < qp->batch; b++)
+                        memcpy(dstp + (size_t)b * it.elems * e, (const char *)it.src + (size_t)b * (size_t)*it.stride * e, it.elems * e);
+                    *it.stride = (long long)it.elems;
+                }
+                *it.out = (const char *)s->dpin + it.off;
+            }
+            SQPH_HIP(s, hipMemcpyAsync(s->dpin, s->hpin, total, hipMemcpyHostToDevice, s->stream));
+            SQPH_HIP(s, hipEventRecord(s->pin_ev, s->stream));
+            s->pin_busy = true;
+            staged = true;
+        }
+    }
+    if (qp->memspace == SQPH_HOST && !staged) {
         // stage host data: one H2D per array into packed device buffers owned by the solver
         struct Item { const void *src; void **dst; size_t elems; long long *stride; };
         Item items[5] = {{qp->P, &s->sP, n * n, &sP}, {qp->q, &s->sq, n, &sq}, {qp->A, &s->sA, csr ? 0 : m * n, &sA},
