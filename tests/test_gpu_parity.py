@@ -1,5 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP kernels through the C-ABI
 (libsqp_hip.so via sqp_solver_amd.QPSolverBatch) against the CPU oracle on identical inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -174,6 +176,47 @@ def test_full_size_properties_c3():
     assert (info.status[:k] == io["status"]).all() and (info.iter[:k] == io["iter"]).all()
     rev = lambda t: torch.flip(t, dims=[0]).contiguous()  # noqa: E731
     s.setup_solve(rev(P), rev(q), rev(A_cm), rev(l), rev(u), colmajor=True)
+    x2, y2, z2, info2 = s.solution()
+    assert np.array_equal(x2[::-1], x) and np.array_equal(y2[::-1], y) and np.array_equal(info2.iter[::-1], info.iter)
+
+
+def test_full_size_properties_c5():
+    """BASELINE config 5 at full size (8,192 x n=200, m=400, 5 % dense CSR A), default termination, native sparse kernel:
+    every SOLVED QP passes the reference's termination test recomputed with torch on the dense A the CSR arrays encode;
+    z is a projection; a sample agrees with the oracle; the reversed batch reverses the results bit-exactly."""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_csr
+
+    B, n, m = 8192, 200, 400
+    dev = torch.device("cuda:0")
+    P, q, rp, ci, v, l, u, A, nnz = bench_csr.make(B, n, m, 0.05, 99, dev)
+    s = make_gpu(n, m, B)
+    s.setup_solve_csr(P, q, rp, ci, v, l, u)
+    assert s.kernel_name() == "csr_t7"
+    x, y, z, info = s.solution()
+    assert np.isin(info.status, [0, 1]).all() and (info.status == 0).mean() > 0.9
+    xt, yt, zt = (torch.from_numpy(a).to(dev) for a in (x, y, z))
+    Ax = torch.einsum("bij,bj->bi", A, xt)
+    Px = torch.einsum("bij,bj->bi", P, xt)
+    ATy = torch.einsum("bij,bi->bj", A, yt)
+    nrm = lambda t: t.abs().amax(dim=1)  # noqa: E731
+    r_p, r_d = nrm(Ax - zt), nrm(Px + q + ATy)
+    e_p = 1e-3 + 1e-3 * torch.maximum(nrm(Ax), nrm(zt))
+    e_d = 1e-3 + 1e-3 * torch.maximum(nrm(Px), torch.maximum(nrm(ATy), nrm(q)))
+    ok = torch.from_numpy(info.status == 0).to(dev)
+    assert bool((r_p[ok] <= e_p[ok] * (1 + 1e-9)).all()) and bool((r_d[ok] <= e_d[ok] * (1 + 1e-9) + 1e-12).all())
+    assert bool(((zt >= l - 1e-12) & (zt <= u + 1e-12)).all())
+    k = 8
+    h = lambda t: t[:k].cpu().numpy()  # noqa: E731
+    xo, yo, zo, io = oracle.solve_batch(h(P), h(q), h(A), h(l), h(u), oracle.default_settings())
+    assert cases.relerr(x[:k], xo) < cases.TOL_F64 and cases.relerr(y[:k], yo) < cases.TOL_F64
+    assert (info.status[:k] == io["status"]).all() and (info.iter[:k] == io["iter"]).all()
+    rev = lambda t: torch.flip(t, dims=[0]).contiguous()  # noqa: E731
+    s.setup_solve_csr(rev(P), rev(q), rev(rp), rev(ci), rev(v), rev(l), rev(u))
     x2, y2, z2, info2 = s.solution()
     assert np.array_equal(x2[::-1], x) and np.array_equal(y2[::-1], y) and np.array_equal(info2.iter[::-1], info.iter)
 
