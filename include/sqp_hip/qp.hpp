@@ -117,6 +117,7 @@ class BatchQPSolver {
         detail::check(sqph_create(&h_, device, n, m, batch, detail::dtype_of<Scalar>::value, flags), nullptr, "sqph_create");
         x_.resize((size_t)batch * n);
         y_.resize((size_t)batch * (m > 0 ? m : 1));
+        z_.resize((size_t)batch * (m > 0 ? m : 1));
         info_.resize(batch);
         raw_info_.resize(batch);
     }
@@ -165,6 +166,7 @@ class BatchQPSolver {
     // results of the last call (host copies, fetched lazily)
     const Scalar *primal_solution(int b) { fetch(); return &x_[(size_t)b * n_]; }
     const Scalar *dual_solution(int b) { fetch(); return &y_[(size_t)b * m_]; }
+    const Scalar *z(int b) { fetch(); return &z_[(size_t)b * m_]; }  // the reference keeps z as solver state (qp.hpp:224)
     const Info &info(int b) { fetch(); return info_[b]; }
     sqph_solver *handle() { return h_; }
     int n() const { return n_; }
@@ -213,7 +215,7 @@ class BatchQPSolver {
     }
     void fetch() {
         if (fetched_) return;
-        detail::check(sqph_get_solution(h_, last_batch_, SQPH_HOST, x_.data(), m_ ? y_.data() : nullptr, nullptr, raw_info_.data()), h_, "sqph_get_solution");
+        detail::check(sqph_get_solution(h_, last_batch_, SQPH_HOST, x_.data(), m_ ? y_.data() : nullptr, m_ ? z_.data() : nullptr, raw_info_.data()), h_, "sqph_get_solution");
         for (int b = 0; b < last_batch_; b++) {
             info_[b].status = (QPSolverStatus)raw_info_[b].status;
             info_[b].iter = raw_info_[b].iter;
@@ -229,7 +231,7 @@ class BatchQPSolver {
     bool fetched_ = true;
     sqph_solver *h_ = nullptr;
     Settings settings_;
-    std::vector<Scalar> x_, y_;
+    std::vector<Scalar> x_, y_, z_;
     std::vector<Info> info_;
     std::vector<sqph_info> raw_info_;
 };
@@ -326,7 +328,8 @@ class QPSolver {
     using info_t = QPSolverInfo<Scalar>;
     // public state, as in the reference (unsupported/qp_solver.hpp:172-200)
     int iter = 0;
-    Scalar x[n], y[m > 0 ? m : 1];
+    Scalar x[n], z[m > 0 ? m : 1], y[m > 0 ? m : 1];
+    int constr_type[m > 0 ? m : 1];  // INEQUALITY_CONSTRAINT / EQUALITY_CONSTRAINT / LOOSE_BOUNDS
     settings_t _settings;
     info_t _info;
 
@@ -346,6 +349,8 @@ class QPSolver {
         (impl_.*fn)(impl_.packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
         for (int i = 0; i < n; i++) x[i] = impl_.primal_solution(0)[i];
         for (int i = 0; i < m; i++) y[i] = impl_.dual_solution(0)[i];
+        for (int i = 0; i < m; i++) z[i] = impl_.z(0)[i];
+        if (m > 0) sqph_constr_type_init(detail::dtype_of<Scalar>::value, m, qp.l, qp.u, constr_type);
         _info = impl_.info(0);
         if (_info.status == NUMERICAL_ISSUES) _info.status = UNSOLVED;  // the legacy enum has no NUMERICAL_ISSUES (unsupported:84-89)
         iter = _info.iter;

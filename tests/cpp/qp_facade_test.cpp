@@ -125,6 +125,9 @@ static void testLegacyFixedSize() {  // tests/unsupported/qp_solver_test.cpp:29-
     const int it1 = prob.iter;
     prob.solve(qp);  // legacy class resets x,z,y when warm_start == false
     CHECK(prob.info().status == SOLVED && prob.iter == it1);
+    // public state of the legacy class: z and the constraint classes
+    CHECK(std::fabs(prob.z[0] - 1.0) < 1e-2 && prob.z[1] >= -1e-9 && prob.z[2] <= 0.7 + 1e-9);
+    CHECK(prob.constr_type[0] == SQPH_EQUALITY_CONSTRAINT && prob.constr_type[1] == SQPH_INEQUALITY_CONSTRAINT);
 }
 static void testBatch() {
     const int B = 256;
