@@ -240,6 +240,11 @@ def cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt):
     t0 = time.perf_counter()
     xo, yo, zo, io = oracle.solve_batch(*hs, settings=ost, nthreads=cores, dtype=ndt)
     dt = time.perf_counter() - t0
+    # one thread, for the per-core figure: a 48-QP sample
+    k1 = min(sample, 48)
+    t0 = time.perf_counter()
+    oracle.solve_batch(*[a[:k1] for a in hs], settings=ost, nthreads=1, dtype=ndt)
+    dt1 = max(time.perf_counter() - t0, 1e-9)
     xg, yg, zg, ig = solver.solution()
 
     def rel(a, b):
@@ -253,6 +258,7 @@ def cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt):
         "kind": "port",
         "sample": "first %d QPs of rank 0's batch, same settings, oracle/qp_oracle.c with OpenMP over QPs (%.1f s)" % (sample, dt),
         "admm_iters_per_sec": float(np.minimum(io["iter"], st.max_iter).sum()) / dt,
+        "single_thread_value": k1 / dt1,
         "parity_max_rel_err_x": rel(xg[:sample], xo),
         "parity_max_rel_err_y": rel(yg[:sample], yo),
         "parity_status_equal": bool((ig.status[:sample] == io["status"]).all()),
