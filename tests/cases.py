@@ -469,3 +469,52 @@ def csr_malformed(make):
     bad_rp[1], bad_rp[2] = rp[2], rp[1] - 1
     with pytest.raises(SqphError, match="row pointers"):
         s.setup_solve_csr(P, q, bad_rp, ci, v, l, u)
+
+
+def csr_edge_cases(make):
+    """unsorted rows / duplicate entries (summed) take the expand path and still match the dense oracle; an all-zero A;
+    NaN in a value marks only that QP NUMERICAL_ISSUES or NaN-propagates like the dense path"""
+    rng = np.random.default_rng(5)
+    n, m, B = 70, 150, 3
+    P, q, A, l, u = random_qp_batch(B, n, m, seed=8)
+    A = A * (rng.uniform(size=A.shape) < 0.1)
+    rp, ci, v = dense_to_csr(A)
+    # reverse the entries inside every row (unsorted) and split one entry into two duplicates
+    ci2 = np.zeros((B, ci.shape[1] + 1), np.int32)
+    v2 = np.zeros((B, v.shape[1] + 1))
+    rp2 = rp.copy()
+    for b in range(B):
+        out_c, out_v, ptr = [], [], [0]
+        for i in range(m):
+            cs = list(ci[b, rp[b, i]:rp[b, i + 1]][::-1])
+            vs = list(v[b, rp[b, i]:rp[b, i + 1]][::-1])
+            if i == 3 and cs:
+                cs.append(cs[0]); vs.append(0.25 * vs[0]); vs[0] *= 0.75
+            out_c += cs; out_v += vs; ptr.append(len(out_c))
+        ci2[b, :len(out_c)] = out_c
+        v2[b, :len(out_v)] = out_v
+        rp2[b] = ptr
+    s = make(n, m, B)
+    s.settings.max_iter, s.settings.check_termination = 40, 0
+    s.setup_solve_csr(P, q, rp2, ci2, v2, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle_settings(s.settings))
+    assert relerr(x, xo) < TOL_F64 and relerr(y, yo) < TOL_F64
+    # all-zero constraint matrix (nnz = 0)
+    s = make(n, m, B)
+    s.settings.max_iter, s.settings.check_termination = 40, 0
+    s.setup_solve_csr(P, q, np.zeros((B, m + 1), np.int32), np.zeros((B, 1), np.int32), np.zeros((B, 1)), l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, np.zeros_like(A), l, u, oracle_settings(s.settings))
+    assert relerr(x, xo) < TOL_F64 and np.allclose(y, yo, atol=1e-9)
+    # a NaN value poisons only its own QP
+    vb = v.copy()
+    vb[1, 0] = np.nan
+    s = make(n, m, B)
+    s.settings.max_iter, s.settings.check_termination = 40, 0
+    s.setup_solve_csr(P, q, rp, ci, vb, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle_settings(s.settings))
+    assert info.status[1] == NUMERICAL_ISSUES or not np.isfinite(x[1]).all()
+    for b in (0, 2):
+        assert relerr(x[b], xo[b]) < TOL_F64

@@ -99,6 +99,10 @@ def test_csr_parity(n, m, batch, density, shared, make):
     cases.csr_parity(make, n, m, batch, density=density, shared_pattern=shared, iters=50)
 
 
+def test_csr_edge_cases():
+    cases.csr_edge_cases(make_gpu)
+
+
 def test_csr_native_kernel_is_used_and_handles_termination_paths():
     from sqp_solver_amd.problems import random_csr_qp_batch
 
