@@ -105,6 +105,25 @@ struct CsrKernel {
     static __device__ __forceinline__ void stage_W(const T (&w)[NE], const T *tcol, T *st, int r, int c, int CS, int SP) {
         T tv[TT];
         wg_read<TT>(tcol + c * CS, tv);
+#ifdef SQPH_CSR_PRERED
+        // two butterfly steps over c inside the quad (DPP) before staging: 8 partials per output instead of 32
+        T acc[TT];
+#pragma unroll
+        for (int a = 0; a < TT; a++) {
+            T s = 0;
+#pragma unroll
+            for (int b = 0; b <= a; b++) s = wg_fma(w[idx(a, b)], tv[b], s);
+            acc[a] = s;
+        }
+#pragma unroll
+        for (int a = 0; a < TT; a++) acc[a] += xchg<1>(acc[a]);
+#pragma unroll
+        for (int a = 0; a < TT; a++) acc[a] += xchg<2>(acc[a]);
+        if ((c & 3) == 0) {
+#pragma unroll
+            for (int a = 0; a < TT; a++) st[(r + 32 * a) * 9 + (c >> 2)] = acc[a];
+        }
+#else
 #pragma unroll
         for (int a = 0; a < TT; a++) {
             T acc = 0;
@@ -112,6 +131,15 @@ struct CsrKernel {
             for (int b = 0; b <= a; b++) acc = wg_fma(w[idx(a, b)], tv[b], acc);
             st[(r + 32 * a) * SP + c] = acc;
         }
+#endif
+    }
+    // sum of the 8 pre-reduced partials of output j (SQPH_CSR_PRERED) by the quad 4j..4j+3
+    static __device__ __forceinline__ T quad_sum8(const T *st, int j, int ql) {
+        const T *p = st + j * 9 + 2 * ql;
+        T s = p[0] + p[1];
+        s += xchg<1>(s);
+        s += xchg<2>(s);
+        return s;
     }
     // W' y : lane (r,c) sums over its rows; partial for output column c+32b goes to st[(c+32b)*SP + r]
     static __device__ __forceinline__ void stage_WT(const T (&w)[NE], const T *yrow, T *st, int r, int c, int CS, int SP) {
@@ -666,7 +694,11 @@ struct CsrKernel {
                 {   // y1 = W t, published in row-gather order
                     SQPH_LANE(tl);
                     const int jn = tl >> 2, ql = tl & 3;
+#ifdef SQPH_CSR_PRERED
+                    const T y1 = quad_sum8(st, jn < L.NP ? jn : 0, ql);
+#else
                     const T y1 = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
+#endif
                     if (ql == 0 && jn < L.NP) yrow[(jn & 31) * CS + (jn >> 5)] = jn < n ? y1 : T(0);
                 }
                 __syncthreads();

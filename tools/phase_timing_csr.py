@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sqp_solver_amd import build as b
 b.FLAGS.append("-DSQPH_PHASE_TIMING")
+for f in os.environ.get("SQPH_EXTRA_FLAGS", "").split():
+    b.FLAGS.append(f)
 b.LIB = b.LIB.replace("libsqp_hip.so", "libsqp_hip_timing.so")
 subprocess.check_call([b.HIPCC] + b.FLAGS + ["-o", b.LIB, os.path.join(b.CSRC, "capi.hip")])
 from sqp_solver_amd import QPSolverBatch
