@@ -240,6 +240,101 @@ struct CsrKernel {
         return s;
     }
 
+    // ---- the same products with a lane's first KA entries held in registers (values + packed 16-bit indices): one LDS
+    // instruction per entry (the gather) instead of three.  The LDS pipeline of the CU serves all 16 waves, and the sparse
+    // phases are bound by its instruction rate, not by latency.
+    static constexpr int KA = 6;
+    struct ARegs {
+        T rv[KA], cv[KA];          // CSR values of my row slice, CSC values of my column slice (0 = padding)
+        unsigned rc[KA / 2], cr[KA / 2];  // their column / row indices, two per word
+        bool rovf, covf;           // my slice is longer than KA entries: the rest is fetched from LDS
+    };
+    static __device__ __forceinline__ void load_aregs(const int *rowptr, const unsigned short *col, const int *colptr, const unsigned *csc,
+                                                      const T *val, int n, int m, int t, ARegs &A) {
+        const int im = t >> 1, pl = t & 1, jn = t >> 2, ql = t & 3;
+        {
+            const bool act = im < m;
+            const int e1 = act ? rowptr[im + 1] : 0;
+            const int e0 = act ? rowptr[im] + pl : 0;
+            const int last = e1 > 0 ? e1 - 1 : 0;
+            unsigned cc[KA];
+#pragma unroll
+            for (int k = 0; k < KA; k++) {
+                const int e = e0 + 2 * k;
+                const bool ok = e < e1;
+                const int ee = ok ? e : last;
+                const T vv = val[ee];
+                const unsigned c_ = col[ee];
+                A.rv[k] = ok ? vv : T(0);
+                cc[k] = ok ? c_ : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < KA / 2; k++) A.rc[k] = cc[2 * k] | (cc[2 * k + 1] << 16);
+            A.rovf = e0 + 2 * KA < e1;
+        }
+        {
+            const bool act = jn < n;
+            const int e1 = act ? colptr[jn + 1] : 0;
+            const int e0 = act ? colptr[jn] + ql : 0;
+            const int last = e1 > 0 ? e1 - 1 : 0;
+            unsigned rr[KA];
+#pragma unroll
+            for (int k = 0; k < KA; k++) {
+                const int e = e0 + 4 * k;
+                const bool ok = e < e1;
+                const unsigned pk = csc[ok ? e : last];
+                const T vv = val[pk & 0xffffu];
+                A.cv[k] = ok ? vv : T(0);
+                rr[k] = ok ? (pk >> 16) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < KA / 2; k++) A.cr[k] = rr[2 * k] | (rr[2 * k + 1] << 16);
+            A.covf = e0 + 4 * KA < e1;
+        }
+    }
+    static __device__ __forceinline__ T csr_row_dot_r(const ARegs &A, const int *rowptr, const unsigned short *col, const T *val, const T *v,
+                                                      int i, int pl) {
+        T xx[KA];
+#pragma unroll
+        for (int k = 0; k < KA; k++) xx[k] = v[(A.rc[k / 2] >> (16 * (k & 1))) & 0xffffu];
+        T a0 = 0, a1 = 0;
+#pragma unroll
+        for (int k = 0; k < KA; k++) {
+            if (k & 1) a1 = wg_fma(A.rv[k], xx[k], a1);
+            else a0 = wg_fma(A.rv[k], xx[k], a0);
+        }
+        if (A.rovf) {
+            const int e1 = rowptr[i + 1];
+            for (int e = rowptr[i] + pl + 2 * KA; e < e1; e += 2) a0 = wg_fma(val[e], v[col[e]], a0);
+        }
+        T s = a0 + a1;
+        s += xchg<1>(s);
+        return s;
+    }
+    static __device__ __forceinline__ T csc_col_dot_r(const ARegs &A, const int *colptr, const unsigned *csc, const T *val, const T *v, int j,
+                                                      int ql) {
+        T xx[KA];
+#pragma unroll
+        for (int k = 0; k < KA; k++) xx[k] = v[(A.cr[k / 2] >> (16 * (k & 1))) & 0xffffu];
+        T a0 = 0, a1 = 0;
+#pragma unroll
+        for (int k = 0; k < KA; k++) {
+            if (k & 1) a1 = wg_fma(A.cv[k], xx[k], a1);
+            else a0 = wg_fma(A.cv[k], xx[k], a0);
+        }
+        if (A.covf) {
+            const int e1 = colptr[j + 1];
+            for (int e = colptr[j] + ql + 4 * KA; e < e1; e += 4) {
+                const unsigned p0 = csc[e];
+                a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
+            }
+        }
+        T s = a0 + a1;
+        s += xchg<1>(s);
+        s += xchg<2>(s);
+        return s;
+    }
+
     // ---------------------------------------------------------------- set-up
     // CSR of this QP -> LDS, CSC index by counting sort (entries of a column ordered by row: deterministic sums)
     static __device__ __forceinline__ void load_sparse(const CsrArgs<TIN> &ca, int qp, int n, int m, const CsrLayout<TT> &L, unsigned char *smem) {
@@ -706,6 +801,12 @@ struct CsrKernel {
                 const int im = t >> 1;
                 if (im < m && (t & 1) == 0) wv[im] = rho * (z - rinvv[im] * y);
             }
+            // my slices of A, in registers for the iteration loop only (dead while a factor is built or a check runs)
+            ARegs AR;
+            {
+                SQPH_LANE(t);
+                load_aregs(rowptr, col, colptr, csc, val, n, m, t, AR);
+            }
             SQPH_CTICK(10)
             for (; iter <= a.max_iter; iter++) {
                 __syncthreads();
@@ -716,7 +817,7 @@ struct CsrKernel {
                     SQPH_LANE(tl);
                     const int jn = tl >> 2, ql = tl & 3;
                     const bool nown = jn < n;
-                    const T s = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
+                    const T s = csc_col_dot_r(AR, colptr, csc, val, wv, jn < n ? jn : 0, ql);
                     if (ql == 0 && jn < L.NP) tcol[(jn & 31) * CS + (jn >> 5)] = nown ? (sigma * x - qv[jn]) + s : T(0);
                 }
                 __syncthreads();
@@ -759,7 +860,7 @@ struct CsrKernel {
                     SQPH_LANE(tl);
                     const int im = tl >> 1, pl = tl & 1;
                     const bool mown = im < m;
-                    const T zt = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
+                    const T zt = csr_row_dot_r(AR, rowptr, col, val, xt, mown ? im : 0, pl);
                     if (mown) {
                         const T zr = alpha * zt + oma * z;
                         T zn = zr + rinvv[im] * y;
@@ -864,6 +965,7 @@ struct CsrKernel {
                     }
                     __syncthreads();
                     if (mown && pl == 0) wv[im] = rho * (z - rinvv[im] * y);  // the check borrowed wv for y
+                    load_aregs(rowptr, col, colptr, csc, val, n, m, tl, AR);
                 }
             }
             if (!need_factor) break;
