@@ -245,33 +245,14 @@ struct CsrKernel {
     // phases are bound by its instruction rate, not by latency.
     static constexpr int KA = 6;
     struct ARegs {
-        T rv[KA], cv[KA];          // CSR values of my row slice, CSC values of my column slice (0 = padding)
-        unsigned rc[KA / 2], cr[KA / 2];  // their column / row indices, two per word
-        bool rovf, covf;           // my slice is longer than KA entries: the rest is fetched from LDS
+        T cv[KA];          // CSC values of my column slice (0 = padding)
+        unsigned cr[KA / 2];  // their row indices, two per word
+        bool covf;         // my slice is longer than KA entries: the rest is fetched from LDS
+        // (the CSR slice stays in LDS: holding both in registers pushed the tile into scratch — measured)
     };
     static __device__ __forceinline__ void load_aregs(const int *rowptr, const unsigned short *col, const int *colptr, const unsigned *csc,
                                                       const T *val, int n, int m, int t, ARegs &A) {
-        const int im = t >> 1, pl = t & 1, jn = t >> 2, ql = t & 3;
-        {
-            const bool act = im < m;
-            const int e1 = act ? rowptr[im + 1] : 0;
-            const int e0 = act ? rowptr[im] + pl : 0;
-            const int last = e1 > 0 ? e1 - 1 : 0;
-            unsigned cc[KA];
-#pragma unroll
-            for (int k = 0; k < KA; k++) {
-                const int e = e0 + 2 * k;
-                const bool ok = e < e1;
-                const int ee = ok ? e : last;
-                const T vv = val[ee];
-                const unsigned c_ = col[ee];
-                A.rv[k] = ok ? vv : T(0);
-                cc[k] = ok ? c_ : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < KA / 2; k++) A.rc[k] = cc[2 * k] | (cc[2 * k + 1] << 16);
-            A.rovf = e0 + 2 * KA < e1;
-        }
+        const int jn = t >> 2, ql = t & 3;
         {
             const bool act = jn < n;
             const int e1 = act ? colptr[jn + 1] : 0;
@@ -291,25 +272,6 @@ struct CsrKernel {
             for (int k = 0; k < KA / 2; k++) A.cr[k] = rr[2 * k] | (rr[2 * k + 1] << 16);
             A.covf = e0 + 4 * KA < e1;
         }
-    }
-    static __device__ __forceinline__ T csr_row_dot_r(const ARegs &A, const int *rowptr, const unsigned short *col, const T *val, const T *v,
-                                                      int i, int pl) {
-        T xx[KA];
-#pragma unroll
-        for (int k = 0; k < KA; k++) xx[k] = v[(A.rc[k / 2] >> (16 * (k & 1))) & 0xffffu];
-        T a0 = 0, a1 = 0;
-#pragma unroll
-        for (int k = 0; k < KA; k++) {
-            if (k & 1) a1 = wg_fma(A.rv[k], xx[k], a1);
-            else a0 = wg_fma(A.rv[k], xx[k], a0);
-        }
-        if (A.rovf) {
-            const int e1 = rowptr[i + 1];
-            for (int e = rowptr[i] + pl + 2 * KA; e < e1; e += 2) a0 = wg_fma(val[e], v[col[e]], a0);
-        }
-        T s = a0 + a1;
-        s += xchg<1>(s);
-        return s;
     }
     static __device__ __forceinline__ T csc_col_dot_r(const ARegs &A, const int *colptr, const unsigned *csc, const T *val, const T *v, int j,
                                                       int ql) {
@@ -860,7 +822,7 @@ struct CsrKernel {
                     SQPH_LANE(tl);
                     const int im = tl >> 1, pl = tl & 1;
                     const bool mown = im < m;
-                    const T zt = csr_row_dot_r(AR, rowptr, col, val, xt, mown ? im : 0, pl);
+                    const T zt = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
                     if (mown) {
                         const T zr = alpha * zt + oma * z;
                         T zn = zr + rinvv[im] * y;
