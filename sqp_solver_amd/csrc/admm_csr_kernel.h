@@ -165,38 +165,19 @@ struct CsrKernel {
 
     // ---------------------------------------------------------------- sparse products (matrices in LDS)
     // (A v)_i by the lane pair 2i, 2i+1; v plain-indexed in LDS.  Every lane of the wave must call this.
-    // The first KU entries of a lane are fetched with clamped indices and masked values so that all index loads, then
-    // all gathers, are in flight together (two LDS round trips per row instead of two per entry); longer rows loop.
+    // (A deeper unroll with all index loads, then all gathers in flight measured no faster — the phase is bound by the
+    // LDS instruction rate of the CU, not by latency — and its temporaries push the tile into scratch.)
     static __device__ __forceinline__ T csr_row_dot(const int *rowptr, const unsigned short *col, const T *val, const T *v, int i,
                                                     int pl, bool active) {
-        constexpr int KU = 6;
         T a0 = 0, a1 = 0;
         if (active) {
             const int e1 = rowptr[i + 1];
-            const int e0 = rowptr[i] + pl;
-            const int last = e1 > 0 ? e1 - 1 : 0;
-            int ee[KU];
-            unsigned cc[KU];
-            T vv[KU], xx[KU];
-#pragma unroll
-            for (int k = 0; k < KU; k++) {
-                const int e = e0 + 2 * k;
-                ee[k] = e < e1 ? e : last;
+            int e = rowptr[i] + pl;
+            for (; e + 2 < e1; e += 4) {
+                a0 = wg_fma(val[e], v[col[e]], a0);
+                a1 = wg_fma(val[e + 2], v[col[e + 2]], a1);
             }
-#pragma unroll
-            for (int k = 0; k < KU; k++) {
-                cc[k] = col[ee[k]];
-                vv[k] = val[ee[k]];
-            }
-#pragma unroll
-            for (int k = 0; k < KU; k++) xx[k] = v[cc[k]];
-#pragma unroll
-            for (int k = 0; k < KU; k++) {
-                const T vk = (e0 + 2 * k < e1) ? vv[k] : T(0);
-                if (k & 1) a1 = wg_fma(vk, xx[k], a1);
-                else a0 = wg_fma(vk, xx[k], a0);
-            }
-            for (int e = e0 + 2 * KU; e < e1; e += 2) a0 = wg_fma(val[e], v[col[e]], a0);
+            if (e < e1) a0 = wg_fma(val[e], v[col[e]], a0);
         }
         T s = a0 + a1;
         s += xchg<1>(s);
