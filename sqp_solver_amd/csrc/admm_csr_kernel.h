@@ -165,8 +165,10 @@ struct CsrKernel {
 
     // ---------------------------------------------------------------- sparse products (matrices in LDS)
     // (A v)_i by the lane pair 2i, 2i+1; v plain-indexed in LDS.  Every lane of the wave must call this.
-    // (A deeper unroll with all index loads, then all gathers in flight measured no faster — the phase is bound by the
-    // LDS instruction rate of the CU, not by latency — and its temporaries push the tile into scratch.)
+    // Measured dead ends (tools/phase_timing_csr.py, config 5): fetching six entries per lane with all index loads, then
+    // all gathers in flight is no faster — the sparse phases are bound by the LDS instruction rate of the CU (16 waves
+    // share one LDS pipeline), not by latency; holding a lane's CSC slice (values + packed indices) in registers takes
+    // 1.0 k cycles off the A'w phase but pushes tile entries into scratch, which costs the same elsewhere.
     static __device__ __forceinline__ T csr_row_dot(const int *rowptr, const unsigned short *col, const T *val, const T *v, int i,
                                                     int pl, bool active) {
         T a0 = 0, a1 = 0;
@@ -186,88 +188,16 @@ struct CsrKernel {
     // (A' v)_j by the lane quad 4j..4j+3; v plain-indexed in LDS.  Every lane of the wave must call this.
     static __device__ __forceinline__ T csc_col_dot(const int *colptr, const unsigned *csc, const T *val, const T *v, int j, int ql,
                                                     bool active) {
-        constexpr int KU = 6;
         T a0 = 0, a1 = 0;
         if (active) {
             const int e1 = colptr[j + 1];
-            const int e0 = colptr[j] + ql;
-            const int last = e1 > 0 ? e1 - 1 : 0;
-            unsigned pk[KU];
-            T vv[KU], xx[KU];
-#pragma unroll
-            for (int k = 0; k < KU; k++) {
-                const int e = e0 + 4 * k;
-                pk[k] = csc[e < e1 ? e : last];
-            }
-#pragma unroll
-            for (int k = 0; k < KU; k++) {
-                vv[k] = val[pk[k] & 0xffffu];
-                xx[k] = v[pk[k] >> 16];
-            }
-#pragma unroll
-            for (int k = 0; k < KU; k++) {
-                const T vk = (e0 + 4 * k < e1) ? vv[k] : T(0);
-                if (k & 1) a1 = wg_fma(vk, xx[k], a1);
-                else a0 = wg_fma(vk, xx[k], a0);
-            }
-            for (int e = e0 + 4 * KU; e < e1; e += 4) {
-                const unsigned p0 = csc[e];
+            int e = colptr[j] + ql;
+            for (; e + 4 < e1; e += 8) {
+                const unsigned p0 = csc[e], p1 = csc[e + 4];
                 a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
+                a1 = wg_fma(val[p1 & 0xffffu], v[p1 >> 16], a1);
             }
-        }
-        T s = a0 + a1;
-        s += xchg<1>(s);
-        s += xchg<2>(s);
-        return s;
-    }
-
-    // ---- the same products with a lane's first KA entries held in registers (values + packed 16-bit indices): one LDS
-    // instruction per entry (the gather) instead of three.  The LDS pipeline of the CU serves all 16 waves, and the sparse
-    // phases are bound by its instruction rate, not by latency.
-    static constexpr int KA = 6;
-    struct ARegs {
-        T cv[KA];          // CSC values of my column slice (0 = padding)
-        unsigned cr[KA / 2];  // their row indices, two per word
-        bool covf;         // my slice is longer than KA entries: the rest is fetched from LDS
-        // (the CSR slice stays in LDS: holding both in registers pushed the tile into scratch — measured)
-    };
-    static __device__ __forceinline__ void load_aregs(const int *rowptr, const unsigned short *col, const int *colptr, const unsigned *csc,
-                                                      const T *val, int n, int m, int t, ARegs &A) {
-        const int jn = t >> 2, ql = t & 3;
-        {
-            const bool act = jn < n;
-            const int e1 = act ? colptr[jn + 1] : 0;
-            const int e0 = act ? colptr[jn] + ql : 0;
-            const int last = e1 > 0 ? e1 - 1 : 0;
-            unsigned rr[KA];
-#pragma unroll
-            for (int k = 0; k < KA; k++) {
-                const int e = e0 + 4 * k;
-                const bool ok = e < e1;
-                const unsigned pk = csc[ok ? e : last];
-                const T vv = val[pk & 0xffffu];
-                A.cv[k] = ok ? vv : T(0);
-                rr[k] = ok ? (pk >> 16) : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < KA / 2; k++) A.cr[k] = rr[2 * k] | (rr[2 * k + 1] << 16);
-            A.covf = e0 + 4 * KA < e1;
-        }
-    }
-    static __device__ __forceinline__ T csc_col_dot_r(const ARegs &A, const int *colptr, const unsigned *csc, const T *val, const T *v, int j,
-                                                      int ql) {
-        T xx[KA];
-#pragma unroll
-        for (int k = 0; k < KA; k++) xx[k] = v[(A.cr[k / 2] >> (16 * (k & 1))) & 0xffffu];
-        T a0 = 0, a1 = 0;
-#pragma unroll
-        for (int k = 0; k < KA; k++) {
-            if (k & 1) a1 = wg_fma(A.cv[k], xx[k], a1);
-            else a0 = wg_fma(A.cv[k], xx[k], a0);
-        }
-        if (A.covf) {
-            const int e1 = colptr[j + 1];
-            for (int e = colptr[j] + ql + 4 * KA; e < e1; e += 4) {
+            if (e < e1) {
                 const unsigned p0 = csc[e];
                 a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
             }
@@ -744,12 +674,6 @@ struct CsrKernel {
                 const int im = t >> 1;
                 if (im < m && (t & 1) == 0) wv[im] = rho * (z - rinvv[im] * y);
             }
-            // my slices of A, in registers for the iteration loop only (dead while a factor is built or a check runs)
-            ARegs AR;
-            {
-                SQPH_LANE(t);
-                load_aregs(rowptr, col, colptr, csc, val, n, m, t, AR);
-            }
             SQPH_CTICK(10)
             for (; iter <= a.max_iter; iter++) {
                 __syncthreads();
@@ -760,7 +684,7 @@ struct CsrKernel {
                     SQPH_LANE(tl);
                     const int jn = tl >> 2, ql = tl & 3;
                     const bool nown = jn < n;
-                    const T s = csc_col_dot_r(AR, colptr, csc, val, wv, jn < n ? jn : 0, ql);
+                    const T s = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
                     if (ql == 0 && jn < L.NP) tcol[(jn & 31) * CS + (jn >> 5)] = nown ? (sigma * x - qv[jn]) + s : T(0);
                 }
                 __syncthreads();
@@ -908,7 +832,6 @@ struct CsrKernel {
                     }
                     __syncthreads();
                     if (mown && pl == 0) wv[im] = rho * (z - rinvv[im] * y);  // the check borrowed wv for y
-                    load_aregs(rowptr, col, colptr, csc, val, n, m, tl, AR);
                 }
             }
             if (!need_factor) break;
