@@ -30,6 +30,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+                    help="c3 (default): BASELINE configs[2] shard 8192 x (50,100); c2: configs[1] 4096 x (20,40); "
+                         "c5: configs[4] 8192 x (200,400) with a 5 %% dense CSR A")
     ap.add_argument("--n", type=int, default=50)
     ap.add_argument("--m", type=int, default=100)
     ap.add_argument("--batch-per-gpu", type=int, default=8192)
@@ -67,12 +70,25 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "c2":
+        args.n, args.m, args.batch_per_gpu = 20, 40, 4096
+    elif args.workload == "c5":
+        args.n, args.m = 200, 400
     n, m, B = args.n, args.m, args.batch_per_gpu
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     ndt = np.float64 if args.dtype == "f64" else np.float32
 
     # synthetic, device-resident, per-QP column-major (the C-ABI layout); rank-dependent seed
-    P, q, A_cm, l, u = random_qp_batch_torch(B, n, m, seed=20250228 + 3 + 1000 * rank, dtype=tdt, device=dev)
+    csr = None
+    if args.workload == "c5":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_csr
+
+        P, q, rp, ci, v, l, u, A_dense, nnz_avg = bench_csr.make(B, n, m, 0.05, 20250228 + 5 + 1000 * rank, dev)
+        csr = (rp, ci, v)
+        A_cm = None
+    else:
+        P, q, A_cm, l, u = random_qp_batch_torch(B, n, m, seed=20250228 + 3 + 1000 * rank, dtype=tdt, device=dev)
     torch.cuda.synchronize()
 
     solver = QPSolverBatch(n, m, B, dtype=ndt, device=local_rank, force_generic=args.force_generic)
@@ -86,7 +102,10 @@ def main():
     xp, yp, zp, ip = solver.device_state_ptrs()
 
     def step():
-        solver.setup_solve(P, q, A_cm, l, u, colmajor=True)
+        if csr is not None:
+            solver.setup_solve_csr(P, q, csr[0], csr[1], csr[2], l, u)
+        else:
+            solver.setup_solve(P, q, A_cm, l, u, colmajor=True)
 
     gather_bufs = None
     if use_dist and not args.no_gather:
@@ -143,9 +162,14 @@ def main():
     out = None
     if rank == 0:
         bytes_per_qp = solver.algorithmic_bytes_per_qp()
+        flops_per_iter = 2.0 * (2 * m * n + n * n)  # Schur-ordered iteration (SURVEY §8(d))
+        if csr is not None:
+            # CSR A: 8(n^2 + n + 2m) + 12 nnz + 4(m+1) read, 8(n+m) + 40 written
+            bytes_per_qp = int(8 * (n * n + n + 2 * m) + 12 * nnz_avg + 4 * (m + 1) + 8 * (n + m) + 40)
+            flops_per_iter = 2.0 * (2 * nnz_avg + n * n)
+            kernel_ms = kernel_ms[-args.steps:]  # one solver launch per step (the structural pre-check is not an event pair)
         avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = bytes_per_qp * B / (avg_kernel_ms * 1e-3) / 1e9
-        flops_per_iter = 2.0 * (2 * m * n + n * n)  # Schur-ordered iteration (SURVEY §8(d))
         iters_per_qp = iters_local / B
         out = {
             "metric": "qp_solves_per_sec",
@@ -161,8 +185,9 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2] shard: %d dense QPs n=%d m=%d per GPU (%d total), %s" % (
-                    B, n, m, B * world,
+                "workload": "%s: %d %s QPs n=%d m=%d per GPU (%d total), %s" % (
+                    {"c3": "BASELINE configs[2] shard", "c2": "BASELINE configs[1]", "c5": "BASELINE configs[4]"}[args.workload],
+                    B, "CSR-A (5 % dense)" if csr is not None else "dense", n, m, B * world,
                     ("fixed %d ADMM iterations (check_termination=0)" % args.iters) if args.mode == "fixed"
                     else "reference default settings (eps 1e-3, check 25, max_iter 1000)"),
                 "n": n, "m": m, "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
@@ -186,7 +211,12 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt)
+            if csr is not None:
+                k = min(B, 512)  # the oracle factors a dense 600 x 600 KKT matrix per QP
+                A_cm = A_dense[:k].transpose(1, 2).contiguous()
+                out["cpu_baseline"] = cpu_baseline(args, solver, P[:k], q[:k], A_cm, l[:k], u[:k], st, ndt)
+            else:
+                out["cpu_baseline"] = cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt)
         print(json.dumps(out), flush=True)
     if use_dist:
         if gather_bufs is not None and rank == 0:
