@@ -24,6 +24,22 @@ inline int tile_try_launch(const KArgs<T, TIN> &a, hipStream_t stream, const cha
     return 0;
 }
 
+// four-QPs-per-wavefront kernels for small shapes (admm_wg_kernel.h, run_group): >0 launched, 0 not covered, <0 error
+template <typename TIN>
+inline int g16_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
+    static const bool off = getenv("SQPH_NO_G16") != nullptr;  // experiments only
+    if (off) return 0;
+#define SQPH_G16_CASE(TR_, TC_, W_)                                                                                            \
+    if (a.m <= 4 * TR_ && a.n <= 4 * TC_) {                                                                                    \
+        hipLaunchKernelGGL((admm_g16_kernel<TIN, TR_, TC_, W_>), dim3((a.batch + 3) / 4), dim3(64), 0, stream, a);             \
+        *name = "g16_" #TR_ "x" #TC_ "_w" #W_;                                                                                 \
+        return hipGetLastError() == hipSuccess ? 1 : -1;                                                                       \
+    }
+    SQPH_G16_SHAPES(SQPH_G16_CASE)
+#undef SQPH_G16_CASE
+    return 0;
+}
+
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>
 inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {

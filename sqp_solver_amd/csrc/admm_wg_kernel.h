@@ -76,12 +76,14 @@ __device__ __forceinline__ double wg_sum(const double *p) {
 
 template <int NW, int R, int C, int TR, int TC, int TW>
 struct WgLayout {
-    static_assert(R * C == 64 * NW, "lane grid must cover the workgroup");
-    static constexpr int NT = 64 * NW;
+    // NW >= 1: the R x C lane grid is a workgroup of NW wavefronts.  NW == 0: a 4 x 4 grid of 16 lanes — four
+    // independent QPs share one wavefront (small problems), see run_group().
+    static_assert(NW == 0 ? R * C == 16 : R * C == 64 * NW, "lane grid must cover the workgroup");
+    static constexpr int NT = R * C;
     static constexpr int MP = R * TR;  // padded m
     static constexpr int NP = C * TC;  // padded n (columns)
     static constexpr int NR = R * TW;  // padded n (rows of W)
-    static_assert(NP <= NT && NR >= NP && NR <= NT && MP <= NT, "owners: lane t owns n-element t and m-element t");
+    static_assert(NW == 0 || (NP <= NT && NR >= NP && NR <= NT && MP <= NT), "owners: lane t owns n-element t and m-element t");
     static constexpr int ev(int x) { return (x + 1) & ~1; }
     static constexpr int TRp = ev(TR) + 2;  // row-gather stride per r    (w, y)
     static constexpr int TWp = ev(TW) + 2;  // W-row gather stride per r  (y1)
@@ -127,6 +129,22 @@ struct WgKernel {
     using T = double;
     using L = WgLayout<NW, R, C, TR, TC, TW>;
     static constexpr int NT = L::NT;
+
+    // barrier of the lanes that work on one QP: the workgroup, or (NW == 0) a 16-lane group of a wavefront, whose LDS
+    // operations execute in program order anyway — only the compiler has to be kept from reordering them
+    static __device__ __forceinline__ void wsync() {
+        if constexpr (NW > 0) {
+            __syncthreads();
+        } else {
+#ifdef SQPH_SIM
+            ::sqph_sim::group16_sync();
+#else
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+        }
+    }
 
     // ------------------------------------------------------------------ gathers (operand from LDS)
     static __device__ __forceinline__ void put_rowv(T *lds, int r, int c, T v) { lds[L::O_ROWV + r * L::TRp + c] = v; }
@@ -240,7 +258,7 @@ struct WgKernel {
         const int myhalf = c / L::CH, cl = c - myhalf * L::CH;  // my column group inside its half
 #pragma unroll
         for (int s = 0; s < TR; s++) {
-            __syncthreads();
+            wsync();
 #pragma unroll
             for (int k = 0; k < TC; k++) As[r * L::SSTR + 8 * c + k] = at[s][k];
             T acc[TC];
@@ -248,7 +266,7 @@ struct WgKernel {
             for (int k = 0; k < TC; k++) acc[k] = 0;
 #pragma unroll 1
             for (int half = 0; half < 2; half++) {
-                __syncthreads();
+                wsync();
                 // Wl[jl][slot(i')] = W[i'][CH*TC*half + jl] from the lanes whose columns lie in this half
                 if (myhalf == half) {
 #pragma unroll
@@ -260,7 +278,7 @@ struct WgKernel {
                         }
                     }
                 }
-                __syncthreads();
+                wsync();
                 // W[TC c + k][j] = 0 for j > TC c + k: column groups beyond my own contribute nothing
                 const int cj0 = L::CH * half;
                 int cj1 = cj0 + L::CH - 1;
@@ -283,7 +301,7 @@ struct WgKernel {
 #pragma unroll
             for (int k = 0; k < TC; k++) at[s][k] = acc[k];
         }
-        __syncthreads();
+        wsync();
     }
     // residual check only: A x partials (staged for the reduction over c) and A' y partials (over r), with
     // the A tile streamed column by column from global memory.  The column loop is deliberately NOT
@@ -364,10 +382,10 @@ struct WgKernel {
         for (int u = 0; u < TW; u++) sl[u] = L::slot(ir[u]);
 #pragma unroll
         for (int s = 0; s < TR; s++) {
-            __syncthreads();
+            wsync();
 #pragma unroll
             for (int k = 0; k < TC; k++) As[r * L::SSTR + 8 * c + k] = at[s][k];
-            __syncthreads();
+            wsync();
 #pragma unroll 2
             for (int il = 0; il < R; il++) {
                 const int i = R * s + il;
@@ -384,12 +402,12 @@ struct WgKernel {
                     for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
             }
         }
-        __syncthreads();
+        wsync();
         for (int e = t; e < L::NP + 2; e += NT) {
             rowbuf[e] = 0;
             if (e < L::NP) sjv[e] = T(1);
         }
-        __syncthreads();
+        wsync();
 #pragma unroll
         for (int u = 0; u < TW; u++) {
             const int i = R * u + r;
@@ -404,17 +422,17 @@ struct WgKernel {
                 if (ok && i == j) sjv[j] = wt[u][k];  // the diagonal, for the Jacobi scaling
             }
         }
-        __syncthreads();
+        wsync();
         // non-positive / non-finite diagonal => not SPD (block-uniform decision through LDS)
         bool bad = false;
         for (int j = 0; j < n; j++) {
             const T d = sjv[j];
             bad = bad || !(d > T(0)) || !(d * T(0) == T(0));
         }
-        __syncthreads();
+        wsync();
         if (bad) return false;
-        if (t < n) sjv[t] = T(1) / (T)sqrt((double)sjv[t]);
-        __syncthreads();
+        for (int e = t; e < n; e += NT) sjv[e] = T(1) / (T)sqrt((double)sjv[e]);
+        wsync();
         T srow[TW], scol[TC];
 #pragma unroll
         for (int u = 0; u < TW; u++) srow[u] = sjv[ir[u]];
@@ -439,7 +457,7 @@ struct WgKernel {
 #pragma unroll
                     for (int q = 0; q < TC; q++) rowbuf[TC * c + q] = wt[u][q];
                 }
-                __syncthreads();
+                wsync();
                 const T d = rowbuf[k];
                 if (!(d > T(0)) || !(d * T(0) == T(0))) {
                     ok_all = false;
@@ -458,7 +476,7 @@ struct WgKernel {
                     const T gi = rowbuf[i < L::NP ? i : 0];
                     f[v] = (i > k && i < n) ? gi * dinv : T(0);
                 }
-                __syncthreads();
+                wsync();
 #pragma unroll
                 for (int v = 0; v < TW; v++)
 #pragma unroll
@@ -799,6 +817,374 @@ struct WgKernel {
             a.rho[qp] = rho_s;
         }
     }
+
+    // ------------------------------------------------------------------ NW == 0: four QPs per wavefront
+    // Small problems (n <= 4 TC <= 24, m <= 4 TR <= 48): a 16-lane 4 x 4 grid per QP, four independent QPs in one
+    // wavefront (threadIdx.x >> 4 selects the QP and its LDS slice).  Same tiles, staging and formulas as run(); no
+    // s_barrier anywhere (wsync() is a compiler fence), a lane owns the elements t, t+16, t+32 of the n- and m-vectors,
+    // the four groups diverge freely (different iteration counts, refactorisations).
+    static constexpr int NON = (L::NP + 15) / 16, NOM = (L::MP + 15) / 16;
+    static __device__ __forceinline__ int rowv_at(int i) { return L::O_ROWV + (i % R) * L::TRp + i / R; }
+    static __device__ __forceinline__ int wrow_at(int i) { return L::O_WROW + (i % R) * L::TWp + i / R; }
+
+    static __device__ void run_group(const KArgs<T, TIN> &a, T *lds_block) {
+        static_assert(NW == 0, "group kernel");
+        const int t = threadIdx.x & 15;
+        const int slot = threadIdx.x >> 4;
+        const int r = t % R, c = t / R;
+        const int qp = blockIdx.x * 4 + slot;
+        if (qp >= a.batch) return;  // a whole group leaves: nobody waits for it
+        T *lds = lds_block + slot * L::TOTAL;
+        const int n = a.n, m = a.m;
+        // per-QP pointers are lane-varying here (four QPs per wave): derived where they are used instead of being kept
+        // in 22 VGPRs for the whole solve
+#define SQPH_GP (a.P + (long)qp * a.sP)
+#define SQPH_GA (a.A + (long)qp * a.sA)
+#define SQPH_GW (a.Sinv + (long)qp * 2 * n * n)
+        T *sx = a.x + (long)qp * n;
+        T *sz = a.z + (long)qp * m;
+        T *sy = a.y + (long)qp * m;
+        T *srho = a.rho_vec + (long)qp * m;
+        int *sct = a.ctype + (long)qp * m;
+
+        sqph_info info = a.info[qp];
+        T rho_s = a.rho[qp];
+        const int mode = a.mode;
+        if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
+            return;  // qp.cpp:68-71
+
+        const T INF = T(1) / T(0);
+        T *qv = lds + L::O_QV, *lov = lds + L::O_LOV, *upv = lds + L::O_UPV, *rinvv = lds + L::O_RINV;
+#pragma unroll
+        for (int k = 0; k < NON; k++) {
+            const int j = t + 16 * k;
+            if (j < L::NP) qv[j] = j < n ? (T)(a.q + (long)qp * a.sq)[j] : T(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NOM; k++) {
+            const int i = t + 16 * k;
+            if (i < L::MP) {
+                lov[i] = i < m ? (T)(a.l + (long)qp * a.sl)[i] : -INF;
+                upv[i] = i < m ? (T)(a.u + (long)qp * a.su)[i] : INF;
+                rinvv[i] = T(1);
+            }
+        }
+        wsync();
+        T x[NON], z[NOM], y[NOM], rho[NOM];
+#pragma unroll
+        for (int k = 0; k < NON; k++) x[k] = 0;
+#pragma unroll
+        for (int k = 0; k < NOM; k++) {
+            z[k] = 0;
+            y[k] = 0;
+            rho[k] = T(1);
+        }
+        if (mode & (MODE_SETUP | MODE_UPDATE)) {
+            rho_s = a.rho0;
+#pragma unroll
+            for (int k = 0; k < NOM; k++) {
+                const int i = t + 16 * k;
+                if (i < m) {
+                    const T lo = lov[i], up = upv[i];
+                    int ctype = SQPH_INEQUALITY_CONSTRAINT;
+                    if (lo < -a.loose_thresh && up > a.loose_thresh)
+                        ctype = SQPH_LOOSE_BOUNDS;
+                    else if (up - lo < a.eq_tol)
+                        ctype = SQPH_EQUALITY_CONSTRAINT;
+                    rho[k] = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
+                    rinvv[i] = T(1) / rho[k];
+                    sct[i] = ctype;
+                    srho[i] = rho[k];
+                }
+            }
+            info.rho_updates += 1;
+        }
+        if (!(mode & MODE_SETUP)) {
+#pragma unroll
+            for (int k = 0; k < NON; k++) {
+                const int j = t + 16 * k;
+                if (j < n) x[k] = sx[j];
+            }
+#pragma unroll
+            for (int k = 0; k < NOM; k++) {
+                const int i = t + 16 * k;
+                if (i < m) {
+                    z[k] = sz[i];
+                    y[k] = sy[i];
+                    if (!(mode & MODE_UPDATE)) {
+                        rho[k] = srho[i];
+                        rinvv[i] = T(1) / rho[k];
+                    }
+                }
+            }
+        }
+
+        T wt[TW][TC];
+        T at[TR][TC];
+        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
+        bool solving = false;
+        bool state_dirty = (mode & MODE_SETUP) != 0;
+        bool have_A = false;
+        if (!need_factor) load_sq_tile<T>(SQPH_GW, n, r, c, wt);
+        const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
+        int iter = 1;
+        int next_check = a.check_termination > 0 ? a.check_termination : -1;
+        int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
+        for (;;) {
+            if (need_factor) {
+                wsync();
+#pragma unroll
+                for (int k = 0; k < NOM; k++) {
+                    const int i = t + 16 * k;
+                    if (i < L::MP) lds[L::O_RHO + i] = i < m ? rho[k] : T(0);
+                }
+                wsync();
+                bool ok;
+                {
+                    int n_f = n, m_f = m, r_f = r, c_f = c, t_f = t, qp_f = qp;
+                    SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(m_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_V(t_f); SQPH_OPAQUE_V(qp_f);
+                    load_A_tile(a.A + (long)qp_f * a.sA, n_f, m_f, r_f, c_f, at);
+                    ok = factor(a.P + (long)qp_f * a.sP, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt);
+                    store_sq_tile(a.Sinv + (long)qp_f * 2 * n_f * n_f, n_f, r_f, c_f, wt);
+                }
+                wsync();
+                need_factor = false;
+                have_A = true;
+                if (!solving) {
+                    info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;
+                } else if (!ok) {
+                    info.status = SQPH_NUMERICAL_ISSUES;
+                    break;
+                } else {
+                    iter++;
+                }
+            }
+            if (!(mode & MODE_SOLVE) || info.status == SQPH_NUMERICAL_ISSUES || info.status == SQPH_UNINITIALIZED) break;
+            if (!solving) {
+                solving = true;
+                state_dirty = true;
+                if ((mode & MODE_COLD_RESET) && !a.warm_start) {
+#pragma unroll
+                    for (int k = 0; k < NON; k++) x[k] = 0;
+#pragma unroll
+                    for (int k = 0; k < NOM; k++) z[k] = y[k] = 0;
+                }
+            }
+            if (!have_A) {
+                int n_t = n, m_t = m, r_t = r, c_t = c, qp_t = qp;
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_S(m_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t); SQPH_OPAQUE_V(qp_t);
+                load_A_tile(a.A + (long)qp_t * a.sA, n_t, m_t, r_t, c_t, at);
+            }
+            have_A = false;
+            {
+                int n_t = n, r_t = r, c_t = c;
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
+                build_B_inplace(at, wt, n_t, lds, r_t, c_t);
+            }
+            T (&bt)[TR][TC] = at;
+#define SQPH_G_PUBLISH()                                                                                         \
+    {                                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < NOM; k++) {                                                        \
+            const int i = t + 16 * k;                                                                            \
+            if (i < L::MP) lds[rowv_at(i)] = i < m ? rho[k] * (z[k] - rinvv[i] * y[k]) : T(0);                   \
+        }                                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < NON; k++) {                                                        \
+            const int j = t + 16 * k;                                                                            \
+            if (j < L::NP) put_colv(lds, j, j < n ? sigma * x[k] - qv[j] : T(0));                                \
+        }                                                                                                        \
+    }
+            SQPH_G_PUBLISH()
+            for (; iter <= a.max_iter; iter++) {
+                wsync();
+                {
+                    T w[TR], uu[TC];
+                    get_rowv(lds, r, w);
+                    get_colv(lds, c, uu);
+                    stage_AT(bt, w, lds, r, c);
+                    stage_W(wt, uu, lds, r, c);
+                }
+                wsync();
+#pragma unroll
+                for (int k = 0; k < NON; k++) {
+                    const int j = t + 16 * k;
+                    if (j < L::NP) {
+                        const T y1 = j < n ? wg_sum<C>(lds + L::O_STAGE_Y + j * L::Cp) + wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0);
+                        lds[wrow_at(j)] = y1;
+                        put_colv2(lds, j, y1);
+                    }
+                }
+                wsync();
+                {
+                    T y1c[TC], y1r[TW];
+                    get_colv2(lds, c, y1c);
+                    get_wrow(lds, r, y1r);
+                    stage_A(bt, y1c, lds, r, c);
+                    stage_WT(wt, y1r, lds, r, c);
+                }
+                wsync();
+#pragma unroll
+                for (int k = 0; k < NON; k++) {
+                    const int j = t + 16 * k;
+                    if (j < n) x[k] = alpha * wg_sum<R>(lds + L::O_STAGE + j * L::Rp) + oma * x[k];
+                }
+#pragma unroll
+                for (int k = 0; k < NOM; k++) {
+                    const int i = t + 16 * k;
+                    if (i < m) {
+                        const T zt = wg_sum<C>(lds + L::O_STAGE_Y + i * L::Cp);
+                        const T zr = alpha * zt + oma * z[k];
+                        T zn = zr + rinvv[i] * y[k];
+                        const T lo = lov[i], up = upv[i];
+                        zn = zn < lo ? lo : zn;
+                        zn = zn > up ? up : zn;
+                        y[k] = y[k] + rho[k] * (zr - zn);
+                        z[k] = zn;
+                    }
+                }
+                bool check = false, adapt = false;
+                if (--next_check == 0) {
+                    check = true;
+                    next_check = a.check_termination;
+                }
+                if (--next_adapt == 0) {
+                    adapt = true;
+                    next_adapt = a.adaptive_rho_interval;
+                }
+                if (check || adapt) {
+                    wsync();
+#pragma unroll
+                    for (int k = 0; k < NON; k++) {
+                        const int j = t + 16 * k;
+                        if (j < L::NP) put_colv(lds, j, j < n ? x[k] : T(0));
+                    }
+#pragma unroll
+                    for (int k = 0; k < NOM; k++) {
+                        const int i = t + 16 * k;
+                        if (i < L::MP) lds[rowv_at(i)] = i < m ? y[k] : T(0);
+                    }
+                    wsync();
+                    {
+                        T yr[TR];
+                        get_rowv(lds, r, yr);
+                        int n_c = n, m_c = m, r_c = r, c_c = c, qp_c = qp;
+                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_S(m_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_V(qp_c);
+                        stage_A_AT_gmem(a.A + (long)qp_c * a.sA, n_c, m_c, r_c, c_c, yr, lds);
+                    }
+                    wsync();
+                    T Ax[NOM], ATy[NON], Px[NON];
+#pragma unroll
+                    for (int k = 0; k < NOM; k++) {
+                        const int i = t + 16 * k;
+                        Ax[k] = i < m ? wg_sum<C>(lds + L::O_STAGE_Y + i * L::Cp) : T(0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NON; k++) {
+                        const int j = t + 16 * k;
+                        ATy[k] = j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0);
+                    }
+                    wsync();
+                    {
+                        int n_c = n, r_c = r, c_c = c, qp_c = qp;
+                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_V(qp_c);
+                        stage_P_gmem(a.P + (long)qp_c * a.sP, n_c, r_c, c_c, lds);
+                    }
+                    wsync();
+#pragma unroll
+                    for (int k = 0; k < NON; k++) {
+                        const int j = t + 16 * k;
+                        Px[k] = j < n ? wg_sum<C>(lds + L::O_STAGE_Y + j * L::Cp) : T(0);
+                    }
+                    wsync();
+                    T v[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < NOM; k++) {
+                        const int i = t + 16 * k;
+                        if (i < m) {
+                            v[0] = nanmax(v[0], tabs(Ax[k]));
+                            v[1] = nanmax(v[1], tabs(z[k]));
+                            v[2] = nanmax(v[2], tabs(Ax[k] - z[k]));
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NON; k++) {
+                        const int j = t + 16 * k;
+                        if (j < n) {
+                            const T q = qv[j];
+                            v[3] = nanmax(v[3], tabs(Px[k]));
+                            v[4] = nanmax(v[4], tabs(ATy[k]));
+                            v[5] = nanmax(v[5], tabs(q));
+                            v[6] = nanmax(v[6], tabs(Px[k] + q + ATy[k]));
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 7; e++) v[e] = group16_nanmax(v[e]);
+                    const T nrm_prim = nanmax(v[0], v[1]);
+                    const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
+                    info.res_prim = (double)v[2];
+                    info.res_dual = (double)v[6];
+                    if (check) {
+                        if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                            info.status = SQPH_SOLVED;
+                            break;
+                        }
+                    }
+                    if (adapt) {
+                        const T eps = a.regul;
+                        const T rp_norm = v[2] / (nrm_prim + eps);
+                        const T rd_norm = v[6] / (nrm_dual + eps);
+                        T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
+                        new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
+                        new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
+                        info.rho_estimate = (double)new_rho;
+                        if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
+                            rho_s = new_rho;
+#pragma unroll
+                            for (int k = 0; k < NOM; k++) {
+                                const int i = t + 16 * k;
+                                if (i < m) {
+                                    rho[k] = rho_for_type<T>(sct[i], rho_s, a.rho_min, a.rho_eq_factor);
+                                    rinvv[i] = T(1) / rho[k];
+                                }
+                            }
+                            info.rho_updates += 1;
+                            need_factor = true;
+                            break;
+                        }
+                    }
+                }
+                SQPH_G_PUBLISH()
+            }
+#undef SQPH_G_PUBLISH
+            if (!need_factor) break;
+        }
+        if (solving) {
+            if (iter > a.max_iter) info.status = SQPH_MAX_ITER_EXCEEDED;
+            info.iter = iter;
+        }
+        if (state_dirty) {
+#pragma unroll
+            for (int k = 0; k < NON; k++) {
+                const int j = t + 16 * k;
+                if (j < n) sx[j] = x[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NOM; k++) {
+                const int i = t + 16 * k;
+                if (i < m) {
+                    sz[i] = z[k];
+                    sy[i] = y[k];
+                    srho[i] = rho[k];
+                }
+            }
+        }
+        if (t == 0) {
+            a.info[qp] = info;
+            a.rho[qp] = rho_s;
+        }
+#undef SQPH_GP
+#undef SQPH_GA
+#undef SQPH_GW
+    }
 };
 
 // WPE = waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
@@ -816,6 +1202,33 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
     X(1, 8, 8, 8, 4, 4, 2)       \
     X(2, 16, 8, 7, 7, 4, 2)      \
     X(4, 16, 16, 8, 4, 4, 2)
+
+// four QPs per wavefront (run_group): block = one wavefront, LDS = 4 slices
+template <typename TIN, int TR, int TC, int WPE>
+__global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a) {
+    __shared__ __attribute__((aligned(16))) double lds[4 * WgLayout<0, 4, 4, TR, TC, TC>::TOTAL];
+    WgKernel<TIN, 0, 4, 4, TR, TC, TC>::run_group(a, lds);
+}
+// shapes {TR, TC, WPE}: m <= 4 TR, n <= 4 TC; first fit wins
+#define SQPH_G16_SHAPES(X) \
+    X(1, 1, 4)             \
+    X(3, 2, 4)             \
+    X(6, 3, 4)             \
+    X(10, 5, 2)
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_g16(const KArgs<double, TIN> &a) {
+#define SQPH_SIM_CASE(TR_, TC_, W_)                                                                        \
+    if (a.m <= 4 * TR_ && a.n <= 4 * TC_) {                                                                \
+        ::sqph_sim::launch(admm_g16_kernel<TIN, TR_, TC_, W_>, dim3((a.batch + 3) / 4), dim3(64), 0, a);   \
+        return 0;                                                                                          \
+    }
+    SQPH_G16_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
 
 #ifdef SQPH_SIM
 template <typename TIN>

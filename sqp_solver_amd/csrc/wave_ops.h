@@ -91,6 +91,35 @@ __device__ __forceinline__ T xchg(T v) {
 #endif
 }
 
+// partner exchange inside an aligned group of 16 lanes (masks 1, 2, 4, 8 never leave the group on the device; the
+// emulator needs to know, because the four groups of a wave may have diverged)
+template <int MASK, typename T>
+__device__ __forceinline__ T xchg16(T v) {
+    static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8, "stays inside 16 lanes");
+#ifdef SQPH_SIM
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    const uint64_t r = ::sqph_sim::group16_exchange(bits, (int)(threadIdx.x & 15) ^ MASK);
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
+#else
+    return xchg<MASK>(v);
+#endif
+}
+// NaN-propagating max over the 16 lanes of a group (all of them end with the result)
+template <typename T>
+__device__ __forceinline__ T group16_nanmax(T v) {
+#define SQPH_GM_STEP(M)                       \
+    {                                         \
+        const T o = xchg16<M>(v);             \
+        v = (o > v || o != o) ? o : v;        \
+    }
+    SQPH_GM_STEP(1) SQPH_GM_STEP(2) SQPH_GM_STEP(4) SQPH_GM_STEP(8)
+#undef SQPH_GM_STEP
+    return v;
+}
+
 // reduce-scatter of v[0..7] over the 8 lanes {g ^ k*M0-ish}; g = my index in the group (bits -> masks M0,M1,M2)
 template <int M0, int M1, int M2, typename T>
 __device__ __forceinline__ T rs8(const T (&v)[8], int g) {

@@ -39,7 +39,7 @@ struct Lane {
     ucontext_t ctx;
     std::vector<unsigned char> stack;
     bool done = false;
-    int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier
+    int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier, 3 barrier of an aligned 16-lane group
 };
 
 struct Block {
@@ -128,6 +128,19 @@ inline void run_block(unsigned nthreads, size_t smem_bytes, const std::function<
                     released = true;
                 }
             }
+            // 16-lane groups (kernels that run several independent QPs per wave; the groups may diverge)
+            for (unsigned g = 0; g * 16 < nthreads; g++) {
+                bool all_grp = true, any = false;
+                for (unsigned t = g * 16; t < nthreads && t < (g + 1) * 16; t++) {
+                    if (blk.lanes[t].done) continue;
+                    any = true;
+                    if (blk.lanes[t].wait != 3) all_grp = false;
+                }
+                if (any && all_grp) {
+                    for (unsigned t = g * 16; t < nthreads && t < (g + 1) * 16; t++) blk.lanes[t].wait = 0;
+                    released = true;
+                }
+            }
         }
         if (!ran && !released) {
             fprintf(stderr, "hip_sim: deadlock (divergent barrier / cross-lane op)\n");
@@ -157,6 +170,18 @@ inline uint64_t wave_exchange(uint64_t v, int src_lane_in_wave) {
     int s = base + (src_lane_in_wave & 63);
     uint64_t r = (s < (int)b->lanes.size()) ? b->xchg[s] : 0;
     yield_wait(2);
+    return r;
+}
+
+// the same inside an aligned group of 16 lanes (groups of one wave may have diverged)
+inline void group16_sync() { yield_wait(3); }
+inline uint64_t group16_exchange(uint64_t v, int src_lane_in_group) {
+    Block *b = cur_block();
+    const int t = b->cur;
+    b->xchg[t] = v;
+    yield_wait(3);
+    const uint64_t r = b->xchg[(t & ~15) + (src_lane_in_group & 15)];
+    yield_wait(3);
     return r;
 }
 
