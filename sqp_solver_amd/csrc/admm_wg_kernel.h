@@ -431,7 +431,11 @@ struct WgKernel {
         }
         wsync();
         if (bad) return false;
-        for (int e = t; e < n; e += NT) sjv[e] = T(1) / (T)sqrt((double)sjv[e]);
+        if constexpr (NW > 0) {
+            if (t < n) sjv[t] = T(1) / (T)sqrt((double)sjv[t]);
+        } else {
+            for (int e = t; e < n; e += NT) sjv[e] = T(1) / (T)sqrt((double)sjv[e]);
+        }
         wsync();
         T srow[TW], scol[TC];
 #pragma unroll
@@ -824,6 +828,7 @@ struct WgKernel {
     // s_barrier anywhere (wsync() is a compiler fence), a lane owns the elements t, t+16, t+32 of the n- and m-vectors,
     // the four groups diverge freely (different iteration counts, refactorisations).
     static constexpr int NON = (L::NP + 15) / 16, NOM = (L::MP + 15) / 16;
+    static constexpr int GTOTAL = L::TOTAL + L::NP + 3 * L::MP + (L::NP & 1);  // LDS doubles per QP slice (layout + iterates)
     static __device__ __forceinline__ int rowv_at(int i) { return L::O_ROWV + (i % R) * L::TRp + i / R; }
     static __device__ __forceinline__ int wrow_at(int i) { return L::O_WROW + (i % R) * L::TWp + i / R; }
 
@@ -834,20 +839,28 @@ struct WgKernel {
         const int r = t % R, c = t / R;
         const int qp = blockIdx.x * 4 + slot;
         if (qp >= a.batch) return;  // a whole group leaves: nobody waits for it
-        T *lds = lds_block + slot * L::TOTAL;
+        T *lds = lds_block + slot * GTOTAL;
+        // the iterates of the owned elements live in LDS as well: with 75 doubles of tiles per lane there is no room for
+        // them in registers (kept there, they were spilled to scratch inside the loop: 12 scratch round trips per iteration)
+        T *xs = lds + L::TOTAL, *zs = xs + L::NP, *ys = zs + L::MP, *rhos = ys + L::MP;
         const int n = a.n, m = a.m;
         // per-QP pointers are lane-varying here (four QPs per wave): derived where they are used instead of being kept
         // in 22 VGPRs for the whole solve
 #define SQPH_GP (a.P + (long)qp * a.sP)
 #define SQPH_GA (a.A + (long)qp * a.sA)
 #define SQPH_GW (a.Sinv + (long)qp * 2 * n * n)
-        T *sx = a.x + (long)qp * n;
-        T *sz = a.z + (long)qp * m;
-        T *sy = a.y + (long)qp * m;
-        T *srho = a.rho_vec + (long)qp * m;
-        int *sct = a.ctype + (long)qp * m;
+#define sx (a.x + (long)qp * n)
+#define sz (a.z + (long)qp * m)
+#define sy (a.y + (long)qp * m)
+#define srho (a.rho_vec + (long)qp * m)
+#define sct (a.ctype + (long)qp * m)
 
-        sqph_info info = a.info[qp];
+        // status / iter / rho_updates travel in registers; the three doubles of the record (written at checks only) are
+        // stored straight to the info array
+        sqph_info info;
+        info.status = a.info[qp].status;
+        info.iter = a.info[qp].iter;
+        info.rho_updates = a.info[qp].rho_updates;
         T rho_s = a.rho[qp];
         const int mode = a.mode;
         if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
@@ -870,14 +883,19 @@ struct WgKernel {
             }
         }
         wsync();
-        T x[NON], z[NOM], y[NOM], rho[NOM];
 #pragma unroll
-        for (int k = 0; k < NON; k++) x[k] = 0;
+        for (int k = 0; k < NON; k++) {
+            const int j = t + 16 * k;
+            if (j < L::NP) xs[j] = 0;
+        }
 #pragma unroll
         for (int k = 0; k < NOM; k++) {
-            z[k] = 0;
-            y[k] = 0;
-            rho[k] = T(1);
+            const int i = t + 16 * k;
+            if (i < L::MP) {
+                zs[i] = 0;
+                ys[i] = 0;
+                rhos[i] = T(1);
+            }
         }
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
             rho_s = a.rho0;
@@ -891,10 +909,10 @@ struct WgKernel {
                         ctype = SQPH_LOOSE_BOUNDS;
                     else if (up - lo < a.eq_tol)
                         ctype = SQPH_EQUALITY_CONSTRAINT;
-                    rho[k] = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
-                    rinvv[i] = T(1) / rho[k];
+                    rhos[i] = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
+                    rinvv[i] = T(1) / rhos[i];
                     sct[i] = ctype;
-                    srho[i] = rho[k];
+                    srho[i] = rhos[i];
                 }
             }
             info.rho_updates += 1;
@@ -903,17 +921,17 @@ struct WgKernel {
 #pragma unroll
             for (int k = 0; k < NON; k++) {
                 const int j = t + 16 * k;
-                if (j < n) x[k] = sx[j];
+                if (j < n) xs[j] = sx[j];
             }
 #pragma unroll
             for (int k = 0; k < NOM; k++) {
                 const int i = t + 16 * k;
                 if (i < m) {
-                    z[k] = sz[i];
-                    y[k] = sy[i];
+                    zs[i] = sz[i];
+                    ys[i] = sy[i];
                     if (!(mode & MODE_UPDATE)) {
-                        rho[k] = srho[i];
-                        rinvv[i] = T(1) / rho[k];
+                        rhos[i] = srho[i];
+                        rinvv[i] = T(1) / rhos[i];
                     }
                 }
             }
@@ -936,7 +954,7 @@ struct WgKernel {
 #pragma unroll
                 for (int k = 0; k < NOM; k++) {
                     const int i = t + 16 * k;
-                    if (i < L::MP) lds[L::O_RHO + i] = i < m ? rho[k] : T(0);
+                    if (i < L::MP) lds[L::O_RHO + i] = i < m ? rhos[i] : T(0);
                 }
                 wsync();
                 bool ok;
@@ -965,9 +983,15 @@ struct WgKernel {
                 state_dirty = true;
                 if ((mode & MODE_COLD_RESET) && !a.warm_start) {
 #pragma unroll
-                    for (int k = 0; k < NON; k++) x[k] = 0;
+                    for (int k = 0; k < NON; k++) {
+                        const int j = t + 16 * k;
+                        if (j < L::NP) xs[j] = 0;
+                    }
 #pragma unroll
-                    for (int k = 0; k < NOM; k++) z[k] = y[k] = 0;
+                    for (int k = 0; k < NOM; k++) {
+                        const int i = t + 16 * k;
+                        if (i < L::MP) zs[i] = ys[i] = 0;
+                    }
                 }
             }
             if (!have_A) {
@@ -986,11 +1010,11 @@ struct WgKernel {
     {                                                                                                            \
         _Pragma("unroll") for (int k = 0; k < NOM; k++) {                                                        \
             const int i = t + 16 * k;                                                                            \
-            if (i < L::MP) lds[rowv_at(i)] = i < m ? rho[k] * (z[k] - rinvv[i] * y[k]) : T(0);                   \
+            if (i < L::MP) lds[rowv_at(i)] = i < m ? rhos[i] * (zs[i] - rinvv[i] * ys[i]) : T(0);                   \
         }                                                                                                        \
         _Pragma("unroll") for (int k = 0; k < NON; k++) {                                                        \
             const int j = t + 16 * k;                                                                            \
-            if (j < L::NP) put_colv(lds, j, j < n ? sigma * x[k] - qv[j] : T(0));                                \
+            if (j < L::NP) put_colv(lds, j, j < n ? sigma * xs[j] - qv[j] : T(0));                                \
         }                                                                                                        \
     }
             SQPH_G_PUBLISH()
@@ -1025,20 +1049,20 @@ struct WgKernel {
 #pragma unroll
                 for (int k = 0; k < NON; k++) {
                     const int j = t + 16 * k;
-                    if (j < n) x[k] = alpha * wg_sum<R>(lds + L::O_STAGE + j * L::Rp) + oma * x[k];
+                    if (j < n) xs[j] = alpha * wg_sum<R>(lds + L::O_STAGE + j * L::Rp) + oma * xs[j];
                 }
 #pragma unroll
                 for (int k = 0; k < NOM; k++) {
                     const int i = t + 16 * k;
                     if (i < m) {
                         const T zt = wg_sum<C>(lds + L::O_STAGE_Y + i * L::Cp);
-                        const T zr = alpha * zt + oma * z[k];
-                        T zn = zr + rinvv[i] * y[k];
+                        const T zr = alpha * zt + oma * zs[i];
+                        T zn = zr + rinvv[i] * ys[i];
                         const T lo = lov[i], up = upv[i];
                         zn = zn < lo ? lo : zn;
                         zn = zn > up ? up : zn;
-                        y[k] = y[k] + rho[k] * (zr - zn);
-                        z[k] = zn;
+                        ys[i] = ys[i] + rhos[i] * (zr - zn);
+                        zs[i] = zn;
                     }
                 }
                 bool check = false, adapt = false;
@@ -1055,12 +1079,12 @@ struct WgKernel {
 #pragma unroll
                     for (int k = 0; k < NON; k++) {
                         const int j = t + 16 * k;
-                        if (j < L::NP) put_colv(lds, j, j < n ? x[k] : T(0));
+                        if (j < L::NP) put_colv(lds, j, j < n ? xs[j] : T(0));
                     }
 #pragma unroll
                     for (int k = 0; k < NOM; k++) {
                         const int i = t + 16 * k;
-                        if (i < L::MP) lds[rowv_at(i)] = i < m ? y[k] : T(0);
+                        if (i < L::MP) lds[rowv_at(i)] = i < m ? ys[i] : T(0);
                     }
                     wsync();
                     {
@@ -1101,8 +1125,8 @@ struct WgKernel {
                         const int i = t + 16 * k;
                         if (i < m) {
                             v[0] = nanmax(v[0], tabs(Ax[k]));
-                            v[1] = nanmax(v[1], tabs(z[k]));
-                            v[2] = nanmax(v[2], tabs(Ax[k] - z[k]));
+                            v[1] = nanmax(v[1], tabs(zs[i]));
+                            v[2] = nanmax(v[2], tabs(Ax[k] - zs[i]));
                         }
                     }
 #pragma unroll
@@ -1120,8 +1144,10 @@ struct WgKernel {
                     for (int e = 0; e < 7; e++) v[e] = group16_nanmax(v[e]);
                     const T nrm_prim = nanmax(v[0], v[1]);
                     const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
-                    info.res_prim = (double)v[2];
-                    info.res_dual = (double)v[6];
+                    if (t == 0) {
+                        a.info[qp].res_prim = (double)v[2];
+                        a.info[qp].res_dual = (double)v[6];
+                    }
                     if (check) {
                         if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
                             info.status = SQPH_SOLVED;
@@ -1135,15 +1161,15 @@ struct WgKernel {
                         T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
                         new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
                         new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
-                        info.rho_estimate = (double)new_rho;
+                        if (t == 0) a.info[qp].rho_estimate = (double)new_rho;
                         if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
                             rho_s = new_rho;
 #pragma unroll
                             for (int k = 0; k < NOM; k++) {
                                 const int i = t + 16 * k;
                                 if (i < m) {
-                                    rho[k] = rho_for_type<T>(sct[i], rho_s, a.rho_min, a.rho_eq_factor);
-                                    rinvv[i] = T(1) / rho[k];
+                                    rhos[i] = rho_for_type<T>(sct[i], rho_s, a.rho_min, a.rho_eq_factor);
+                                    rinvv[i] = T(1) / rhos[i];
                                 }
                             }
                             info.rho_updates += 1;
@@ -1165,25 +1191,32 @@ struct WgKernel {
 #pragma unroll
             for (int k = 0; k < NON; k++) {
                 const int j = t + 16 * k;
-                if (j < n) sx[j] = x[k];
+                if (j < n) sx[j] = xs[j];
             }
 #pragma unroll
             for (int k = 0; k < NOM; k++) {
                 const int i = t + 16 * k;
                 if (i < m) {
-                    sz[i] = z[k];
-                    sy[i] = y[k];
-                    srho[i] = rho[k];
+                    sz[i] = zs[i];
+                    sy[i] = ys[i];
+                    srho[i] = rhos[i];
                 }
             }
         }
         if (t == 0) {
-            a.info[qp] = info;
+            a.info[qp].status = info.status;
+            a.info[qp].iter = info.iter;
+            a.info[qp].rho_updates = info.rho_updates;
             a.rho[qp] = rho_s;
         }
 #undef SQPH_GP
 #undef SQPH_GA
 #undef SQPH_GW
+#undef sx
+#undef sz
+#undef sy
+#undef srho
+#undef sct
     }
 };
 
@@ -1206,7 +1239,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
 // four QPs per wavefront (run_group): block = one wavefront, LDS = 4 slices
 template <typename TIN, int TR, int TC, int WPE>
 __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a) {
-    __shared__ __attribute__((aligned(16))) double lds[4 * WgLayout<0, 4, 4, TR, TC, TC>::TOTAL];
+    __shared__ __attribute__((aligned(16))) double lds[4 * WgKernel<TIN, 0, 4, 4, TR, TC, TC>::GTOTAL];
     WgKernel<TIN, 0, 4, 4, TR, TC, TC>::run_group(a, lds);
 }
 // shapes {TR, TC, WPE}: m <= 4 TR, n <= 4 TC; first fit wins
