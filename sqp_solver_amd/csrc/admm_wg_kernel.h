@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
     X(1, 1, 4)             \
     X(3, 2, 4)             \
     X(6, 3, 4)             \
-    X(10, 5, 2)
+    X(10, 5, 1)
 
 #ifdef SQPH_SIM
 template <typename TIN>

@@ -108,6 +108,7 @@ __global__ void csr_check(int batch, int n, int m, long long nnz_cap, const int 
 
 struct sqph_solver {
     int device = 0, n = 0, m = 0, cap = 0, dtype = SQPH_F64, flags = 0;
+    int num_simds = 1024;  // 4 per CU
     hipStream_t stream = nullptr;
     sqph_settings settings{};
     // persistent device state
@@ -216,6 +217,10 @@ int sqph_create(sqph_solver **out, int device, int n, int m, int batch_capacity,
     s->dtype = dtype;
     s->flags = flags;
     sqph_default_settings(&s->settings);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->num_simds = 4 * cus;
+    }
 
     DeviceGuard g(device);
     const size_t e = sizeof(double), B = (size_t)batch_capacity;  // state/workspace: always fp64
@@ -504,7 +509,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     }
     if (!launched && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
         int rc = 0;
-        if (!(s->flags & SQPH_FLAG_WAVE_TILE)) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
+        if (!(s->flags & SQPH_FLAG_WAVE_TILE)) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name, s->num_simds);
         if (rc == 0 && !(s->flags & SQPH_FLAG_WAVE_TILE)) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = tile_try_launch<T, TIN>(a, s->stream, &s->kernel_name);
         if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "tiled kernel launch failed: %s", hipGetErrorString(hipGetLastError()));

@@ -225,6 +225,21 @@ def test_full_size_properties_c5():
     assert np.array_equal(x2[::-1], x) and np.array_equal(y2[::-1], y) and np.array_equal(info2.iter[::-1], info.iter)
 
 
+def test_small_shapes_take_the_four_per_wave_kernel():
+    """n <= 12 / m <= 24 (SQP-sized subproblems): four QPs per wavefront; a large odd batch against the oracle"""
+    from sqp_solver_amd.problems import random_qp_batch
+
+    for (n, m, B) in ((2, 3, 4099), (8, 12, 2051), (12, 24, 1027)):
+        P, q, A, l, u = random_qp_batch(B, n, m, seed=31)
+        s = make_gpu(n, m, B)
+        s.setup_solve(P, q, A, l, u)
+        assert s.kernel_name().startswith("g16_"), s.kernel_name()
+        x, y, z, info = s.solution()
+        xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle.default_settings(), nthreads=0)
+        assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all()
+        assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
+
+
 def test_full_size_fixed_iters_c2():
     """BASELINE config 2: 4,096 x (n=20, m=40), 200 ADMM iterations, whole batch against the oracle."""
     from sqp_solver_amd.problems import random_qp_batch

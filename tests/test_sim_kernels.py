@@ -148,3 +148,39 @@ def test_csr_kernel_adaptive_rho_refactors_in_kernel():
     assert (io["rho_updates"] > 1).any()  # the case does exercise a refactorisation
     assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all() and (info.rho_updates == io["rho_updates"]).all()
     assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
+
+
+# ------------------------------------------------------------------ four QPs per wavefront (admm_wg_kernel.h, run_group)
+def make_g16(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G16, legacy_cold_start=legacy_cold_start)
+
+
+@pytest.mark.parametrize("case", cases.REFERENCE_CASES, ids=lambda f: f.__name__)
+def test_g16_reference_cases(case):
+    case(make_g16)
+
+
+@pytest.mark.parametrize("n,m,batch", [(2, 3, 7), (5, 7, 5), (8, 12, 6), (12, 24, 5), (20, 40, 6), (17, 33, 3)])
+def test_g16_parity_fixed(n, m, batch):
+    """batches that are not multiples of four leave groups of the last wavefront empty"""
+    cases.parity_fixed_iters(make_g16, n, m, batch, iters=100)
+
+
+def test_g16_parity_alpha_and_float():
+    cases.parity_fixed_iters(make_g16, 9, 14, 3, iters=100, alpha=1.6)
+    cases.parity_fixed_iters(make_g16, 10, 15, 2, iters=100, dtype=np.float32)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(adaptive=True), dict(sqp_settings=True)], ids=["default", "adaptive", "sqp"])
+@pytest.mark.parametrize("n,m", [(12, 20), (20, 40)])
+def test_g16_parity_termination(n, m, kw):
+    """the four QPs of a wavefront stop / refactor at different iterations"""
+    cases.parity_termination(make_g16, n, m, 6, **kw)
+
+
+def test_g16_state_paths():
+    cases.warm_start_and_resolve(make_g16)
+    cases.set_state_warm_start(make_g16)
+    cases.uninitialized_and_numerical_issues(make_g16)
+    cases.shared_matrices(make_g16)
+    cases.edge_shapes(make_g16)
