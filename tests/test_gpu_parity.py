@@ -237,7 +237,9 @@ def test_small_shapes_take_the_four_per_wave_kernel():
         x, y, z, info = s.solution()
         xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle.default_settings(), nthreads=0)
         assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all()
-        assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
+        # tiny QPs can have every constraint inactive (y == 0 up to rounding): scale the dual error by max(1, |y|)
+        assert cases.relerr(x, xo) < cases.TOL_F64
+        assert (np.max(np.abs(y - yo), axis=1) <= cases.TOL_F64 * np.maximum(1.0, np.max(np.abs(yo), axis=1))).all()
 
 
 def test_full_size_fixed_iters_c2():
