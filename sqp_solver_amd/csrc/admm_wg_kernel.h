@@ -78,7 +78,7 @@ template <int NW, int R, int C, int TR, int TC, int TW>
 struct WgLayout {
     // NW >= 1: the R x C lane grid is a workgroup of NW wavefronts.  NW == 0: a 4 x 4 grid of 16 lanes — four
     // independent QPs share one wavefront (small problems), see run_group().
-    static_assert(NW == 0 ? R * C == 16 : R * C == 64 * NW, "lane grid must cover the workgroup");
+    static_assert(NW == 0 ? (R * C == 16 || R * C == 64) : R * C == 64 * NW, "lane grid must cover the workgroup");
     static constexpr int NT = R * C;
     static constexpr int MP = R * TR;  // padded m
     static constexpr int NP = C * TC;  // padded n (columns)
@@ -137,7 +137,8 @@ struct WgKernel {
             __syncthreads();
         } else {
 #ifdef SQPH_SIM
-            ::sqph_sim::group16_sync();
+            if constexpr (NT == 16) ::sqph_sim::group16_sync();
+            else ::sqph_sim::yield_wait(2);
 #else
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -827,17 +828,18 @@ struct WgKernel {
     // wavefront (threadIdx.x >> 4 selects the QP and its LDS slice).  Same tiles, staging and formulas as run(); no
     // s_barrier anywhere (wsync() is a compiler fence), a lane owns the elements t, t+16, t+32 of the n- and m-vectors,
     // the four groups diverge freely (different iteration counts, refactorisations).
-    static constexpr int NON = (L::NP + 15) / 16, NOM = (L::MP + 15) / 16;
+    static constexpr int GL = NT;  // lanes per QP: 16 (four QPs per wavefront) or 64 (one)
+    static constexpr int NON = (L::NP + GL - 1) / GL, NOM = (L::MP + GL - 1) / GL;
     static constexpr int GTOTAL = L::TOTAL + L::NP + 3 * L::MP + (L::NP & 1);  // LDS doubles per QP slice (layout + iterates)
     static __device__ __forceinline__ int rowv_at(int i) { return L::O_ROWV + (i % R) * L::TRp + i / R; }
     static __device__ __forceinline__ int wrow_at(int i) { return L::O_WROW + (i % R) * L::TWp + i / R; }
 
-    static __device__ void run_group(const KArgs<T, TIN> &a, T *lds_block) {
+    static __device__ __forceinline__ void run_group(const KArgs<T, TIN> &a, T *lds_block) {
         static_assert(NW == 0, "group kernel");
-        const int t = threadIdx.x & 15;
-        const int slot = threadIdx.x >> 4;
+        const int t = threadIdx.x % GL;
+        const int slot = threadIdx.x / GL;
         const int r = t % R, c = t / R;
-        const int qp = blockIdx.x * 4 + slot;
+        const int qp = blockIdx.x * (64 / GL) + slot;
         if (qp >= a.batch) return;  // a whole group leaves: nobody waits for it
         T *lds = lds_block + slot * GTOTAL;
         // the iterates of the owned elements live in LDS as well: with 75 doubles of tiles per lane there is no room for
@@ -870,12 +872,12 @@ struct WgKernel {
         T *qv = lds + L::O_QV, *lov = lds + L::O_LOV, *upv = lds + L::O_UPV, *rinvv = lds + L::O_RINV;
 #pragma unroll
         for (int k = 0; k < NON; k++) {
-            const int j = t + 16 * k;
+            const int j = t + GL * k;
             if (j < L::NP) qv[j] = j < n ? (T)(a.q + (long)qp * a.sq)[j] : T(0);
         }
 #pragma unroll
         for (int k = 0; k < NOM; k++) {
-            const int i = t + 16 * k;
+            const int i = t + GL * k;
             if (i < L::MP) {
                 lov[i] = i < m ? (T)(a.l + (long)qp * a.sl)[i] : -INF;
                 upv[i] = i < m ? (T)(a.u + (long)qp * a.su)[i] : INF;
@@ -885,12 +887,12 @@ struct WgKernel {
         wsync();
 #pragma unroll
         for (int k = 0; k < NON; k++) {
-            const int j = t + 16 * k;
+            const int j = t + GL * k;
             if (j < L::NP) xs[j] = 0;
         }
 #pragma unroll
         for (int k = 0; k < NOM; k++) {
-            const int i = t + 16 * k;
+            const int i = t + GL * k;
             if (i < L::MP) {
                 zs[i] = 0;
                 ys[i] = 0;
@@ -901,7 +903,7 @@ struct WgKernel {
             rho_s = a.rho0;
 #pragma unroll
             for (int k = 0; k < NOM; k++) {
-                const int i = t + 16 * k;
+                const int i = t + GL * k;
                 if (i < m) {
                     const T lo = lov[i], up = upv[i];
                     int ctype = SQPH_INEQUALITY_CONSTRAINT;
@@ -920,12 +922,12 @@ struct WgKernel {
         if (!(mode & MODE_SETUP)) {
 #pragma unroll
             for (int k = 0; k < NON; k++) {
-                const int j = t + 16 * k;
+                const int j = t + GL * k;
                 if (j < n) xs[j] = sx[j];
             }
 #pragma unroll
             for (int k = 0; k < NOM; k++) {
-                const int i = t + 16 * k;
+                const int i = t + GL * k;
                 if (i < m) {
                     zs[i] = sz[i];
                     ys[i] = sy[i];
@@ -953,7 +955,7 @@ struct WgKernel {
                 wsync();
 #pragma unroll
                 for (int k = 0; k < NOM; k++) {
-                    const int i = t + 16 * k;
+                    const int i = t + GL * k;
                     if (i < L::MP) lds[L::O_RHO + i] = i < m ? rhos[i] : T(0);
                 }
                 wsync();
@@ -984,12 +986,12 @@ struct WgKernel {
                 if ((mode & MODE_COLD_RESET) && !a.warm_start) {
 #pragma unroll
                     for (int k = 0; k < NON; k++) {
-                        const int j = t + 16 * k;
+                        const int j = t + GL * k;
                         if (j < L::NP) xs[j] = 0;
                     }
 #pragma unroll
                     for (int k = 0; k < NOM; k++) {
-                        const int i = t + 16 * k;
+                        const int i = t + GL * k;
                         if (i < L::MP) zs[i] = ys[i] = 0;
                     }
                 }
@@ -1009,11 +1011,11 @@ struct WgKernel {
 #define SQPH_G_PUBLISH()                                                                                         \
     {                                                                                                            \
         _Pragma("unroll") for (int k = 0; k < NOM; k++) {                                                        \
-            const int i = t + 16 * k;                                                                            \
+            const int i = t + GL * k;                                                                            \
             if (i < L::MP) lds[rowv_at(i)] = i < m ? rhos[i] * (zs[i] - rinvv[i] * ys[i]) : T(0);                   \
         }                                                                                                        \
         _Pragma("unroll") for (int k = 0; k < NON; k++) {                                                        \
-            const int j = t + 16 * k;                                                                            \
+            const int j = t + GL * k;                                                                            \
             if (j < L::NP) put_colv(lds, j, j < n ? sigma * xs[j] - qv[j] : T(0));                                \
         }                                                                                                        \
     }
@@ -1030,7 +1032,7 @@ struct WgKernel {
                 wsync();
 #pragma unroll
                 for (int k = 0; k < NON; k++) {
-                    const int j = t + 16 * k;
+                    const int j = t + GL * k;
                     if (j < L::NP) {
                         const T y1 = j < n ? wg_sum<C>(lds + L::O_STAGE_Y + j * L::Cp) + wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0);
                         lds[wrow_at(j)] = y1;
@@ -1048,12 +1050,12 @@ struct WgKernel {
                 wsync();
 #pragma unroll
                 for (int k = 0; k < NON; k++) {
-                    const int j = t + 16 * k;
+                    const int j = t + GL * k;
                     if (j < n) xs[j] = alpha * wg_sum<R>(lds + L::O_STAGE + j * L::Rp) + oma * xs[j];
                 }
 #pragma unroll
                 for (int k = 0; k < NOM; k++) {
-                    const int i = t + 16 * k;
+                    const int i = t + GL * k;
                     if (i < m) {
                         const T zt = wg_sum<C>(lds + L::O_STAGE_Y + i * L::Cp);
                         const T zr = alpha * zt + oma * zs[i];
@@ -1078,12 +1080,12 @@ struct WgKernel {
                     wsync();
 #pragma unroll
                     for (int k = 0; k < NON; k++) {
-                        const int j = t + 16 * k;
+                        const int j = t + GL * k;
                         if (j < L::NP) put_colv(lds, j, j < n ? xs[j] : T(0));
                     }
 #pragma unroll
                     for (int k = 0; k < NOM; k++) {
-                        const int i = t + 16 * k;
+                        const int i = t + GL * k;
                         if (i < L::MP) lds[rowv_at(i)] = i < m ? ys[i] : T(0);
                     }
                     wsync();
@@ -1098,12 +1100,12 @@ struct WgKernel {
                     T Ax[NOM], ATy[NON], Px[NON];
 #pragma unroll
                     for (int k = 0; k < NOM; k++) {
-                        const int i = t + 16 * k;
+                        const int i = t + GL * k;
                         Ax[k] = i < m ? wg_sum<C>(lds + L::O_STAGE_Y + i * L::Cp) : T(0);
                     }
 #pragma unroll
                     for (int k = 0; k < NON; k++) {
-                        const int j = t + 16 * k;
+                        const int j = t + GL * k;
                         ATy[k] = j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0);
                     }
                     wsync();
@@ -1115,14 +1117,14 @@ struct WgKernel {
                     wsync();
 #pragma unroll
                     for (int k = 0; k < NON; k++) {
-                        const int j = t + 16 * k;
+                        const int j = t + GL * k;
                         Px[k] = j < n ? wg_sum<C>(lds + L::O_STAGE_Y + j * L::Cp) : T(0);
                     }
                     wsync();
                     T v[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                     for (int k = 0; k < NOM; k++) {
-                        const int i = t + 16 * k;
+                        const int i = t + GL * k;
                         if (i < m) {
                             v[0] = nanmax(v[0], tabs(Ax[k]));
                             v[1] = nanmax(v[1], tabs(zs[i]));
@@ -1131,7 +1133,7 @@ struct WgKernel {
                     }
 #pragma unroll
                     for (int k = 0; k < NON; k++) {
-                        const int j = t + 16 * k;
+                        const int j = t + GL * k;
                         if (j < n) {
                             const T q = qv[j];
                             v[3] = nanmax(v[3], tabs(Px[k]));
@@ -1141,7 +1143,10 @@ struct WgKernel {
                         }
                     }
 #pragma unroll
-                    for (int e = 0; e < 7; e++) v[e] = group16_nanmax(v[e]);
+                    for (int e = 0; e < 7; e++) {
+                        if constexpr (GL == 16) v[e] = group16_nanmax(v[e]);
+                        else v[e] = wave_nanmax(v[e]);
+                    }
                     const T nrm_prim = nanmax(v[0], v[1]);
                     const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
                     if (t == 0) {
@@ -1166,7 +1171,7 @@ struct WgKernel {
                             rho_s = new_rho;
 #pragma unroll
                             for (int k = 0; k < NOM; k++) {
-                                const int i = t + 16 * k;
+                                const int i = t + GL * k;
                                 if (i < m) {
                                     rhos[i] = rho_for_type<T>(sct[i], rho_s, a.rho_min, a.rho_eq_factor);
                                     rinvv[i] = T(1) / rhos[i];
@@ -1190,12 +1195,12 @@ struct WgKernel {
         if (state_dirty) {
 #pragma unroll
             for (int k = 0; k < NON; k++) {
-                const int j = t + 16 * k;
+                const int j = t + GL * k;
                 if (j < n) sx[j] = xs[j];
             }
 #pragma unroll
             for (int k = 0; k < NOM; k++) {
-                const int i = t + 16 * k;
+                const int i = t + GL * k;
                 if (i < m) {
                     sz[i] = zs[i];
                     sy[i] = ys[i];
@@ -1241,6 +1246,12 @@ template <typename TIN, int TR, int TC, int WPE>
 __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a) {
     __shared__ __attribute__((aligned(16))) double lds[4 * WgKernel<TIN, 0, 4, 4, TR, TC, TC>::GTOTAL];
     WgKernel<TIN, 0, 4, 4, TR, TC, TC>::run_group(a, lds);
+}
+// one QP per wavefront on the same barrier-free code path (8 x 8 grid, owners hold several elements)
+template <typename TIN, int TR, int TC, int WPE>
+__global__ __launch_bounds__(64, WPE) void admm_g64_kernel(KArgs<double, TIN> a) {
+    __shared__ __attribute__((aligned(16))) double lds[WgKernel<TIN, 0, 8, 8, TR, TC, TC>::GTOTAL];
+    WgKernel<TIN, 0, 8, 8, TR, TC, TC>::run_group(a, lds);
 }
 // shapes {TR, TC, WPE}: m <= 4 TR, n <= 4 TC; first fit wins
 #define SQPH_G16_SHAPES(X) \
