@@ -43,19 +43,6 @@ inline int g16_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const
     return 0;
 }
 
-// experiment: one QP per wavefront without barriers (SQPH_G64=1)
-template <typename TIN>
-inline int g64_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
-    static const bool on = getenv("SQPH_G64") != nullptr;
-    if (!on) return 0;
-    if (a.m <= 104 && a.n <= 56) {
-        hipLaunchKernelGGL((admm_g64_kernel<TIN, 13, 7, 1>), dim3(a.batch), dim3(64), 0, stream, a);
-        *name = "g64_13x7_w1";
-        return hipGetLastError() == hipSuccess ? 1 : -1;
-    }
-    return 0;
-}
-
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>
 inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
