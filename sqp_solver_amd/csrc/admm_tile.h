@@ -43,6 +43,22 @@ inline int g16_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const
     return 0;
 }
 
+// two QPs per wavefront (32 lanes each): >0 launched, 0 not covered, <0 error
+template <typename TIN>
+inline int g32_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
+    static const bool off = getenv("SQPH_NO_G32") != nullptr;  // experiments only
+    if (off) return 0;
+#define SQPH_G32_CASE(TR_, TC_, TW_, W_)                                                                                       \
+    if (a.m <= 8 * TR_ && a.n <= 4 * TC_) {                                                                                    \
+        hipLaunchKernelGGL((admm_g32_kernel<TIN, TR_, TC_, TW_, W_>), dim3((a.batch + 1) / 2), dim3(64), 0, stream, a);        \
+        *name = "g32_" #TR_ "x" #TC_ "_w" #W_;                                                                                 \
+        return hipGetLastError() == hipSuccess ? 1 : -1;                                                                       \
+    }
+    SQPH_G32_SHAPES(SQPH_G32_CASE)
+#undef SQPH_G32_CASE
+    return 0;
+}
+
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>
 inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {

@@ -78,7 +78,7 @@ template <int NW, int R, int C, int TR, int TC, int TW>
 struct WgLayout {
     // NW >= 1: the R x C lane grid is a workgroup of NW wavefronts.  NW == 0: a 4 x 4 grid of 16 lanes — four
     // independent QPs share one wavefront (small problems), see run_group().
-    static_assert(NW == 0 ? (R * C == 16 || R * C == 64) : R * C == 64 * NW, "lane grid must cover the workgroup");
+    static_assert(NW == 0 ? (R * C == 16 || R * C == 32 || R * C == 64) : R * C == 64 * NW, "lane grid must cover the workgroup");
     static constexpr int NT = R * C;
     static constexpr int MP = R * TR;  // padded m
     static constexpr int NP = C * TC;  // padded n (columns)
@@ -137,7 +137,8 @@ struct WgKernel {
             __syncthreads();
         } else {
 #ifdef SQPH_SIM
-            if constexpr (NT == 16) ::sqph_sim::group16_sync();
+            if constexpr (NT == 16) ::sqph_sim::group_sync<16>();
+            else if constexpr (NT == 32) ::sqph_sim::group_sync<32>();
             else ::sqph_sim::yield_wait(2);
 #else
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1145,6 +1146,7 @@ struct WgKernel {
 #pragma unroll
                     for (int e = 0; e < 7; e++) {
                         if constexpr (GL == 16) v[e] = group16_nanmax(v[e]);
+                        else if constexpr (GL == 32) v[e] = group32_nanmax(v[e]);
                         else v[e] = wave_nanmax(v[e]);
                     }
                     const T nrm_prim = nanmax(v[0], v[1]);
@@ -1250,12 +1252,37 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 // (the same path with one QP per wavefront — 8 x 8 grid, TR = 13, TC = 7, 481 VGPRs, one wave per SIMD — measured
 // 4.99 ms on the C3 shard against 3.72 ms for the two-waves-per-QP workgroup kernel: without a second wave per SIMD
 // nothing hides the LDS round trips)
+// two QPs per wavefront: an 8 x 4 grid of 32 lanes per QP (m <= 8 TR, n <= 4 TC, W rows 8 TW >= n)
+template <typename TIN, int TR, int TC, int TW, int WPE>
+__global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * WgKernel<TIN, 0, 8, 4, TR, TC, TW>::GTOTAL];
+    WgKernel<TIN, 0, 8, 4, TR, TC, TW>::run_group(a, lds);
+}
+// shapes {TR, TC, TW, WPE}
+#define SQPH_G32_SHAPES(X) \
+    X(5, 5, 3, 2)          \
+    X(8, 8, 4, 1)
+
 // shapes {TR, TC, WPE}: m <= 4 TR, n <= 4 TC; first fit wins
 #define SQPH_G16_SHAPES(X) \
     X(1, 1, 4)             \
     X(3, 2, 4)             \
     X(6, 3, 4)             \
     X(10, 5, 1)
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_g32(const KArgs<double, TIN> &a) {
+#define SQPH_SIM_CASE(TR_, TC_, TW_, W_)                                                                         \
+    if (a.m <= 8 * TR_ && a.n <= 4 * TC_) {                                                                      \
+        ::sqph_sim::launch(admm_g32_kernel<TIN, TR_, TC_, TW_, W_>, dim3((a.batch + 1) / 2), dim3(64), 0, a);    \
+        return 0;                                                                                                \
+    }
+    SQPH_G32_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
 
 #ifdef SQPH_SIM
 template <typename TIN>

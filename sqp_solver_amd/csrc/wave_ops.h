@@ -120,6 +120,31 @@ __device__ __forceinline__ T group16_nanmax(T v) {
     return v;
 }
 
+// the same for an aligned group of 32 lanes (two QPs per wavefront)
+template <typename T>
+__device__ __forceinline__ T group32_nanmax(T v) {
+#ifdef SQPH_SIM
+    for (int M = 1; M < 32; M <<= 1) {
+        uint64_t bits = 0;
+        memcpy(&bits, &v, sizeof(T));
+        const uint64_t r = ::sqph_sim::group_exchange<32>(bits, (int)(threadIdx.x & 31) ^ M);
+        T o;
+        memcpy(&o, &r, sizeof(T));
+        v = (o > v || o != o) ? o : v;
+    }
+    return v;
+#else
+#define SQPH_GM_STEP(M)                       \
+    {                                         \
+        const T o = xchg<M>(v);               \
+        v = (o > v || o != o) ? o : v;        \
+    }
+    SQPH_GM_STEP(1) SQPH_GM_STEP(2) SQPH_GM_STEP(4) SQPH_GM_STEP(8) SQPH_GM_STEP(16)
+#undef SQPH_GM_STEP
+    return v;
+#endif
+}
+
 // reduce-scatter of v[0..7] over the 8 lanes {g ^ k*M0-ish}; g = my index in the group (bits -> masks M0,M1,M2)
 template <int M0, int M1, int M2, typename T>
 __device__ __forceinline__ T rs8(const T (&v)[8], int g) {

@@ -39,7 +39,7 @@ struct Lane {
     ucontext_t ctx;
     std::vector<unsigned char> stack;
     bool done = false;
-    int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier, 3 barrier of an aligned 16-lane group
+    int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier, 3 / 4 barrier of an aligned 16- / 32-lane group
 };
 
 struct Block {
@@ -128,17 +128,20 @@ inline void run_block(unsigned nthreads, size_t smem_bytes, const std::function<
                     released = true;
                 }
             }
-            // 16-lane groups (kernels that run several independent QPs per wave; the groups may diverge)
-            for (unsigned g = 0; g * 16 < nthreads; g++) {
-                bool all_grp = true, any = false;
-                for (unsigned t = g * 16; t < nthreads && t < (g + 1) * 16; t++) {
-                    if (blk.lanes[t].done) continue;
-                    any = true;
-                    if (blk.lanes[t].wait != 3) all_grp = false;
-                }
-                if (any && all_grp) {
-                    for (unsigned t = g * 16; t < nthreads && t < (g + 1) * 16; t++) blk.lanes[t].wait = 0;
-                    released = true;
+            // 16- and 32-lane groups (kernels that run several independent QPs per wave; the groups may diverge)
+            for (unsigned gs = 16; gs <= 32; gs *= 2) {
+                const int kind = gs == 16 ? 3 : 4;
+                for (unsigned g = 0; g * gs < nthreads; g++) {
+                    bool all_grp = true, any = false;
+                    for (unsigned t = g * gs; t < nthreads && t < (g + 1) * gs; t++) {
+                        if (blk.lanes[t].done) continue;
+                        any = true;
+                        if (blk.lanes[t].wait != kind) all_grp = false;
+                    }
+                    if (any && all_grp) {
+                        for (unsigned t = g * gs; t < nthreads && t < (g + 1) * gs; t++) blk.lanes[t].wait = 0;
+                        released = true;
+                    }
                 }
             }
         }
@@ -174,16 +177,23 @@ inline uint64_t wave_exchange(uint64_t v, int src_lane_in_wave) {
 }
 
 // the same inside an aligned group of 16 lanes (groups of one wave may have diverged)
-inline void group16_sync() { yield_wait(3); }
-inline uint64_t group16_exchange(uint64_t v, int src_lane_in_group) {
+template <int GS>
+inline void group_sync() {
+    static_assert(GS == 16 || GS == 32, "group size");
+    yield_wait(GS == 16 ? 3 : 4);
+}
+template <int GS>
+inline uint64_t group_exchange(uint64_t v, int src_lane_in_group) {
     Block *b = cur_block();
     const int t = b->cur;
     b->xchg[t] = v;
-    yield_wait(3);
-    const uint64_t r = b->xchg[(t & ~15) + (src_lane_in_group & 15)];
-    yield_wait(3);
+    group_sync<GS>();
+    const uint64_t r = b->xchg[(t & ~(GS - 1)) + (src_lane_in_group & (GS - 1))];
+    group_sync<GS>();
     return r;
 }
+inline void group16_sync() { group_sync<16>(); }
+inline uint64_t group16_exchange(uint64_t v, int src) { return group_exchange<16>(v, src); }
 
 }  // namespace sqph_sim
 
