@@ -25,15 +25,12 @@ inline int tile_try_launch(const KArgs<T, TIN> &a, hipStream_t stream, const cha
 }
 
 // four-QPs-per-wavefront kernels for small shapes (admm_wg_kernel.h, run_group): >0 launched, 0 not covered, <0 error
-// The largest shape (m <= 40, n <= 20: 75 doubles of tiles per lane) needs the whole register file of a SIMD for one
-// wave, so it only pays while the batch leaves at most one such wave per SIMD (measured: 0.474 vs 0.513 ms at 4,096
-// QPs, 7.1 vs 6.2 ms at 65,536); beyond that the one-wave-per-QP kernel takes over.
 template <typename TIN>
-inline int g16_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name, int num_simds) {
+inline int g16_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
     static const bool off = getenv("SQPH_NO_G16") != nullptr;  // experiments only
     if (off) return 0;
 #define SQPH_G16_CASE(TR_, TC_, W_)                                                                                            \
-    if (a.m <= 4 * TR_ && a.n <= 4 * TC_ && (W_ > 1 || (a.batch + 3) / 4 <= num_simds)) {                                                                                    \
+    if (a.m <= 4 * TR_ && a.n <= 4 * TC_) {                                                                                    \
         hipLaunchKernelGGL((admm_g16_kernel<TIN, TR_, TC_, W_>), dim3((a.batch + 3) / 4), dim3(64), 0, stream, a);             \
         *name = "g16_" #TR_ "x" #TC_ "_w" #W_;                                                                                 \
         return hipGetLastError() == hipSuccess ? 1 : -1;                                                                       \

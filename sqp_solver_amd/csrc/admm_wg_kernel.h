@@ -1258,17 +1258,17 @@ __global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a)
     __shared__ __attribute__((aligned(16))) double lds[2 * WgKernel<TIN, 0, 8, 4, TR, TC, TW>::GTOTAL];
     WgKernel<TIN, 0, 8, 4, TR, TC, TW>::run_group(a, lds);
 }
-// shapes {TR, TC, TW, WPE}
+// shapes {TR, TC, TW, WPE}.  Measured (200 iterations): n = 20, m = 40 at 4,096 QPs 0.415 ms against 0.477 ms for four QPs per
+// wave (10 x 5 tiles, one wave per SIMD) and 0.513 ms for one QP per wave; an 8 x 8 tile shape (m <= 64, n <= 32, 322 VGPRs)
+// lost to the one-wave-per-QP kernel (3.19 vs 2.44 ms at 16,384 QPs) and is not compiled.
 #define SQPH_G32_SHAPES(X) \
-    X(5, 5, 3, 2)          \
-    X(8, 8, 4, 1)
+    X(5, 5, 3, 2)
 
 // shapes {TR, TC, WPE}: m <= 4 TR, n <= 4 TC; first fit wins
 #define SQPH_G16_SHAPES(X) \
     X(1, 1, 4)             \
     X(3, 2, 4)             \
-    X(6, 3, 4)             \
-    X(10, 5, 1)
+    X(6, 3, 4)
 
 #ifdef SQPH_SIM
 template <typename TIN>

@@ -509,7 +509,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     }
     if (!launched && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
         int rc = 0;
-        if (!(s->flags & SQPH_FLAG_WAVE_TILE)) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name, s->num_simds);
+        if (!(s->flags & SQPH_FLAG_WAVE_TILE)) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0 && !(s->flags & SQPH_FLAG_WAVE_TILE)) rc = g32_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0 && !(s->flags & SQPH_FLAG_WAVE_TILE)) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = tile_try_launch<T, TIN>(a, s->stream, &s->kernel_name);

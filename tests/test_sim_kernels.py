@@ -160,7 +160,7 @@ def test_g16_reference_cases(case):
     case(make_g16)
 
 
-@pytest.mark.parametrize("n,m,batch", [(2, 3, 7), (5, 7, 5), (8, 12, 6), (12, 24, 5), (20, 40, 6), (17, 33, 3)])
+@pytest.mark.parametrize("n,m,batch", [(2, 3, 7), (5, 7, 5), (8, 12, 6), (12, 24, 5), (11, 21, 3)])
 def test_g16_parity_fixed(n, m, batch):
     """batches that are not multiples of four leave groups of the last wavefront empty"""
     cases.parity_fixed_iters(make_g16, n, m, batch, iters=100)
@@ -172,7 +172,7 @@ def test_g16_parity_alpha_and_float():
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(adaptive=True), dict(sqp_settings=True)], ids=["default", "adaptive", "sqp"])
-@pytest.mark.parametrize("n,m", [(12, 20), (20, 40)])
+@pytest.mark.parametrize("n,m", [(12, 20), (7, 11)])
 def test_g16_parity_termination(n, m, kw):
     """the four QPs of a wavefront stop / refactor at different iterations"""
     cases.parity_termination(make_g16, n, m, 6, **kw)
@@ -184,3 +184,26 @@ def test_g16_state_paths():
     cases.uninitialized_and_numerical_issues(make_g16)
     cases.shared_matrices(make_g16)
     cases.edge_shapes(make_g16)
+
+
+# ------------------------------------------------------------------ two QPs per wavefront (8 x 4 lane grid per QP)
+def make_g32(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G32, legacy_cold_start=legacy_cold_start)
+
+
+@pytest.mark.parametrize("n,m,batch", [(5, 7, 5), (20, 40, 5), (17, 33, 3)])
+def test_g32_parity_fixed(n, m, batch):
+    cases.parity_fixed_iters(make_g32, n, m, batch, iters=100)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(adaptive=True), dict(sqp_settings=True)], ids=["default", "adaptive", "sqp"])
+def test_g32_parity_termination(kw):
+    cases.parity_termination(make_g32, 20, 40, 5, **kw)
+
+
+def test_g32_state_paths():
+    cases.ref_testSimpleQP(make_g32)
+    cases.warm_start_and_resolve(make_g32)
+    cases.set_state_warm_start(make_g32)
+    cases.uninitialized_and_numerical_issues(make_g32)
+    cases.shared_matrices(make_g32)
