@@ -1032,12 +1032,12 @@ struct WgKernel {
                 }
                 wsync();
 #pragma unroll
-                for (int k = 0; k < NON; k++) {
+                for (int k = 0; k < (L::NR + GL - 1) / GL; k++) {
                     const int j = t + GL * k;
-                    if (j < L::NP) {
+                    if (j < L::NR) {  // the W-row gather is padded to R * TW >= NP entries: all of them must be defined
                         const T y1 = j < n ? wg_sum<C>(lds + L::O_STAGE_Y + j * L::Cp) + wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0);
                         lds[wrow_at(j)] = y1;
-                        put_colv2(lds, j, y1);
+                        if (j < L::NP) put_colv2(lds, j, y1);
                     }
                 }
                 wsync();
