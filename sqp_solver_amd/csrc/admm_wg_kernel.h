@@ -1231,6 +1231,9 @@ struct WgKernel {
 template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
 __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN> a) {
     __shared__ __attribute__((aligned(16))) double lds[WgLayout<NW, R, C, TR, TC, TW>::TOTAL];
+#ifdef SQPH_SIM
+    ::sqph_sim::poison_static_lds(lds, sizeof(lds));
+#endif
     WgKernel<TIN, NW, R, C, TR, TC, TW>::run(a, lds);
 }
 
@@ -1247,6 +1250,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
 template <typename TIN, int TR, int TC, int WPE>
 __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a) {
     __shared__ __attribute__((aligned(16))) double lds[4 * WgKernel<TIN, 0, 4, 4, TR, TC, TC>::GTOTAL];
+#ifdef SQPH_SIM
+    ::sqph_sim::poison_static_lds(lds, sizeof(lds));
+#endif
     WgKernel<TIN, 0, 4, 4, TR, TC, TC>::run_group(a, lds);
 }
 // (the same path with one QP per wavefront — 8 x 8 grid, TR = 13, TC = 7, 481 VGPRs, one wave per SIMD — measured
@@ -1256,6 +1262,9 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 template <typename TIN, int TR, int TC, int TW, int WPE>
 __global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a) {
     __shared__ __attribute__((aligned(16))) double lds[2 * WgKernel<TIN, 0, 8, 4, TR, TC, TW>::GTOTAL];
+#ifdef SQPH_SIM
+    ::sqph_sim::poison_static_lds(lds, sizeof(lds));
+#endif
     WgKernel<TIN, 0, 8, 4, TR, TC, TW>::run_group(a, lds);
 }
 // shapes {TR, TC, TW, WPE}.  Measured (200 iterations): n = 20, m = 40 at 4,096 QPs 0.415 ms against 0.477 ms for four QPs per

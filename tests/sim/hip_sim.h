@@ -81,7 +81,7 @@ inline void fiber_entry() {
 inline void run_block(unsigned nthreads, size_t smem_bytes, const std::function<void()> &body) {
     Block blk;
     blk.lanes.resize(nthreads);
-    blk.smem.assign(smem_bytes + 64, 0);
+    blk.smem.assign(smem_bytes + 64, 0xFF);  // poison: uninitialised LDS reads as NaN (doubles) / -1 (ints), like stale LDS might
     blk.body = body;
     cur_block() = &blk;
     const size_t STACK = 256 * 1024;
@@ -174,6 +174,11 @@ inline uint64_t wave_exchange(uint64_t v, int src_lane_in_wave) {
     uint64_t r = (s < (int)b->lanes.size()) ? b->xchg[s] : 0;
     yield_wait(2);
     return r;
+}
+
+// statically allocated __shared__ arrays are plain statics here: kernels poison them on entry (thread 0 runs first)
+inline void poison_static_lds(void *p, size_t bytes) {
+    if (cur_block()->cur == 0) memset(p, 0xFF, bytes);
 }
 
 // the same inside an aligned group of 16 lanes (groups of one wave may have diverged)
