@@ -121,6 +121,8 @@ def main():
 
     for _ in range(args.warmup):
         full_step()
+    if gather_bufs is not None:
+        gather_bufs.flush()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -130,6 +132,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full_step()
+    if gather_bufs is not None:
+        gather_bufs.flush()  # the last batches' gathers are still in flight (they overlap the following solve)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -223,6 +227,7 @@ def main():
             # sanity: the gathered record of rank 0's own shard equals its resident state
             xs = gather_bufs.stacked()[0]
             assert torch.equal(xs[:B], gather_bufs.local[0]), "gather mismatch"
+            assert xs.shape[0] == B * world
         dist.barrier()
         dist.destroy_process_group()
     return out

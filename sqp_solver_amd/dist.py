@@ -33,28 +33,66 @@ def device_views(solver, device):
 
 
 class ResultGather:
-    """Collect per-rank result tensors on rank `dst` with one gather per array."""
+    """Collect the per-rank result records on rank `dst`: the arrays are packed into ONE staging buffer and sent with
+    ONE gather per batch (direct peer-to-root over xGMI with the "nccl" backend).  The collective is asynchronous and
+    double-buffered: the gather of batch k runs on the communication stream while batch k+1 is being solved; a staging
+    buffer is reused only after its previous gather has completed (stream dependency, no host wait).  `flush()` joins
+    everything outstanding (call it before the final synchronisation / before reading `stacked()`)."""
 
-    def __init__(self, solver=None, world=1, rank=0, device=None, tensors=None, dst=0):
+    def __init__(self, solver=None, world=1, rank=0, device=None, tensors=None, dst=0, depth=2):
         import torch
         import torch.distributed as dist
 
         self.dist = dist
-        self.world, self.rank, self.dst = world, rank, dst
+        self.world, self.rank, self.dst, self.depth = world, rank, dst, depth
         self.local = list(tensors) if tensors is not None else list(device_views(solver, device))
+        self.local = [t if t.is_contiguous() else t.contiguous() for t in self.local]
+        self.nbytes = [t.numel() * t.element_size() for t in self.local]
+        total = sum(self.nbytes)
+        dev = self.local[0].device
+        self.stage = [torch.empty(total, dtype=torch.uint8, device=dev) for _ in range(depth)]
         self.out = None
         if rank == dst:
-            self.out = [[torch.empty_like(t) for _ in range(world)] for t in self.local]
+            self.out = [[torch.empty(total, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(depth)]
+        self.work = [None] * depth
+        self.k = 0
+        self.last = None
 
     def gather(self):
-        for i, t in enumerate(self.local):
-            self.dist.gather(t, self.out[i] if self.rank == self.dst else None, dst=self.dst)
-        return self.out
-
-    def stacked(self):
-        """On dst: each array concatenated over ranks in rank order (== the unsharded batch order)."""
+        """Pack the current contents of the local arrays and start their gather (returns immediately)."""
         import torch
 
-        if self.out is None:
+        slot = self.k % self.depth
+        self.k += 1
+        if self.work[slot] is not None:
+            self.work[slot].wait()  # the staging buffer is free again once its previous gather is done
+        off = 0
+        for t, nb in zip(self.local, self.nbytes):
+            self.stage[slot][off:off + nb].copy_(t.view(torch.uint8).reshape(-1))
+            off += nb
+        self.work[slot] = self.dist.gather(self.stage[slot], self.out[slot] if self.rank == self.dst else None, dst=self.dst,
+                                           async_op=True)
+        self.last = slot
+        return self.work[slot]
+
+    def flush(self):
+        for i, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[i] = None
+
+    def stacked(self):
+        """On dst: each array of the most recent gather concatenated over ranks in rank order (== the unsharded batch
+        order); joins outstanding gathers first."""
+        import torch
+
+        self.flush()
+        if self.out is None or self.last is None:
             return None
-        return [torch.cat(parts, dim=0) for parts in self.out]
+        res = []
+        off = 0
+        for t, nb in zip(self.local, self.nbytes):
+            parts = [o[off:off + nb].view(t.dtype).reshape(t.shape) for o in self.out[self.last]]
+            res.append(torch.cat(parts, dim=0))
+            off += nb
+        return res

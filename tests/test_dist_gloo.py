@@ -42,6 +42,7 @@ def test_two_rank_shard_and_gather(tmp_path):
     import simlib
     from sqp_solver_amd.problems import random_qp_batch
 
+    simlib.lib()  # build the emulator library once here: the two ranks would otherwise race in `make`
     out = str(tmp_path / "gathered.npz")
     script = str(tmp_path / "worker.py")
     open(script, "w").write(WORKER)
