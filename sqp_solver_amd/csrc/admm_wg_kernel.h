@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a)
 #define SQPH_G16_SHAPES(X) \
     X(1, 1, 4)             \
     X(3, 2, 4)             \
-    X(6, 3, 4)
+    X(6, 3, 2)
 
 #ifdef SQPH_SIM
 template <typename TIN>
