@@ -675,6 +675,15 @@ struct WgKernel {
                     stage_WT(wt, y1r, lds, r, c);
                 }
                 SQPH_TICK(5)
+                // the owner's constants do not depend on the partial sums: fetched before the barrier, their LDS latency
+                // hides behind it
+                T c_rinv = T(1), c_lo = T(0), c_up = T(0), c_q = T(0);
+                if (t < L::MP) {
+                    c_rinv = rinvv[t];
+                    c_lo = lov[t];
+                    c_up = upv[t];
+                }
+                if (t < L::NP) c_q = qv[t];
                 __syncthreads();
                 SQPH_TICK(6)
                 // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
@@ -683,8 +692,8 @@ struct WgKernel {
                 if (mown) {
                     const T zt = reduce_over_c(lds, t);
                     const T zr = alpha * zt + oma * z;
-                    T zn = zr + rinvv[t] * y;
-                    const T lo = lov[t], up = upv[t];
+                    T zn = zr + c_rinv * y;
+                    const T lo = c_lo, up = c_up;
                     zn = zn < lo ? lo : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
                     zn = zn > up ? up : zn;
                     y = y + rho * (zr - zn);
@@ -795,8 +804,8 @@ struct WgKernel {
                     }
                 }
                 // operands of the next iteration (the barrier at the loop top orders them before the gathers)
-                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
-                if (t < L::NP) put_colv(lds, t, nown ? sigma * x - qv[t] : T(0));
+                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - c_rinv * y) : T(0));
+                if (t < L::NP) put_colv(lds, t, nown ? sigma * x - c_q : T(0));
                 SQPH_TICK(7)
             }
 #ifdef SQPH_PHASE_TIMING
