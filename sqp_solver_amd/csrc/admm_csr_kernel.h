@@ -509,7 +509,6 @@ struct CsrKernel {
         if (qp >= a.batch) return;
         const int n = a.n, m = a.m;
         const CsrLayout<TT> L = CsrLayout<TT>::make(m, ca.nnz_cap);
-        using LL = CsrLayout<TT>;
         T *lds = reinterpret_cast<T *>(smem);
         int *li = reinterpret_cast<int *>(smem);
         const int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr;
