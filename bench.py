@@ -212,6 +212,9 @@ def main():
                 "kernel_ms_avg": avg_kernel_ms,
                 "kernel_launches_timed": len(kernel_ms),
                 "onchip_f64_tflops": flops_per_iter * iters_local / (avg_kernel_ms * 1e-3) / 1e12,
+                # the loop is on-chip bound: iteration flops against the fp64 vector peak (78.6 TFLOP/s public
+                # spec = half the guide's 157.3 TFLOP/s fp32 vector rate)
+                "onchip_f64_frac": flops_per_iter * iters_local / (avg_kernel_ms * 1e-3) / 1e12 / 78.6,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
