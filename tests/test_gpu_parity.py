@@ -99,6 +99,21 @@ def test_csr_parity(n, m, batch, density, shared, make):
     cases.csr_parity(make, n, m, batch, density=density, shared_pattern=shared, iters=50)
 
 
+def test_csr_falls_back_when_the_sparse_matrix_does_not_fit_lds():
+    """n=200, m=400 at 12 % density (~9,600 nnz > the ~6,000 the CU's LDS holds next to the vectors): expand + dense path"""
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    n, m, B = 200, 400, 2
+    P, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=0.12, seed=2)
+    s = make_gpu(n, m, B)
+    s.settings.max_iter, s.settings.check_termination = 30, 0
+    s.setup_solve_csr(P, q, rp, ci, v, l, u)
+    assert s.kernel_name().startswith("generic"), s.kernel_name()
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings))
+    assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
+
+
 def test_csr_edge_cases():
     cases.csr_edge_cases(make_gpu)
 
