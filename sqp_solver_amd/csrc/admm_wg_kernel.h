@@ -507,7 +507,7 @@ struct WgKernel {
     }
 
     // ------------------------------------------------------------------ kernel body
-    static __device__ void run(const KArgs<T, TIN> &a, T *lds) {
+    static __device__ __forceinline__ void run(const KArgs<T, TIN> &a, T *lds) {
         const int t = threadIdx.x;
         const int r = t % R, c = t / R;
         const int qp = blockIdx.x;
@@ -1253,7 +1253,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
     X(1, 8, 8, 5, 3, 3, 3)       \
     X(1, 8, 8, 8, 4, 4, 2)       \
     X(2, 16, 8, 7, 7, 4, 2)      \
-    X(4, 16, 16, 8, 4, 4, 2)
+    X(4, 16, 16, 8, 4, 4, 2)     \
+    X(4, 16, 16, 13, 7, 7, 1)
 
 // four QPs per wavefront (run_group): block = one wavefront, LDS = 4 slices
 template <typename TIN, int TR, int TC, int WPE>

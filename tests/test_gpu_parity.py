@@ -72,6 +72,16 @@ def test_state_paths(make):
     cases.edge_shapes(make)
 
 
+def test_four_wave_shapes():
+    """m <= 208, n <= 112: four wavefronts per QP (13 x 7 + 7 x 7 doubles of tiles per lane, one wave per SIMD)"""
+    s = make_gpu(100, 200, 2)
+    s.setup_solve(*[a[:2] for a in cases.random_qp_batch(2, 100, 200, seed=3)])
+    assert s.kernel_name().startswith("wg4_16x16_13x7"), s.kernel_name()
+    cases.parity_fixed_iters(make_gpu, 100, 200, 8, iters=60)
+    cases.parity_fixed_iters(make_gpu, 112, 208, 4, iters=40)
+    cases.parity_termination(make_gpu, 90, 180, 6, adaptive=True)
+
+
 def test_large_generic_shape():
     """beyond the tiled kernels: n=120, m=260 takes the 4-wave generic kernel"""
     cases.parity_fixed_iters(make_gpu, 120, 260, 4, iters=40)

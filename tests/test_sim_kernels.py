@@ -186,6 +186,11 @@ def test_g16_state_paths():
     cases.edge_shapes(make_g16)
 
 
+def test_wg_four_wave_large_tile_shape():
+    """the m <= 208, n <= 112 shape (4 waves, 13 x 7 tiles) under the emulator"""
+    cases.parity_fixed_iters(lambda n, m, b, **kw: simlib.SimSolverBatch(n, m, b, variant=simlib.WG), 70, 150, 1, iters=25)
+
+
 # ------------------------------------------------------------------ two QPs per wavefront (8 x 4 lane grid per QP)
 def make_g32(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
     return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G32, legacy_cold_start=legacy_cold_start)
