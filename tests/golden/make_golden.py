@@ -29,7 +29,26 @@ CASES = [
 ]
 
 
+def csr_case():
+    """BASELINE config 5 in small: a CSR constraint matrix beyond the dense register-tiled shapes (native sparse kernel)"""
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    n, m, B = 80, 160, 3
+    P, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=0.08, seed=20250233)
+    for name, over in (("c5_csr_n80_m160_fixed100", dict(max_iter=100, check_termination=0)), ("c5_csr_n80_m160_default", dict())):
+        st = oracle.default_settings(**over)
+        x, y, z, info = oracle.solve_batch(P, q, A, l, u, st, nthreads=1)
+        d = dict(n=n, m=m, P=P, q=q, A=A, l=l, u=u, x=x, y=y, z=z, status=info["status"], iter=info["iter"],
+                 rho_updates=info["rho_updates"], res_prim=info["res_prim"], res_dual=info["res_dual"],
+                 csr_rowptr=rp, csr_colind=ci, csr_val=v)
+        for k in SETTING_KEYS:
+            d["set_" + k] = getattr(st, k)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        print(name, "status", np.bincount(info["status"], minlength=2), "iters", info["iter"].min(), info["iter"].max())
+
+
 def main():
+    csr_case()
     for name, n, m, B, seed, over in CASES:
         if seed is None:
             S = SIMPLE_QP

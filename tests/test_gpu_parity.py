@@ -170,7 +170,11 @@ def test_golden_fixtures():
     for name, g in golden_io.load_all():
         s = make_gpu(g["n"], g["m"], g["P"].shape[0])
         golden_io.apply_settings(s.settings, g)
-        s.setup_solve(g["P"], g["q"], g["A"], g["l"], g["u"])
+        if "csr_rowptr" in g:
+            s.setup_solve_csr(g["P"], g["q"], g["csr_rowptr"], g["csr_colind"], g["csr_val"], g["l"], g["u"])
+            assert s.kernel_name().startswith("csr_"), s.kernel_name()
+        else:
+            s.setup_solve(g["P"], g["q"], g["A"], g["l"], g["u"])
         x, y, z, info = s.solution()
         assert cases.relerr(x, g["x"]) < cases.TOL_F64, name
         assert np.max(np.abs(y - g["y"])) <= cases.TOL_F64 * max(1.0, np.max(np.abs(g["y"]))), name
