@@ -212,6 +212,60 @@ struct WgKernel {
 #pragma unroll
         for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = px[k];
     }
+    // The iteration's two stages with the W' tile (vt[u][k] = W[TC c + k][R u + r]): both products of a stage share the
+    // reduction direction, so stage 1 stages ONE set of partial sums (W u and B'w accumulate into the same registers)
+    // and every owner sums 16 + 8 + 8 instead of 16 + 8 + 16 + 8 partials per iteration; 18 instead of 25 LDS stores.
+    //   stage 1:  y1[TC c + k] += sum_s B[R s + r][.] w[R s + r] + sum_u W[.][R u + r] u[R u + r]      (reduced over r)
+    static __device__ __forceinline__ void stage1(const T (&bt)[TR][TC], const T (&vt)[TW][TC], const T (&w)[TR], const T (&ur)[TW], T *lds,
+                                                  int r, int c) {
+        T pb[TC];
+#pragma unroll
+        for (int k = 0; k < TC; k++) pb[k] = 0;
+#pragma unroll
+        for (int s = 0; s < TR; s++)
+#pragma unroll
+            for (int k = 0; k < TC; k++) pb[k] = wg_fma(bt[s][k], w[s], pb[k]);
+#pragma unroll
+        for (int u = 0; u < TW; u++)
+#pragma unroll
+            for (int k = 0; k < TC; k++) pb[k] = wg_fma(vt[u][k], ur[u], pb[k]);
+        T *st = lds + L::O_STAGE;
+#pragma unroll
+        for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = pb[k];
+    }
+    //   stage 2:  z~[R s + r] = sum_k B[.][TC c + k] y1[TC c + k] ,  x~[R u + r] = sum_k W[TC c + k][.] y1[TC c + k]   (both over c)
+    // x~ partials go to the (by now consumed) stage-1 area as [R u + r][Cp].
+    static_assert(L::NR * L::Cp <= L::STAGE_X, "x~ partials reuse the stage-1 area");
+    static __device__ __forceinline__ void stage2(const T (&bt)[TR][TC], const T (&vt)[TW][TC], const T (&y1)[TC], T *lds, int r, int c) {
+        T pz[TR];
+#pragma unroll
+        for (int s = 0; s < TR; s++) pz[s] = 0;
+#pragma unroll
+        for (int k = 0; k < TC; k++)
+#pragma unroll
+            for (int s = 0; s < TR; s++) pz[s] = wg_fma(bt[s][k], y1[k], pz[s]);
+        T *sty = lds + L::O_STAGE_Y;
+#pragma unroll
+        for (int s = 0; s < TR; s++) sty[(R * s + r) * L::Cp + c] = pz[s];
+        T *stx = lds + L::O_STAGE;
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            T acc = 0;
+#pragma unroll
+            for (int k = 0; k < TC; k++) acc = wg_fma(vt[u][k], y1[k], acc);
+            stx[(R * u + r) * L::Cp + c] = acc;
+        }
+    }
+    static __device__ __forceinline__ void load_vt(const T *__restrict__ gvt, int n, int r, int c, T (&vt)[TW][TC]) {
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const int jp = R * u + r;
+#pragma unroll
+            for (int k = 0; k < TC; k++) vt[u][k] = (jp < n && TC * c + k < n) ? gvt[(long)jp * n + TC * c + k] : T(0);
+        }
+    }
+    static __device__ __forceinline__ T reduce_xt(const T *lds, int i) { return wg_sum<C>(lds + L::O_STAGE + i * L::Cp); }
+
     // owner-side reductions (lane t owns output t)
     static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? t : 0) * L::Rp); }
     static __device__ __forceinline__ T reduce_over_c(const T *lds, int t) { return wg_sum<C>(lds + L::O_STAGE_Y + t * L::Cp); }
@@ -255,9 +309,11 @@ struct WgKernel {
     // B = A W' IN PLACE over the A tile (bt[s][k] = sum_j A[R s + r][j] * W[TC c + k][j], W lower triangular).
     // W is staged once (transposed) in LDS from the register tile, A goes through LDS one block of R rows at
     // a time — nothing is re-read from global memory.
-    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c) {
+    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], T *__restrict__ gvt, int n, T *lds, int r,
+                                                           int c) {
         T *As = lds + L::O_AS, *Wl = lds + L::O_WL;
         const int myhalf = c / L::CH, cl = c - myhalf * L::CH;  // my column group inside its half
+
 #pragma unroll
         for (int s = 0; s < TR; s++) {
             wsync();
@@ -281,6 +337,23 @@ struct WgKernel {
                     }
                 }
                 wsync();
+                if (s == 0) {
+                    // the tile of W' in the tile layout (rows cyclic over r, columns blocked by c) for the iteration loop,
+                    // vt[u][k] = W[TC c + k][R u + r], is picked from the staged half that holds column R u + r and parked
+                    // in this lane's slots of the workspace (same thread writes and reads: no coherence question) — it
+                    // must not be live in registers next to the A / W tiles of the set-up
+#pragma unroll
+                    for (int u = 0; u < TW; u++) {
+                        const int jp = R * u + r;
+                        if (jp >= L::CH * TC * half && jp < L::CH * TC * (half + 1) && jp < n) {
+                            T tmp[8];
+                            wg_read<8>(Wl + (jp - L::CH * TC * half) * L::WSTR + 8 * c, tmp);
+#pragma unroll
+                            for (int k = 0; k < TC; k++)
+                                if (TC * c + k < n) gvt[(long)jp * n + TC * c + k] = tmp[k];
+                        }
+                    }
+                }
                 // W[TC c + k][j] = 0 for j > TC c + k: column groups beyond my own contribute nothing
                 const int cj0 = L::CH * half;
                 int cj1 = cj0 + L::CH - 1;
@@ -580,19 +653,21 @@ struct WgKernel {
             }
         }
 
-        T wt[TW][TC];
+        T vt[TW][TC];  // the tile of W' the iteration runs on (the W tile itself lives only inside the set-up block)
         T at[TR][TC];  // the A tile; turned into B = A W' in place once the factor is known
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         bool have_A = false;  // `at` currently holds A (as opposed to B)
-        if (!need_factor) load_sq_tile<T>(gW, n, r, c, wt);
         const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
         int iter = 1;
         // countdowns to the next termination check / rho adaptation (0 or disabled: never fires)
         int next_check = a.check_termination > 0 ? a.check_termination : -1;
         int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
         for (;;) {
+            {  // ---- set-up part of a pass; the W tile is a local of this block so that it is dead in the iteration loop
+            T wt[TW][TC];
+            if (!need_factor) load_sq_tile<T>(gW, n, r, c, wt);  // solve() on a previously set-up instance
             if (need_factor) {
                 __syncthreads();
                 if (t < L::MP) lds[L::O_RHO + t] = mown ? rho : T(0);
@@ -634,12 +709,18 @@ struct WgKernel {
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                build_B_inplace(at, wt, n_t, lds, r_t, c_t);
+                build_B_inplace(at, wt, gW + (long)n_t * n_t, n_t, lds, r_t, c_t);
+            }
+            }  // ---- end of the set-up part
+            {
+                int n_t = n, r_t = r, c_t = c;
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
+                load_vt(gW + (long)n_t * n_t, n_t, r_t, c_t, vt);
             }
             T (&bt)[TR][TC] = at;
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
             if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
-            if (t < L::NP) put_colv(lds, t, nown ? sigma * x - qv[t] : T(0));
+            if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - qv[t < L::NP ? t : 0] : T(0));
 #ifdef SQPH_PHASE_TIMING
             unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define SQPH_TICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
@@ -649,30 +730,26 @@ struct WgKernel {
             for (; iter <= a.max_iter; iter++) {
                 __syncthreads();
                 SQPH_TICK(0)
-                {   // stage 1 partials:  B' w (reduced over r)  and  W u (reduced over c)
-                    T w[TR], uu[TC];
+                {   // stage 1 partials:  B' w + W u, both reduced over r
+                    T w[TR], ur[TW];
                     get_rowv(lds, r, w);
-                    get_colv(lds, c, uu);
-                    stage_AT(bt, w, lds, r, c);
-                    stage_W(wt, uu, lds, r, c);
+                    get_wrow(lds, r, ur);
+                    stage1(bt, vt, w, ur, lds, r, c);
                 }
                 SQPH_TICK(1)
                 __syncthreads();
                 SQPH_TICK(2)
-                if (t < L::NR) {   // y1 = W u + B' w, published in both gather orders
-                    const T y1 = nown ? reduce_over_c(lds, t) + reduce_over_r(lds, t) : T(0);
-                    put_wrow(lds, r, c, y1);
-                    if (t < L::NP) put_colv2(lds, t, y1);
+                if (t < L::NP) {   // y1 = W u + B' w, published in column-gather order
+                    const T y1 = nown ? reduce_over_r(lds, t) : T(0);
+                    put_colv2(lds, t, y1);
                 }
                 SQPH_TICK(3)
                 __syncthreads();
                 SQPH_TICK(4)
-                {   // stage 2 partials:  z~ = B y1 (reduced over c)  and  x~ = W' y1 (reduced over r)
-                    T y1c[TC], y1r[TW];
+                {   // stage 2 partials:  z~ = B y1  and  x~ = W' y1, both reduced over c
+                    T y1c[TC];
                     get_colv2(lds, c, y1c);
-                    get_wrow(lds, r, y1r);
-                    stage_A(bt, y1c, lds, r, c);
-                    stage_WT(wt, y1r, lds, r, c);
+                    stage2(bt, vt, y1c, lds, r, c);
                 }
                 SQPH_TICK(5)
                 // the owner's constants do not depend on the partial sums: fetched before the barrier, their LDS latency
@@ -688,7 +765,7 @@ struct WgKernel {
                 SQPH_TICK(6)
                 // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
                 // SIMDs are issue-bound at two waves each (a branch-free variant measured 14 % slower)
-                if (nown) x = alpha * reduce_over_r(lds, t) + oma * x;
+                if (nown) x = alpha * reduce_xt(lds, t) + oma * x;
                 if (mown) {
                     const T zt = reduce_over_c(lds, t);
                     const T zr = alpha * zt + oma * z;
@@ -805,7 +882,7 @@ struct WgKernel {
                 }
                 // operands of the next iteration (the barrier at the loop top orders them before the gathers)
                 if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - c_rinv * y) : T(0));
-                if (t < L::NP) put_colv(lds, t, nown ? sigma * x - c_q : T(0));
+                if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - c_q : T(0));
                 SQPH_TICK(7)
             }
 #ifdef SQPH_PHASE_TIMING
@@ -949,18 +1026,20 @@ struct WgKernel {
             }
         }
 
-        T wt[TW][TC];
+        T vt[TW][TC];
         T at[TR][TC];
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         bool have_A = false;
-        if (!need_factor) load_sq_tile<T>(SQPH_GW, n, r, c, wt);
         const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
         int iter = 1;
         int next_check = a.check_termination > 0 ? a.check_termination : -1;
         int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
         for (;;) {
+            {  // ---- set-up part of a pass (the W tile is local to it)
+            T wt[TW][TC];
+            if (!need_factor) load_sq_tile<T>(SQPH_GW, n, r, c, wt);
             if (need_factor) {
                 wsync();
 #pragma unroll
@@ -1015,7 +1094,14 @@ struct WgKernel {
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                build_B_inplace(at, wt, n_t, lds, r_t, c_t);
+                T *gvt_t = a.Sinv + (long)qp * 2 * n_t * n_t + (long)n_t * n_t;
+                build_B_inplace(at, wt, gvt_t, n_t, lds, r_t, c_t);
+            }
+            }  // ---- end of the set-up part
+            {
+                int n_t = n, r_t = r, c_t = c, qp_t = qp;
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t); SQPH_OPAQUE_V(qp_t);
+                load_vt(a.Sinv + (long)qp_t * 2 * n_t * n_t + (long)n_t * n_t, n_t, r_t, c_t, vt);
             }
             T (&bt)[TR][TC] = at;
 #define SQPH_G_PUBLISH()                                                                                         \
@@ -1024,44 +1110,37 @@ struct WgKernel {
             const int i = t + GL * k;                                                                            \
             if (i < L::MP) lds[rowv_at(i)] = i < m ? rhos[i] * (zs[i] - rinvv[i] * ys[i]) : T(0);                   \
         }                                                                                                        \
-        _Pragma("unroll") for (int k = 0; k < NON; k++) {                                                        \
+        _Pragma("unroll") for (int k = 0; k < (L::NR + GL - 1) / GL; k++) {                                      \
             const int j = t + GL * k;                                                                            \
-            if (j < L::NP) put_colv(lds, j, j < n ? sigma * xs[j] - qv[j] : T(0));                                \
+            if (j < L::NR) lds[wrow_at(j)] = j < n ? sigma * xs[j] - qv[j] : T(0);                                \
         }                                                                                                        \
     }
             SQPH_G_PUBLISH()
             for (; iter <= a.max_iter; iter++) {
                 wsync();
                 {
-                    T w[TR], uu[TC];
+                    T w[TR], ur[TW];
                     get_rowv(lds, r, w);
-                    get_colv(lds, c, uu);
-                    stage_AT(bt, w, lds, r, c);
-                    stage_W(wt, uu, lds, r, c);
-                }
-                wsync();
-#pragma unroll
-                for (int k = 0; k < (L::NR + GL - 1) / GL; k++) {
-                    const int j = t + GL * k;
-                    if (j < L::NR) {  // the W-row gather is padded to R * TW >= NP entries: all of them must be defined
-                        const T y1 = j < n ? wg_sum<C>(lds + L::O_STAGE_Y + j * L::Cp) + wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0);
-                        lds[wrow_at(j)] = y1;
-                        if (j < L::NP) put_colv2(lds, j, y1);
-                    }
-                }
-                wsync();
-                {
-                    T y1c[TC], y1r[TW];
-                    get_colv2(lds, c, y1c);
-                    get_wrow(lds, r, y1r);
-                    stage_A(bt, y1c, lds, r, c);
-                    stage_WT(wt, y1r, lds, r, c);
+                    get_wrow(lds, r, ur);
+                    stage1(bt, vt, w, ur, lds, r, c);
                 }
                 wsync();
 #pragma unroll
                 for (int k = 0; k < NON; k++) {
                     const int j = t + GL * k;
-                    if (j < n) xs[j] = alpha * wg_sum<R>(lds + L::O_STAGE + j * L::Rp) + oma * xs[j];
+                    if (j < L::NP) put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0));
+                }
+                wsync();
+                {
+                    T y1c[TC];
+                    get_colv2(lds, c, y1c);
+                    stage2(bt, vt, y1c, lds, r, c);
+                }
+                wsync();
+#pragma unroll
+                for (int k = 0; k < NON; k++) {
+                    const int j = t + GL * k;
+                    if (j < n) xs[j] = alpha * reduce_xt(lds, j) + oma * xs[j];
                 }
 #pragma unroll
                 for (int k = 0; k < NOM; k++) {
