@@ -27,8 +27,14 @@ x, y, z, info = s.solution()
 # equal-sized records are what gather needs: pad the last shard like a capacity-sized device buffer
 cap = -(-total // world)
 pad = lambda a: torch.from_numpy(np.concatenate([a, np.zeros((cap - a.shape[0],) + a.shape[1:], a.dtype)]))
-g = ResultGather(world=world, rank=rank, tensors=[pad(x), pad(y), pad(info.iter.astype(np.int32).reshape(-1, 1))])
-g.gather()
+tx, ty, ti = pad(x), pad(y), pad(info.iter.astype(np.int32).reshape(-1, 1))
+g = ResultGather(world=world, rank=rank, tensors=[tx, ty, ti])
+# three batches through the two staging buffers (the third reuses the first one after its gather has completed);
+# the arrays change in between, as the solver state does from batch to batch
+keep = tx.clone()
+tx.mul_(0.5); g.gather()
+tx.mul_(3.0); g.gather()
+tx.copy_(keep); g.gather()
 if rank == 0:
     xs, ys, its = [t.numpy() for t in g.stacked()]
     rows = np.concatenate([np.arange(*shard_bounds(total, world, r)) - shard_bounds(total, world, r)[0] + r * cap for r in range(world)])
