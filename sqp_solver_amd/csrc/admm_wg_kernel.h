@@ -120,7 +120,10 @@ struct WgLayout {
     static constexpr int O_LOV = O_QV + NP;
     static constexpr int O_UPV = O_LOV + MP;
     static constexpr int O_RINV = O_UPV + MP;  // 1/rho of the owned constraint (changes only at a refactorisation)
-    static constexpr int TOTAL = O_RINV + MP;
+    // x~ partials of stage 2 ([R u + r][Cp]): a region of their own — stage 2 of a fast wave must not overwrite the stage-1
+    // partials a slower wave of the workgroup is still reducing (there is no workgroup barrier between the two stages)
+    static constexpr int O_STX = ev(O_RINV + MP);
+    static constexpr int TOTAL = O_STX + NR * Cp;
     static constexpr int slot(int j) { return 8 * (j / TC) + (j % TC); }
 };
 
@@ -132,6 +135,18 @@ struct WgKernel {
 
     // barrier of the lanes that work on one QP: the workgroup, or (NW == 0) a 16-lane group of a wavefront, whose LDS
     // operations execute in program order anyway — only the compiler has to be kept from reordering them
+    // ordering among the lanes of ONE wavefront (the R lanes of a column group always sit in one): LDS operations of a
+    // wave execute in program order, so this only pins the compiler
+    static __device__ __forceinline__ void wave_sync() {
+#ifdef SQPH_SIM
+        if constexpr (NW == 0 && NT < 64) wsync();
+        else ::sqph_sim::yield_wait(2);
+#else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+    }
     static __device__ __forceinline__ void wsync() {
         if constexpr (NW > 0) {
             __syncthreads();
@@ -234,8 +249,6 @@ struct WgKernel {
         for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = pb[k];
     }
     //   stage 2:  z~[R s + r] = sum_k B[.][TC c + k] y1[TC c + k] ,  x~[R u + r] = sum_k W[TC c + k][.] y1[TC c + k]   (both over c)
-    // x~ partials go to the (by now consumed) stage-1 area as [R u + r][Cp].
-    static_assert(L::NR * L::Cp <= L::STAGE_X, "x~ partials reuse the stage-1 area");
     static __device__ __forceinline__ void stage2(const T (&bt)[TR][TC], const T (&vt)[TW][TC], const T (&y1)[TC], T *lds, int r, int c) {
         T pz[TR];
 #pragma unroll
@@ -247,7 +260,7 @@ struct WgKernel {
         T *sty = lds + L::O_STAGE_Y;
 #pragma unroll
         for (int s = 0; s < TR; s++) sty[(R * s + r) * L::Cp + c] = pz[s];
-        T *stx = lds + L::O_STAGE;
+        T *stx = lds + L::O_STX;
 #pragma unroll
         for (int u = 0; u < TW; u++) {
             T acc = 0;
@@ -264,7 +277,7 @@ struct WgKernel {
             for (int k = 0; k < TC; k++) vt[u][k] = (jp < n && TC * c + k < n) ? gvt[(long)jp * n + TC * c + k] : T(0);
         }
     }
-    static __device__ __forceinline__ T reduce_xt(const T *lds, int i) { return wg_sum<C>(lds + L::O_STAGE + i * L::Cp); }
+    static __device__ __forceinline__ T reduce_xt(const T *lds, int i) { return wg_sum<C>(lds + L::O_STX + i * L::Cp); }
 
     // owner-side reductions (lane t owns output t)
     static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? t : 0) * L::Rp); }
@@ -737,14 +750,17 @@ struct WgKernel {
                     stage1(bt, vt, w, ur, lds, r, c);
                 }
                 SQPH_TICK(1)
-                __syncthreads();
+                // y1 = W u + B' w: the R producers of a column group's TC outputs and their consumers in stage 2 are the
+                // same R lanes of one wavefront, so the reduction is wave-local — lane r < TC of group c sums output
+                // TC c + r and publishes it for its group; no workgroup barrier between the two stages
+                wave_sync();
                 SQPH_TICK(2)
-                if (t < L::NP) {   // y1 = W u + B' w, published in column-gather order
-                    const T y1 = nown ? reduce_over_r(lds, t) : T(0);
-                    put_colv2(lds, t, y1);
+                if (r < TC) {
+                    const int j = TC * c + r;
+                    put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0));
                 }
                 SQPH_TICK(3)
-                __syncthreads();
+                wave_sync();
                 SQPH_TICK(4)
                 {   // stage 2 partials:  z~ = B y1  and  x~ = W' y1, both reduced over c
                     T y1c[TC];
