@@ -20,6 +20,8 @@
  *   primal_solution()/dual_solution()/info()  qp.hpp:160-170       sqph_get_solution / sqph_device_state
  *   settings()                    qp.hpp:166-167                   sqph_set_settings / sqph_get_settings
  *   static constr_type_init(l,u,type)  src/qp.cpp:283-294          sqph_constr_type_init (host utility)
+ *   legacy sparse QP<n,m> (Eigen::SparseMatrix A), setup/update_qp/solve
+ *                                 include/unsupported/qp_solver.hpp:17-32,215-330   sqph_*_csr (sqph_csr_batch: dense P, CSR A)
  *
  * Conventions
  *   - plain pointers and sizes only; no C++/torch types.  dtype selects Scalar.
