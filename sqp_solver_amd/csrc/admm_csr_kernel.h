@@ -40,7 +40,7 @@ template <int TT>
 struct CsrLayout {
     static constexpr int NP = 32 * TT;
     static constexpr int CS = ((TT + 1) & ~1) + 2;  // stride of one lane-group's slice of a gathered vector (16-B aligned)
-    static constexpr int SP = 33;                   // stride of one output's 32 partial sums (odd: conflict-free column writes)
+    static constexpr int SP = 34;                   // stride of one output's 32 partial sums (even: 16-B aligned quarters for b128 reads)
     static constexpr int LDP = NP + 1;              // S panel column stride
     static constexpr int ev(int x) { return (x + 1) & ~1; }
     // offsets in doubles
@@ -150,12 +150,14 @@ struct CsrKernel {
             T acc = 0;
 #pragma unroll
             for (int a = b; a < TT; a++) acc = wg_fma(w[idx(a, b)], yv[a], acc);
-            st[(c + 32 * b) * SP + r] = acc;
+            st[(c + 32 * b) * SP + ((r + c) & 31)] = acc;  // rotated inside the row: with the even stride the plain column
+                                                           // index would put lanes c and c+8 on the same banks; the sum is order-free
         }
     }
     // sum of the 32 partials of output j by the 4 lanes 4j..4j+3 (every lane of the quad gets the total)
     static __device__ __forceinline__ T quad_sum(const T *st, int j, int ql, int SP) {
-        const T *p = st + j * SP + 8 * ql;
+        T p[8];
+        wg_read<8>(st + j * SP + 8 * ql, p);  // ds_read_b128 moves twice the bytes per LDS cycle of ds_read2_b64
         T s0 = p[0] + p[4], s1 = p[1] + p[5], s2 = p[2] + p[6], s3 = p[3] + p[7];
         T s = (s0 + s1) + (s2 + s3);
         s += xchg<1>(s);
@@ -500,7 +502,7 @@ struct CsrKernel {
                     if (j < n) acc = wg_fma((T)gP[(long)j * n + i], xv[b], acc);
                 }
             }
-            st[(c + 32 * a) * SP + r] = acc;
+            st[(c + 32 * a) * SP + ((r + c) & 31)] = acc;
         }
     }
 
