@@ -258,15 +258,18 @@ struct WgKernel {
 #pragma unroll
             for (int s = 0; s < TR; s++) pz[s] = wg_fma(bt[s][k], y1[k], pz[s]);
         T *sty = lds + L::O_STAGE_Y;
+        // position inside a row rotated by r/8: with the even row stride lanes r and r+8 of a store would share banks;
+        // the owner sums the whole row, so the order is free
+        const int pos = (c + (r >> 3)) & (C - 1);
 #pragma unroll
-        for (int s = 0; s < TR; s++) sty[(R * s + r) * L::Cp + c] = pz[s];
+        for (int s = 0; s < TR; s++) sty[(R * s + r) * L::Cp + pos] = pz[s];
         T *stx = lds + L::O_STX;
 #pragma unroll
         for (int u = 0; u < TW; u++) {
             T acc = 0;
 #pragma unroll
             for (int k = 0; k < TC; k++) acc = wg_fma(vt[u][k], y1[k], acc);
-            stx[(R * u + r) * L::Cp + c] = acc;
+            stx[(R * u + r) * L::Cp + pos] = acc;
         }
     }
     static __device__ __forceinline__ void load_vt(const T *__restrict__ gvt, int n, int r, int c, T (&vt)[TW][TC]) {
