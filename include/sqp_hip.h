@@ -131,9 +131,7 @@ enum {
     SQPH_FLAG_LEGACY_COLD_START = 1,
     /* force the generic (global-memory) kernel even where a register-tiled one exists */
     SQPH_FLAG_FORCE_GENERIC = 2,
-    /* prefer the single-wave register-butterfly kernels (admm_tile_kernel.h) over the workgroup-tiled
-     * ones (admm_wg_kernel.h); kept for A/B measurements */
-    SQPH_FLAG_WAVE_TILE = 4,
+    /* (value 4 is retired: it selected a superseded single-wave kernel family) */
     /* CSR entry points: always expand A to dense on the device instead of using the native sparse kernel */
     SQPH_FLAG_CSR_EXPAND = 8
 };
@@ -170,7 +168,8 @@ int sqph_get_solution(sqph_solver *s, int batch, int memspace, void *x, void *y,
  * non-const primal_solution()/dual_solution() accessors). NULL = leave unchanged. */
 int sqph_set_state(sqph_solver *s, int batch, int memspace, const void *x, const void *z, const void *y);
 
-/* Device-resident state arrays (QP-major, valid until sqph_destroy): no copy. */
+/* Device-resident state arrays (QP-major, valid until sqph_destroy): no copy.  The arrays are fp64 whatever the
+ * solver's interface dtype (a QPSolver<float> iterates in fp64 on the device and narrows on the way out). */
 int sqph_device_state(sqph_solver *s, void **x, void **y, void **z, sqph_info **info);
 
 int sqph_synchronize(sqph_solver *s);

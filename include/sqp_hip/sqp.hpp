@@ -54,7 +54,10 @@ struct Info {
     Status status = MAX_ITER_EXCEEDED;
 };
 
-template <typename Scalar_>
+// QPBackend: the batched QP-subproblem solver (setup_solve / info / primal_solution / dual_solution over a packed
+// batch).  The product instantiates the default — qp_solver::BatchQPSolver, i.e. libsqp_hip; tests/cpp substitutes a
+// backend that calls the CPU oracle to separate "the host driver is exact" from "a QP rounding flipped a line search".
+template <typename Scalar_, typename QPBackend = qp_solver::BatchQPSolver<Scalar_>>
 class BatchSQP {
    public:
     using Scalar = Scalar_;
@@ -155,6 +158,7 @@ class BatchSQP {
                 Problem &prob = *probs[live[k]];
                 for (int a = 0; a < m; a++) I.p_lambda[a] -= I.lambda[a];
                 const Scalar alpha = line_search(I, prob);
+                if (trace_) trace_(trace_user_, live[k], iter, I.p.data(), I.p_lambda.data(), alpha, I.info.qp_solver_iter);
                 for (int a = 0; a < n; a++) I.x[a] += alpha * I.p[a];
                 for (int a = 0; a < m; a++) I.lambda[a] += alpha * I.p_lambda[a];
                 for (int a = 0; a < n; a++) I.step_prev[a] = alpha * I.p[a];
@@ -173,6 +177,11 @@ class BatchSQP {
             inst_[i].info.iter = settings_.max_iter + 1;
         }
     }
+
+    // Per-instance trajectory record, called once per outer iteration after the line search (the reference has no such
+    // hook; used by the parity tests to locate the first outer iteration at which two runs separate).
+    typedef void (*trace_fn)(void *user, int instance, int iter, const Scalar *p, const Scalar *p_lambda, Scalar alpha, int qp_iter);
+    void set_trace(trace_fn f, void *user) { trace_ = f; trace_user_ = user; }
 
     const Scalar *primal_solution(int i) const { return inst_[i].x.data(); }
     const Scalar *dual_solution(int i) const { return inst_[i].lambda.data(); }
@@ -313,7 +322,9 @@ class BatchSQP {
     int n_, m_, batch_;
     int launches_ = 0;
     Settings settings_;
-    qp_solver::BatchQPSolver<Scalar> qp_;
+    QPBackend qp_;
+    trace_fn trace_ = nullptr;
+    void *trace_user_ = nullptr;
     std::vector<Inst> inst_;
     std::vector<Scalar> P_, q_, A_, l_, u_;
 };

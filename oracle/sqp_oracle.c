@@ -17,6 +17,13 @@
 #include <stdio.h>
 #include <string.h>
 
+static sqpo_trace_fn g_trace = 0;
+static void *g_trace_user = 0;
+void sqpo_set_trace(sqpo_trace_fn f, void *user) {
+    g_trace = f;
+    g_trace_user = user;
+}
+
 /* sqp_settings_t defaults, sqp.hpp:13-23 */
 void sqpo_default_settings(sqpo_settings *s) {
     s->tau = 0.5;
@@ -215,6 +222,7 @@ void sqpo_solve(const sqpo_problem *prob, const sqpo_settings *settings, const d
         solve_qp(s, prob);
         for (int i = 0; i < m; i++) s->p_lambda[i] -= s->lambda[i];
         const double alpha = line_search(s, prob);
+        if (g_trace) g_trace(g_trace_user, iter, s->p, s->p_lambda, alpha, s->info.qp_solver_iter);
         for (int i = 0; i < n; i++) s->x[i] += alpha * s->p[i];
         for (int i = 0; i < m; i++) s->lambda[i] += alpha * s->p_lambda[i];
         for (int i = 0; i < n; i++) s->step_prev[i] = alpha * s->p[i];

@@ -28,6 +28,10 @@ typedef struct sqpo_problem {
 } sqpo_problem;
 
 void sqpo_default_settings(sqpo_settings *s);
+/* trajectory record, once per outer iteration after the line search (p_lambda is the dual STEP, sqp.cpp:79); NULL = off.
+ * Process-global (test infrastructure, single-threaded use). */
+typedef void (*sqpo_trace_fn)(void *user, int iter, const double *p, const double *p_lambda, double alpha, int qp_iter);
+void sqpo_set_trace(sqpo_trace_fn f, void *user);
 void sqpo_solve(const sqpo_problem *prob, const sqpo_settings *settings, const double *x0, const double *lambda0,
                 double *x_out, double *lambda_out, sqpo_info *info_out);
 

@@ -1,28 +1,12 @@
-// Host-side dispatch of the register-tiled kernels (admm_tile_kernel.h): picks the smallest
-// compiled tile shape {TR, TC} with m <= 8*TR and n <= 8*TC.
+// Host-side dispatch of the register-tiled kernels (admm_wg_kernel.h): first compiled shape that fits wins.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 
-#include "admm_tile_kernel.h"
 #include "admm_wg_kernel.h"
 
 namespace sqph {
-
-// >0: launched (name set), 0: shape not covered, <0: launch error
-template <typename T, typename TIN>
-inline int tile_try_launch(const KArgs<T, TIN> &a, hipStream_t stream, const char **name) {
-#define SQPH_TILE_CASE(TR_, TC_, L_, W_)                                                                        \
-    if (a.m <= 8 * TR_ && a.n <= 8 * TC_) {                                                                     \
-        hipLaunchKernelGGL((admm_tile_kernel<T, TIN, TR_, TC_, L_, W_>), dim3(a.batch), dim3(64), 0, stream, a); \
-        *name = "tile_" #TR_ "x" #TC_;                                                                      \
-        return hipGetLastError() == hipSuccess ? 1 : -1;                                                    \
-    }
-    SQPH_TILE_SHAPES(SQPH_TILE_CASE)
-#undef SQPH_TILE_CASE
-    return 0;
-}
 
 // four-QPs-per-wavefront kernels for small shapes (admm_wg_kernel.h, run_group): >0 launched, 0 not covered, <0 error
 template <typename TIN>

@@ -1,7 +1,7 @@
 // Generic ADMM kernel: one workgroup (1..4 wavefronts) per QP, runtime (n, m).
 //
 // This is the shape-agnostic fallback: matrices stay in global memory (L1/L2 resident while a
-// QP is being iterated), vectors live in LDS.  The register-tiled kernels in admm_tile.h are
+// QP is being iterated), vectors live in LDS.  The register-tiled kernels in admm_wg_kernel.h are
 // the fast path for the shapes they cover.  Algorithm = the reference ADMM
 // (/root/reference/src/qp.cpp:64-157) on the Schur-ordered KKT system: with R = diag(rho_vec)
 //     S = P + sigma I + A' R A = (W'W)^-1 (n x n, SPD)          [replaces the (n+m)^2 LDL^T, qp.cpp:159-259]

@@ -15,7 +15,7 @@
 #include "../../include/sqp_hip.h"
 #include "admm_generic.h"
 #include "admm_csr_kernel.h"
-#include "admm_tile.h"
+#include "admm_dispatch.h"
 #include "kargs.h"
 
 namespace {
@@ -62,7 +62,7 @@ constexpr size_t SMALL_CALL_BYTES = 4u << 20;
 template <typename TIN>
 __global__ void csr_expand(int batch, int n, int m, const int *__restrict__ rowptr, const int *__restrict__ colind,
                            const TIN *__restrict__ val, long long s_rowptr, long long s_colind, long long s_val,
-                           TIN *__restrict__ dst, int *__restrict__ bad) {
+                           long long nnz_cap, TIN *__restrict__ dst, int *__restrict__ bad) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)batch * m) return;
     const int b = (int)(t / m), i = (int)(t - (long long)b * m);
@@ -71,7 +71,7 @@ __global__ void csr_expand(int batch, int n, int m, const int *__restrict__ rowp
     const TIN *v = val + b * s_val;
     TIN *d = dst + (long long)b * m * n;
     const int e0 = rp[i], e1 = rp[i + 1];
-    if (e0 < 0 || e1 < e0) { atomicOr(bad, 1); return; }
+    if (e0 < 0 || e1 < e0 || e1 > nnz_cap || (i == 0 && e0 != 0)) { atomicOr(bad, 1); return; }  // as csr_check
     for (int e = e0; e < e1; e++) {
         const int j = ci[e];
         if (j < 0 || j >= n) { atomicOr(bad, 2); continue; }
@@ -241,12 +241,15 @@ int sqph_create(sqph_solver **out, int device, int n, int m, int batch_capacity,
     if (err == hipSuccess) {
         // every instance starts UNINITIALIZED (qp.hpp:74): status field = 4, rest 0
         sqph_info *h = new (std::nothrow) sqph_info[B];
-        if (h) {
-            memset(h, 0, B * sizeof(sqph_info));
-            for (size_t i = 0; i < B; i++) h[i].status = SQPH_UNINITIALIZED;
-            err = hipMemcpy(s->info, h, B * sizeof(sqph_info), hipMemcpyHostToDevice);
-            delete[] h;
+        if (!h) {
+            g_err = "sqph_create: out of host memory";
+            sqph_destroy(s);
+            return SQPH_ERR_INVALID;
         }
+        memset(h, 0, B * sizeof(sqph_info));
+        for (size_t i = 0; i < B; i++) h[i].status = SQPH_UNINITIALIZED;
+        err = hipMemcpy(s->info, h, B * sizeof(sqph_info), hipMemcpyHostToDevice);
+        delete[] h;
     }
     if (err != hipSuccess) {
         g_err = std::string("sqph_create: device allocation failed: ") + hipGetErrorString(err);
@@ -509,10 +512,9 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     }
     if (!launched && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
         int rc = 0;
-        if (!(s->flags & SQPH_FLAG_WAVE_TILE)) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
-        if (rc == 0 && !(s->flags & SQPH_FLAG_WAVE_TILE)) rc = g32_try_launch<TIN>(a, s->stream, &s->kernel_name);
-        if (rc == 0 && !(s->flags & SQPH_FLAG_WAVE_TILE)) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);
-        if (rc == 0) rc = tile_try_launch<T, TIN>(a, s->stream, &s->kernel_name);
+        rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
+        if (rc == 0) rc = g32_try_launch<TIN>(a, s->stream, &s->kernel_name);
+        if (rc == 0) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "tiled kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         launched = rc > 0;
     }
@@ -720,10 +722,10 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
     const unsigned blocks = (unsigned)((nexp * m + 255) / 256);
     if (s->dtype == SQPH_F32)
         hipLaunchKernelGGL((csr_expand<float>), dim3(blocks), dim3(256), 0, s->stream, (int)nexp, (int)n, (int)m, rowptr, colind,
-                           (const float *)val, s_row, s_col, s_val, (float *)s->cA, s->cBad);
+                           (const float *)val, s_row, s_col, s_val, (long long)c->nnz_max, (float *)s->cA, s->cBad);
     else
         hipLaunchKernelGGL((csr_expand<double>), dim3(blocks), dim3(256), 0, s->stream, (int)nexp, (int)n, (int)m, rowptr, colind,
-                           (const double *)val, s_row, s_col, s_val, (double *)s->cA, s->cBad);
+                           (const double *)val, s_row, s_col, s_val, (long long)c->nnz_max, (double *)s->cA, s->cBad);
     SQPH_HIP(s, hipGetLastError());
     int bad = 0;
     SQPH_HIP(s, hipMemcpyAsync(&bad, s->cBad, sizeof(int), hipMemcpyDeviceToHost, s->stream));

@@ -20,11 +20,13 @@ class _DevArray:
 
 
 def device_views(solver, device):
-    """torch tensors aliasing the solver's resident x [B,n], y [B,m], info bytes [B,40]."""
+    """torch tensors aliasing the solver's resident x [B,n], y [B,m], info bytes [B,40].
+
+    The resident state is fp64 whatever the solver's interface dtype (sqph_device_state, include/sqp_hip.h)."""
     import torch
 
     xp, yp, zp, ip = solver.device_state_ptrs()
-    ts = "<f8" if solver.dtype == np.float64 else "<f4"
+    ts = "<f8"
     B = solver.batch
     x = torch.as_tensor(_DevArray(xp, (B, solver.n), ts), device=device)
     y = torch.as_tensor(_DevArray(yp, (B, max(solver.m, 1)), ts), device=device)

@@ -3,7 +3,9 @@
 //   1. through the serial C oracle (oracle/sqp_oracle.c) — pins the oracle to the reference's known answers;
 //   2. through sqp::BatchSQP (include/sqp_hip/sqp.hpp): host SQP logic, all QP subproblems of an outer
 //      iteration solved by ONE libsqp_hip launch — compared per instance with the oracle.
-// `sqp_batch_test.bin oracle` runs part 1 only (no GPU needed).  Exit 0 = passed, 3 = no HIP device.
+//   3. through sqp::BatchSQP with a TEST-ONLY QP backend that calls the QP oracle: bit-identical to the serial oracle on
+//      every instance (the host driver is exact; what differs under 2. is QP rounding through a discontinuity).
+// `sqp_batch_test.bin oracle` runs part 1 only, `... exact` parts 1 and 3 (no GPU needed).  Exit 0 = passed, 3 = no HIP device.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -128,10 +130,22 @@ static void cb_con(void *u, const double *x, double *c, double *l, double *uu) {
 static void cb_conl(void *u, const double *x, double *J, double *c, double *l, double *uu) {
     static_cast<NLP *>(u)->constraint_linearized(x, J, c, l, uu);
 }
+struct TraceRec {  // one outer iteration of one instance: QP solution (primal step, dual step), step length, cumulative ADMM iterations
+    int iter, qp_iter;
+    double alpha;
+    std::vector<double> p, p_lambda;
+};
+typedef std::vector<TraceRec> Trace;
 struct OracleRun {
     std::vector<double> x, lambda;
     sqpo_info info;
+    Trace trace;
 };
+struct OracleTraceCtx { Trace *t; int n, m; };
+static void oracle_trace_cb(void *user, int iter, const double *p, const double *pl, double alpha, int qp_iter) {
+    OracleTraceCtx *c = static_cast<OracleTraceCtx *>(user);
+    c->t->push_back(TraceRec{iter, qp_iter, alpha, std::vector<double>(p, p + c->n), std::vector<double>(pl, pl + c->m)});
+}
 static OracleRun oracle_solve(NLP &p, const sqp::sqp_settings_t<double> &s, const double *x0, const double *l0) {
     sqpo_problem op = {p.num_var, p.num_constr, &p, cb_obj, cb_objl, cb_con, cb_conl};
     sqpo_settings os;
@@ -143,7 +157,10 @@ static OracleRun oracle_solve(NLP &p, const sqp::sqp_settings_t<double> &s, cons
     r.x.assign(p.num_var, 0);
     r.lambda.assign(p.num_constr, 0);
     std::vector<double> z0(p.num_var, 0), zl(p.num_constr, 0);
+    OracleTraceCtx ctx{&r.trace, p.num_var, p.num_constr};
+    sqpo_set_trace(oracle_trace_cb, &ctx);
     sqpo_solve(&op, &os, x0 ? x0 : z0.data(), l0 ? l0 : zl.data(), r.x.data(), r.lambda.data(), &r.info);
+    sqpo_set_trace(nullptr, nullptr);
     return r;
 }
 static bool is_approx(const double *a, const double *b, int k, double prec) {  // Eigen's isApprox
@@ -200,11 +217,136 @@ static void oracle_cases() {
     }
 }
 
+// ---------------------------------------------------------------- TEST-ONLY QP backend: the CPU oracle behind BatchSQP
+// Same surface as qp_solver::BatchQPSolver<double> as far as sqp::BatchSQP uses it.  With this backend the batched host
+// driver must reproduce the serial SQP oracle BIT FOR BIT on every instance: whatever differs with the GPU backend is then
+// attributable to the QP solutions' rounding, not to the driver (lock-step batching, live compaction, BFGS, SOC, line search).
+class OracleBatchQP {
+   public:
+    using Settings = qp_solver::QPSolverSettings<double>;
+    using Info = qp_solver::QPSolverInfo<double>;
+    struct Batch { int batch; const double *P, *q, *A, *l, *u; };
+    OracleBatchQP(int n, int m, int batch, int /*device*/ = 0) : n_(n), m_(m), x_((size_t)batch * n), y_((size_t)batch * (m > 0 ? m : 1)), info_(batch) {
+        qp_ = qpo_create_f64();
+    }
+    ~OracleBatchQP() { qpo_destroy_f64(qp_); }
+    OracleBatchQP(const OracleBatchQP &) = delete;
+    Settings &settings() { return settings_; }
+    Batch packed(int batch, const double *P, const double *q, const double *A, const double *l, const double *u) const { return Batch{batch, P, q, A, l, u}; }
+    void setup_solve(const Batch &b) {
+        qpo_settings *qs = qpo_settings_ptr_f64(qp_);
+        qs->rho = settings_.rho; qs->sigma = settings_.sigma; qs->alpha = settings_.alpha; qs->eps_rel = settings_.eps_rel; qs->eps_abs = settings_.eps_abs;
+        qs->max_iter = settings_.max_iter; qs->check_termination = settings_.check_termination; qs->warm_start = settings_.warm_start;
+        qs->adaptive_rho = settings_.adaptive_rho; qs->adaptive_rho_tolerance = settings_.adaptive_rho_tolerance;
+        qs->adaptive_rho_interval = settings_.adaptive_rho_interval; qs->verbose = 0;
+        const size_t n = n_, m = m_;
+        for (int k = 0; k < b.batch; k++) {
+            const double *P = b.P + k * n * n, *q = b.q + k * n, *A = b.A + k * m * n, *l = b.l + k * m, *u = b.u + k * m;
+            qpo_setup_f64(qp_, n_, m_, P, q, A, l, u);  // run_solve_qp: setup() then solve(), src/sqp.cpp:221-222
+            qpo_solve_f64(qp_, P, q, A, l, u);
+            const qpo_info *qi = qpo_info_ptr_f64(qp_);
+            info_[k].status = (qp_solver::QPSolverStatus)qi->status;
+            info_[k].iter = qi->iter;
+            std::memcpy(&x_[k * n], qpo_primal_f64(qp_), sizeof(double) * n);
+            if (m) std::memcpy(&y_[k * m], qpo_dual_f64(qp_), sizeof(double) * m);
+        }
+    }
+    const Info &info(int k) const { return info_[k]; }
+    const double *primal_solution(int k) const { return &x_[(size_t)k * n_]; }
+    const double *dual_solution(int k) const { return &y_[(size_t)k * m_]; }
+
+   private:
+    int n_, m_;
+    Settings settings_;
+    qpo_solver_f64 *qp_;
+    std::vector<double> x_, y_;
+    std::vector<Info> info_;
+};
+
+static int batch_exact(const char *name, NLP &prob, int batch, const std::vector<double> &X0, const std::vector<double> &L0, bool soc) {
+    const int n = prob.num_var, m = prob.num_constr;
+    sqp::BatchSQP<double, OracleBatchQP> solver(n, m, batch);
+    solver.settings().max_iter = 100;
+    solver.settings().second_order_correction = soc;
+    std::vector<NLP *> probs(batch, &prob);
+    solver.solve(probs, X0.data(), L0.data());
+    int exact = 0;
+    for (int i = 0; i < batch; i++) {
+        OracleRun r = oracle_solve(prob, solver.settings(), &X0[(size_t)i * n], &L0[(size_t)i * m]);
+        const sqp::Info &inf = solver.info(i);
+        const bool same = (int)inf.status == r.info.status && inf.iter == r.info.iter && inf.qp_solver_iter == r.info.qp_solver_iter &&
+                          !std::memcmp(solver.primal_solution(i), r.x.data(), sizeof(double) * n) &&
+                          (m == 0 || !std::memcmp(solver.dual_solution(i), r.lambda.data(), sizeof(double) * m));
+        if (same) exact++;
+        else if (batch - exact < 8)
+            fprintf(stderr, "  %s instance %d differs from the serial oracle: status %d/%d iter %d/%d qp_iter %d/%d\n", name, i, (int)inf.status,
+                    r.info.status, inf.iter, r.info.iter, inf.qp_solver_iter, r.info.qp_solver_iter);
+    }
+    printf("exact  %-28s N %5d bit-identical to the serial oracle: %d\n", name, batch, exact);
+    CHECK(exact == batch);
+    return batch;
+}
+
 // ---------------------------------------------------------------- batched driver vs oracle
 struct Lcg {
     unsigned long long s;
     double uni() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; }
 };
+
+// The batched workloads (used with both QP backends)
+struct Workload {
+    const char *name;
+    std::unique_ptr<NLP> prob;
+    int N;
+    std::vector<double> X0, L0, sol;
+    bool soc;
+    double min_solved_frac, min_strict, max_split;
+};
+static std::vector<Workload> workloads() {
+    std::vector<Workload> w;
+    {   // BASELINE config 4: 1,024 SimpleNLP instances, second-order correction on, started in a +-0.05 box around the two
+        // starts the reference's tests use (feasible (1.2, 0.1) with lambda0 = 0, infeasible (2, -1) with lambda0 = 1)
+        Workload k{"SimpleNLP x1024 (ref starts)", std::unique_ptr<NLP>(new SimpleNLP), 1024, {}, {}, {1, 1}, true, 0.7, 0.85, 0.08};
+        Lcg g{12345};
+        k.X0.resize(k.N * 2); k.L0.resize(k.N * 3);
+        for (int i = 0; i < k.N; i++) {
+            const bool feas = i < k.N / 2;
+            k.X0[2 * i + 0] = (feas ? 1.2 : 2.0) + 0.1 * (g.uni() - 0.5);
+            k.X0[2 * i + 1] = (feas ? 0.1 : -1.0) + 0.1 * (g.uni() - 0.5);
+            for (int c = 0; c < 3; c++) k.L0[3 * i + c] = feas ? 0.0 : 1.0;
+        }
+        w.push_back(std::move(k));
+    }
+    {   // the same NLP from wide random starts (SURVEY's x0 ~ U([0.2,2]^2)): the reference's SQP itself only converges on
+        // part of these, and runs that do not converge are 100-iteration chaotic trajectories
+        Workload k{"SimpleNLP x1024 (wide starts)", std::unique_ptr<NLP>(new SimpleNLP), 1024, {}, {}, {1, 1}, true, 0.5, 0.75, 0.15};
+        Lcg g{12345};
+        k.X0.resize(k.N * 2); k.L0.assign(k.N * 3, 0.0);
+        for (auto &v : k.X0) v = 0.2 + 1.8 * g.uni();
+        w.push_back(std::move(k));
+    }
+    {
+        Workload k{"Rosenbrock3 x256", std::unique_ptr<NLP>(new Rosenbrock(3)), 256, {}, {}, {1, 1, 1}, false, 0.0, 0.5, 0.3};
+        Lcg g{777};
+        k.X0.resize(k.N * 3); k.L0.assign(k.N * 3, 0.0);
+        for (auto &v : k.X0) v = g.uni();
+        w.push_back(std::move(k));
+    }
+    {
+        Workload k{"SimpleNLP2 x256", std::unique_ptr<NLP>(new SimpleNLP2), 256, {}, {}, {}, false, 0.0, 0.5, 0.3};
+        Lcg g{4242};
+        k.X0.resize(k.N * 2); k.L0.assign(k.N, 0.0);
+        for (auto &v : k.X0) v = -2 + 4 * g.uni();
+        w.push_back(std::move(k));
+    }
+    return w;
+}
+
+// host driver exactness: oracle QP backend behind BatchSQP == serial SQP oracle, bit for bit, on every instance (CPU only)
+static void exact_cases() {
+    for (auto &c : reference_cases()) batch_exact(c.name, *c.prob, 1, c.x0, c.y0, c.soc);
+    for (auto &w : workloads()) batch_exact(w.name, *w.prob, w.N, w.X0, w.L0, w.soc);
+}
 
 // Per-instance comparison with the serial oracle.  An SQP trajectory is not a continuous function of its QP solutions:
 // the merit weight mu = (...)/((1-rho)*constr_l1) is ~1e16 whenever the iterate is feasible (constr_l1 = eps,
@@ -217,6 +359,43 @@ struct Lcg {
 //   split  : anything else (the trajectories separated at a discontinuity and ended in different places)
 // at least `min_strict` of the batch must be strict, at most `max_split` may split, and the batch statistics (solved,
 // near-solution counts) of the two runs must agree within max_split as well.
+//
+// EVERY non-strict instance is then explained from the two per-iteration traces: at the first outer iteration whose
+// record differs, either
+//   line-search flip  : the QP solutions agree (|dp| <= 1e-6 max(1,|p|), |dp_lambda| <= 1e-5 max(1,|p_lambda|), same ADMM
+//                       iteration count) and only the accepted step length alpha differs, or
+//   termination flip  : the subproblem's ADMM iteration count differs by a multiple of check_termination (10) — its stop
+//                       test (eps 1e-4) was decided by the last digits of a residual — while every earlier record agrees;
+// anything else is `unexplained` and fails the test.  (With the oracle QP backend nothing differs at all: exact_cases.)
+struct BatchTraceCtx { std::vector<Trace> *t; int n, m; };
+static void batch_trace_cb(void *user, int inst, int iter, const double *p, const double *pl, double alpha, int qp_iter) {
+    BatchTraceCtx *c = static_cast<BatchTraceCtx *>(user);
+    (*c->t)[inst].push_back(TraceRec{iter, qp_iter, alpha, std::vector<double>(p, p + c->n), std::vector<double>(pl, pl + c->m)});
+}
+enum { DIV_NONE, DIV_LINE_SEARCH, DIV_TERMINATION, DIV_UNEXPLAINED };
+static int first_divergence(const Trace &a, const Trace &b, int *at, double *dp_out) {
+    const size_t K = a.size() < b.size() ? a.size() : b.size();
+    int prev_a = 0, prev_b = 0;
+    for (size_t k = 0; k < K; k++) {
+        const TraceRec &x = a[k], &y = b[k];
+        double dp = 0, sp = 1, dl = 0, sl = 1;
+        for (size_t e = 0; e < x.p.size(); e++) { dp = std::fmax(dp, std::fabs(x.p[e] - y.p[e])); sp = std::fmax(sp, std::fabs(y.p[e])); }
+        for (size_t e = 0; e < x.p_lambda.size(); e++) { dl = std::fmax(dl, std::fabs(x.p_lambda[e] - y.p_lambda[e])); sl = std::fmax(sl, std::fabs(y.p_lambda[e])); }
+        const int qa = x.qp_iter - prev_a, qb = y.qp_iter - prev_b;  // ADMM iterations of this outer iteration's subproblem(s)
+        prev_a = x.qp_iter; prev_b = y.qp_iter;
+        const bool qp_same = qa == qb && dp <= 1e-6 * sp && dl <= 1e-5 * sl;
+        if (qp_same && x.alpha == y.alpha) continue;
+        *at = (int)k + 1;
+        *dp_out = dp;
+        if (qp_same) return DIV_LINE_SEARCH;
+        if (qa != qb && (qa - qb) % 10 == 0) return DIV_TERMINATION;
+        return DIV_UNEXPLAINED;
+    }
+    *at = (int)K + 1;
+    *dp_out = 0;
+    return a.size() == b.size() ? DIV_NONE : DIV_UNEXPLAINED;
+}
+
 static int batch_vs_oracle(const char *name, NLP &prob, int batch, const std::vector<double> &X0, const std::vector<double> &L0,
                            bool soc, const double *solution, double min_solved_frac, double min_strict = 0.9, double max_split = 0.0) {
     const int n = prob.num_var, m = prob.num_constr;
@@ -224,11 +403,15 @@ static int batch_vs_oracle(const char *name, NLP &prob, int batch, const std::ve
     solver.settings().max_iter = 100;
     solver.settings().second_order_correction = soc;
     std::vector<NLP *> probs(batch, &prob);
+    std::vector<Trace> bt(batch);
+    BatchTraceCtx tctx{&bt, n, m};
+    solver.set_trace(batch_trace_cb, &tctx);
     const auto t0 = std::chrono::steady_clock::now();
     solver.solve(probs, X0.data(), L0.data());
     const auto t1 = std::chrono::steady_clock::now();
     int solved = 0, strict = 0, loose = 0, near_solution = 0, bad = 0, osolved = 0, onear_solution = 0;
-    double worst_x = 0, worst_l = 0;
+    int n_ls = 0, n_term = 0, n_unexpl = 0, n_late = 0;
+    double worst_x = 0, worst_l = 0, worst_dp_at_flip = 0;
     for (int i = 0; i < batch; i++) {
         OracleRun r = oracle_solve(prob, solver.settings(), &X0[(size_t)i * n], &L0[(size_t)i * m]);
         const sqp::Info &inf = solver.info(i);
@@ -247,21 +430,34 @@ static int batch_vs_oracle(const char *name, NLP &prob, int batch, const std::ve
             strict++;
             worst_x = std::fmax(worst_x, dx);
             worst_l = std::fmax(worst_l, dl);
-        } else if ((inf.status == sqp::SOLVED && r.info.status == SQPO_SOLVED && dx <= 1e-3) || (near && onear)) {
-            loose++;
-        } else {
-            bad++;
-            if (bad <= 8) fprintf(stderr, "  instance %d: status %d/%d iter %d/%d qp_iter %d/%d dx %.3e dl %.3e\n", i, (int)inf.status, r.info.status,
-                    inf.iter, r.info.iter, inf.qp_solver_iter, r.info.qp_solver_iter, dx, dl);
+            continue;
         }
+        const bool is_loose = (inf.status == sqp::SOLVED && r.info.status == SQPO_SOLVED && dx <= 1e-3) || (near && onear);
+        if (is_loose) loose++;
+        else bad++;
+        int at = 0;
+        double dp = 0;
+        const int why = first_divergence(bt[i], r.trace, &at, &dp);
+        if (why == DIV_LINE_SEARCH) { n_ls++; worst_dp_at_flip = std::fmax(worst_dp_at_flip, dp); }
+        else if (why == DIV_TERMINATION) n_term++;
+        else if (why == DIV_NONE) n_late++;  // every record agrees within the QP bar: the end points differ by accumulated 1e-6-level drift only
+        else n_unexpl++;
+        if (why == DIV_UNEXPLAINED || (!is_loose && bad <= 4))
+            fprintf(stderr, "  instance %d (%s): status %d/%d iter %d/%d qp_iter %d/%d dx %.3e dl %.3e | first divergence at outer iteration %d: %s (|dp| %.2e)\n",
+                    i, is_loose ? "loose" : "split", (int)inf.status, r.info.status, inf.iter, r.info.iter, inf.qp_solver_iter, r.info.qp_solver_iter, dx, dl, at,
+                    why == DIV_LINE_SEARCH ? "line-search flip" : why == DIV_TERMINATION ? "ADMM termination-check flip" : why == DIV_NONE ? "none (drift)" : "UNEXPLAINED", dp);
     }
     printf("batch  %-28s N %5d launches %4d solved %5d near-solution %5d | strict %5d (max|dx| %.2e max|dlambda| %.2e) loose %d split %d | oracle solved %d near-solution %d\n",
            name, batch, solver.qp_launches(), solved, near_solution, strict, worst_x, worst_l, loose, bad, osolved, onear_solution);
+    if (loose + bad)
+        printf("       non-strict instances explained: line-search flip %d (max |dp| at the flip %.2e), ADMM termination-check flip %d, drift only %d, UNEXPLAINED %d\n",
+               n_ls, worst_dp_at_flip, n_term, n_late, n_unexpl);
     const auto t2 = std::chrono::steady_clock::now();
     if (batch > 1)
         printf("       wall: batched driver %.1f ms (%.0f instances/s), serial oracle %.1f ms (%.0f instances/s, 1 thread)\n",
                std::chrono::duration<double, std::milli>(t1 - t0).count(), batch / std::chrono::duration<double>(t1 - t0).count(),
                std::chrono::duration<double, std::milli>(t2 - t1).count(), batch / std::chrono::duration<double>(t2 - t1).count());
+    CHECK(n_unexpl == 0);
     CHECK(bad <= max_split * batch);
     CHECK(std::abs(solved - osolved) <= max_split * batch);
     CHECK(std::abs(near_solution - onear_solution) <= max_split * batch);
@@ -274,58 +470,19 @@ static int batch_vs_oracle(const char *name, NLP &prob, int batch, const std::ve
 static void gpu_cases() {
     // every reference case as a batch of one
     for (auto &c : reference_cases()) batch_vs_oracle(c.name, *c.prob, 1, c.x0, c.y0, c.soc, c.known ? c.solution.data() : nullptr, c.known ? 1.0 : 0.0, 0.0);
-    // BASELINE config 4: 1,024 SimpleNLP instances, second-order correction on, started in a +-0.05 box around the two
-    // starts the reference's tests use (feasible (1.2, 0.1) with lambda0 = 0, infeasible (2, -1) with lambda0 = 1)
-    {
-        SimpleNLP p;
-        const int N = 1024;
-        Lcg g{12345};
-        std::vector<double> X0(N * 2), L0(N * 3);
-        for (int i = 0; i < N; i++) {
-            const bool feas = i < N / 2;
-            X0[2 * i + 0] = (feas ? 1.2 : 2.0) + 0.1 * (g.uni() - 0.5);
-            X0[2 * i + 1] = (feas ? 0.1 : -1.0) + 0.1 * (g.uni() - 0.5);
-            for (int k = 0; k < 3; k++) L0[3 * i + k] = feas ? 0.0 : 1.0;
-        }
-        const double sol[2] = {1, 1};
-        // (the reference's SQP reaches (1,1) from only ~77% of these starts — oracle and GPU runs alike — and ~4% of the
-        // trajectories split at a line-search discontinuity; the batch statistics agree to a few instances)
-        batch_vs_oracle("SimpleNLP x1024 (ref starts)", p, N, X0, L0, true, sol, 0.7, 0.85, 0.08);
-    }
-    // the same NLP from wide random starts: the reference's SQP itself only converges on part of these, and runs that
-    // do not converge are 100-iteration chaotic trajectories — compared statistically
-    {
-        SimpleNLP p;
-        const int N = 1024;
-        Lcg g{12345};
-        std::vector<double> X0(N * 2), L0(N * 3, 0.0);
-        for (auto &v : X0) v = 0.2 + 1.8 * g.uni();
-        const double sol[2] = {1, 1};
-        batch_vs_oracle("SimpleNLP x1024 (wide starts)", p, N, X0, L0, true, sol, 0.5, 0.75, 0.15);
-    }
-    {
-        Rosenbrock p(3);
-        const int N = 256;
-        Lcg g{777};
-        std::vector<double> X0(N * 3), L0(N * 3, 0.0);
-        for (auto &v : X0) v = g.uni();
-        const double sol[3] = {1, 1, 1};
-        batch_vs_oracle("Rosenbrock3 x256", p, N, X0, L0, false, sol, 0.0, 0.5, 0.3);
-    }
-    {
-        SimpleNLP2 p;
-        const int N = 256;
-        Lcg g{4242};
-        std::vector<double> X0(N * 2), L0(N, 0.0);
-        for (auto &v : X0) v = -2 + 4 * g.uni();
-        batch_vs_oracle("SimpleNLP2 x256", p, N, X0, L0, false, nullptr, 0.0, 0.5, 0.3);
-    }
+    for (auto &w : workloads())
+        batch_vs_oracle(w.name, *w.prob, w.N, w.X0, w.L0, w.soc, w.sol.empty() ? nullptr : w.sol.data(), w.min_solved_frac, w.min_strict, w.max_split);
 }
 
 int main(int argc, char **argv) {
     oracle_cases();
     if (argc > 1 && !strcmp(argv[1], "oracle")) {
         printf("oracle cases passed\n");
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "exact")) {
+        exact_cases();
+        printf("exact cases passed\n");
         return 0;
     }
     try {

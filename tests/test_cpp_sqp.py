@@ -21,7 +21,8 @@ def build():
     oracle.build()
     libdir = os.path.dirname(_capi.lib_path())
     odir = os.path.join(ROOT, "oracle")
-    deps = [SRC, os.path.join(ROOT, "include", "sqp_hip", "sqp.hpp"), os.path.join(ROOT, "include", "sqp_hip", "qp.hpp")]
+    deps = [SRC, os.path.join(ROOT, "include", "sqp_hip", "sqp.hpp"), os.path.join(ROOT, "include", "sqp_hip", "qp.hpp"),
+            os.path.join(odir, "libqp_oracle.so"), _capi.lib_path()]
     if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
         return EXE
     cmd = ["g++", "-std=c++14", "-O1", "-o", EXE, SRC, "-L" + odir, "-lqp_oracle", "-L" + libdir, "-lsqp_hip",
@@ -35,6 +36,14 @@ def test_sqp_oracle_reproduces_reference_known_answers():
     p = subprocess.run([exe, "oracle"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "oracle cases passed" in p.stdout
+
+
+def test_batch_sqp_host_driver_is_bit_exact_with_the_oracle_qp_backend():
+    """sqp::BatchSQP<double, OracleBatchQP> (tests/cpp) == serial SQP oracle, bit for bit, on every instance of every
+    workload (reference cases, 2 x 1,024 SimpleNLP, 256 Rosenbrock3, 256 SimpleNLP2)."""
+    p = subprocess.run([build(), "exact"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "exact cases passed" in p.stdout
 
 
 def test_batch_sqp_refuses_without_device():

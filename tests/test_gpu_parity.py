@@ -299,3 +299,50 @@ def test_api_misuse_errors():
         s.setup(P[:2], q[:2], A[:2], l[:2], u[:2])
     with pytest.raises(SqphError):
         QPSolverBatch(0, 1, 1)
+
+
+def _stress_log(rec):
+    import json
+
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "stress_metrics.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
+@pytest.mark.parametrize("make", MAKERS, ids=IDS)
+@pytest.mark.parametrize("kind", cases.STRESS_KINDS)
+@pytest.mark.parametrize("n,m,batch", [(20, 40, 32), (50, 100, 32)])
+def test_stress_parity(n, m, batch, kind, make):
+    """rho at its clamps, equality-heavy and ill-conditioned batches against the oracle (and its x87 yard-stick)"""
+    cases.stress_parity(make, n, m, batch, kind, log=_stress_log)
+
+
+def test_stress_parity_sparse_shape():
+    """the same stress kinds on the config-5 shape through the native sparse kernel"""
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    n, m, B = 200, 400, 4
+    for kind in ("rho_low", "rho_high", "half_eq"):
+        P, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=0.05, seed=21)
+        if kind == "half_eq":
+            # equalities on every other row, feasible by construction: both bounds at the row's midpoint
+            fin = np.isfinite(l) & np.isfinite(u) & (np.abs(l) < 1e19)
+            c = np.where(fin, 0.5 * (l + u), 0.0)
+            eq = fin & (np.arange(m) % 2 == 0)[None, :]
+            l, u = np.where(eq, c, l), np.where(eq, c, u)
+        s = make_gpu(n, m, B)
+        cases.stress_settings(s.settings, kind, 100)
+        s.setup_solve_csr(P, q, rp, ci, v, l, u)
+        assert s.kernel_name() == "csr_t7"
+        x, y, z, info = s.solution()
+        ost = cases.oracle_settings(s.settings)
+        xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, ost)
+        ld = np.longdouble
+        xl, yl, _, _ = oracle.solve_batch(P.astype(ld), q.astype(ld), A.astype(ld), l.astype(ld), u.astype(ld), ost, dtype=ld)
+        noise = max(cases.relerr(xo, xl.astype(np.float64)), cases.relerr(yo, yl.astype(np.float64)))
+        tol = max(cases.TOL_F64, 4 * noise)
+        rec = dict(kind=kind + "_csr", n=n, m=m, batch=B, ex=cases.relerr(x, xo), ey=cases.relerr(y, yo), noise=noise, tol=tol)
+        _stress_log(rec)
+        assert rec["ex"] < tol and rec["ey"] < tol, rec
+        assert (info.rho_updates == io["rho_updates"]).all() and (info.iter == io["iter"]).all()
