@@ -158,7 +158,10 @@ class BatchSQP {
                 Problem &prob = *probs[live[k]];
                 for (int a = 0; a < m; a++) I.p_lambda[a] -= I.lambda[a];
                 const Scalar alpha = line_search(I, prob);
-                if (trace_) trace_(trace_user_, live[k], iter, I.p.data(), I.p_lambda.data(), alpha, I.info.qp_solver_iter);
+                if (trace_) {
+                    const Scalar *const qpv[6] = {I.Hess.data(), I.grad_obj.data(), I.Jac.data(), I.ql.data(), I.qu.data(), I.lambda.data()};
+                    trace_(trace_user_, live[k], iter, I.p.data(), I.p_lambda.data(), alpha, I.info.qp_solver_iter, qpv);
+                }
                 for (int a = 0; a < n; a++) I.x[a] += alpha * I.p[a];
                 for (int a = 0; a < m; a++) I.lambda[a] += alpha * I.p_lambda[a];
                 for (int a = 0; a < n; a++) I.step_prev[a] = alpha * I.p[a];
@@ -180,7 +183,10 @@ class BatchSQP {
 
     // Per-instance trajectory record, called once per outer iteration after the line search (the reference has no such
     // hook; used by the parity tests to locate the first outer iteration at which two runs separate).
-    typedef void (*trace_fn)(void *user, int instance, int iter, const Scalar *p, const Scalar *p_lambda, Scalar alpha, int qp_iter);
+    // `qp` = the five arrays (P, q, A, l, u; column-major) of the last QP subproblem of that outer iteration, then the
+    // multiplier estimate lambda the dual step was taken from (QP dual = p_lambda + lambda).
+    typedef void (*trace_fn)(void *user, int instance, int iter, const Scalar *p, const Scalar *p_lambda, Scalar alpha, int qp_iter,
+                             const Scalar *const qp[6]);
     void set_trace(trace_fn f, void *user) { trace_ = f; trace_user_ = user; }
 
     const Scalar *primal_solution(int i) const { return inst_[i].x.data(); }
