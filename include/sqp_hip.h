@@ -133,7 +133,12 @@ enum {
     SQPH_FLAG_FORCE_GENERIC = 2,
     /* (value 4 is retired: it selected a superseded single-wave kernel family) */
     /* CSR entry points: always expand A to dense on the device instead of using the native sparse kernel */
-    SQPH_FLAG_CSR_EXPAND = 8
+    SQPH_FLAG_CSR_EXPAND = 8,
+    /* Keep the KKT factor of a fused sqph_setup_solve* call resident in the workspace (n*n doubles written per QP).  Without
+     * it a fused call writes no factor, and a later sqph_solve* on that handle rebuilds the factor first — same arithmetic,
+     * same results, one extra factorisation.  sqph_setup / sqph_update_qp always leave their factor resident.  Set this for
+     * callers that follow a fused call with sqph_solve on new q, l, u (SQP second-order correction, MPC). */
+    SQPH_FLAG_KEEP_FACTOR = 16
 };
 
 void sqph_default_settings(sqph_settings *s);

@@ -602,7 +602,7 @@ struct CsrKernel {
         SQPH_CTICK(0)
 
         T w[NE];
-        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
+        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         if (!need_factor) {
@@ -641,7 +641,7 @@ struct CsrKernel {
                     SQPH_CTICK(1)
                     ok = eliminate(n_f, L, lds, tf, w);
                     SQPH_CTICK(2)
-                    store_tile(gW, n_f, tf >> 5, tf & 31, w);
+                    if (!(mode & MODE_NO_FACTOR_STORE)) store_tile(gW, n_f, tf >> 5, tf & 31, w);  // kept for later solve() calls
                 }
                 __syncthreads();
                 {   // pick the parked iterates up again
@@ -654,7 +654,8 @@ struct CsrKernel {
                 }
                 need_factor = false;
                 if (!solving) {
-                    info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
+                    if (mode & (MODE_SETUP | MODE_UPDATE)) info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
+                    else if (!ok) info.status = SQPH_NUMERICAL_ISSUES;  // solve() rebuilding a factor that was not kept
                 } else if (!ok) {
                     info.status = SQPH_NUMERICAL_ISSUES;  // qp.cpp:139-142
                     break;

@@ -115,15 +115,17 @@ struct WgLayout {
     static constexpr int SETUP = O_WL + CH * TC * WSTR;
     static constexpr int O_RED = O_STAGE + MP + 2 * NP + 16;  // workgroup max scratch (residual checks)
     static constexpr int STAGE = mx(STAGE_X + STAGE_Y, MP + 2 * NP + 16 + 8 * NW);
-    // per-element constants of the owners (q, l, u): LDS instead of VGPRs, after everything that is aliased
-    static constexpr int O_QV = ev(mx(O_STAGE + STAGE, SETUP));
+    // x~ partials of stage 2 ([R u + r][Cp]): a region of their own — stage 2 of a fast wave must not overwrite the stage-1
+    // partials a slower wave of the workgroup is still reducing (there is no workgroup barrier between the two stages)
+    // (the aliased region below the owners' constants is also made large enough to stage all of W for the W -> W' transposition)
+    static constexpr int O_STX = ev(mx(mx(O_STAGE + STAGE, SETUP), NP * WSTR - NR * Cp));
+    // per-element constants of the owners (q, l, u): LDS instead of VGPRs, after everything the set-up may alias
+    static constexpr int O_QV = ev(O_STX + NR * Cp);
     static constexpr int O_LOV = O_QV + NP;
     static constexpr int O_UPV = O_LOV + MP;
     static constexpr int O_RINV = O_UPV + MP;  // 1/rho of the owned constraint (changes only at a refactorisation)
-    // x~ partials of stage 2 ([R u + r][Cp]): a region of their own — stage 2 of a fast wave must not overwrite the stage-1
-    // partials a slower wave of the workgroup is still reducing (there is no workgroup barrier between the two stages)
-    static constexpr int O_STX = ev(O_RINV + MP);
-    static constexpr int TOTAL = O_STX + NR * Cp;
+    static constexpr int TOTAL = ev(O_RINV + MP);
+    static_assert(NP * WSTR <= O_QV, "W -> W' transposition stages all of W in [0, O_QV)");
     static constexpr int slot(int j) { return 8 * (j / TC) + (j % TC); }
 };
 
@@ -272,14 +274,6 @@ struct WgKernel {
             stx[(R * u + r) * L::Cp + pos] = acc;
         }
     }
-    static __device__ __forceinline__ void load_vt(const T *__restrict__ gvt, int n, int r, int c, T (&vt)[TW][TC]) {
-#pragma unroll
-        for (int u = 0; u < TW; u++) {
-            const int jp = R * u + r;
-#pragma unroll
-            for (int k = 0; k < TC; k++) vt[u][k] = (jp < n && TC * c + k < n) ? gvt[(long)jp * n + TC * c + k] : T(0);
-        }
-    }
     static __device__ __forceinline__ T reduce_xt(const T *lds, int i) { return wg_sum<C>(lds + L::O_STX + i * L::Cp); }
 
     // owner-side reductions (lane t owns output t)
@@ -325,8 +319,7 @@ struct WgKernel {
     // B = A W' IN PLACE over the A tile (bt[s][k] = sum_j A[R s + r][j] * W[TC c + k][j], W lower triangular).
     // W is staged once (transposed) in LDS from the register tile, A goes through LDS one block of R rows at
     // a time — nothing is re-read from global memory.
-    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], T *__restrict__ gvt, int n, T *lds, int r,
-                                                           int c) {
+    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c) {
         T *As = lds + L::O_AS, *Wl = lds + L::O_WL;
         const int myhalf = c / L::CH, cl = c - myhalf * L::CH;  // my column group inside its half
 
@@ -353,23 +346,6 @@ struct WgKernel {
                     }
                 }
                 wsync();
-                if (s == 0) {
-                    // the tile of W' in the tile layout (rows cyclic over r, columns blocked by c) for the iteration loop,
-                    // vt[u][k] = W[TC c + k][R u + r], is picked from the staged half that holds column R u + r and parked
-                    // in this lane's slots of the workspace (same thread writes and reads: no coherence question) — it
-                    // must not be live in registers next to the A / W tiles of the set-up
-#pragma unroll
-                    for (int u = 0; u < TW; u++) {
-                        const int jp = R * u + r;
-                        if (jp >= L::CH * TC * half && jp < L::CH * TC * (half + 1) && jp < n) {
-                            T tmp[8];
-                            wg_read<8>(Wl + (jp - L::CH * TC * half) * L::WSTR + 8 * c, tmp);
-#pragma unroll
-                            for (int k = 0; k < TC; k++)
-                                if (TC * c + k < n) gvt[(long)jp * n + TC * c + k] = tmp[k];
-                        }
-                    }
-                }
                 // W[TC c + k][j] = 0 for j > TC c + k: column groups beyond my own contribute nothing
                 const int cj0 = L::CH * half;
                 int cj1 = cj0 + L::CH - 1;
@@ -391,6 +367,36 @@ struct WgKernel {
             }
 #pragma unroll
             for (int k = 0; k < TC; k++) at[s][k] = acc[k];
+        }
+        // The tile of W' in the tile layout (rows cyclic over r, columns blocked by c) for the iteration loop,
+        // vt[u][k] = W[TC c + k][R u + r]: a transposition of the W tile through the same staging area, half of W's columns
+        // at a time.  It comes last so that vt is not live in registers next to the accumulators of the loop above (the W
+        // tile is dead after its owner's half has been staged).  Nothing goes through global memory.
+        // First half of the W -> W' transposition: every lane stages its W tile (dead afterwards) in [0, NP * WSTR); the W' tile
+        // is picked up by load_vt_lds() once the set-up block — and with it the W tile's registers — has ended.  (Computing vt
+        // inside this block, next to the live W tile, put 20 tile registers of the iteration loop into scratch.)
+        T *Wf = lds;
+        wsync();
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const int i = R * u + r;
+            if (i < L::NP) {
+#pragma unroll
+                for (int k = 0; k < TC; k++) Wf[(TC * c + k) * L::WSTR + L::slot(i)] = wt[u][k];
+            }
+        }
+    }
+    // second half of the W -> W' transposition: vt[u][k] = W[TC c + k][R u + r] from the staged copy (the tile of W' in the tile
+    // layout — rows cyclic over r, columns blocked by c — that the iteration loop runs on).  Nothing goes through global memory.
+    static __device__ __forceinline__ void load_vt_lds(T *lds, int n, int r, int c, T (&vt)[TW][TC]) {
+        wsync();
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const int jp = R * u + r;
+            T tmp[8];
+            wg_read<8>(lds + (jp < L::NP ? jp : 0) * L::WSTR + 8 * c, tmp);
+#pragma unroll
+            for (int k = 0; k < TC; k++) vt[u][k] = (jp < n && TC * c + k < n) ? tmp[k] : T(0);
         }
         wsync();
     }
@@ -671,7 +677,7 @@ struct WgKernel {
 
         T vt[TW][TC];  // the tile of W' the iteration runs on (the W tile itself lives only inside the set-up block)
         T at[TR][TC];  // the A tile; turned into B = A W' in place once the factor is known
-        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
+        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         bool have_A = false;  // `at` currently holds A (as opposed to B)
@@ -694,12 +700,14 @@ struct WgKernel {
                 SQPH_OPAQUE_S(gA_f); SQPH_OPAQUE_S(gP_f);
                 load_A_tile(gA_f, n_f, m_f, r_f, c_f, at);  // the only read of A from global memory per factorisation
                 const bool ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt);
-                store_sq_tile(gW, n_f, r_f, c_f, wt);
+                // the factor is kept for later solve() calls unless the host asked for a fused setup+solve without it
+                if (!(mode & MODE_NO_FACTOR_STORE)) store_sq_tile(gW, n_f, r_f, c_f, wt);
                 __syncthreads();
                 need_factor = false;
                 have_A = true;
                 if (!solving) {
-                    info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
+                    if (mode & (MODE_SETUP | MODE_UPDATE)) info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
+                    else if (!ok) info.status = SQPH_NUMERICAL_ISSUES;  // solve() rebuilding a factor that was not kept
                 } else if (!ok) {
                     info.status = SQPH_NUMERICAL_ISSUES;  // qp.cpp:139-142: break, iter not advanced
                     break;
@@ -725,13 +733,13 @@ struct WgKernel {
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                build_B_inplace(at, wt, gW + (long)n_t * n_t, n_t, lds, r_t, c_t);
+                build_B_inplace(at, wt, n_t, lds, r_t, c_t);
             }
             }  // ---- end of the set-up part
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                load_vt(gW + (long)n_t * n_t, n_t, r_t, c_t, vt);
+                load_vt_lds(lds, n_t, r_t, c_t, vt);
             }
             T (&bt)[TR][TC] = at;
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
@@ -1047,7 +1055,7 @@ struct WgKernel {
 
         T vt[TW][TC];
         T at[TR][TC];
-        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE)) != 0;
+        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         bool have_A = false;
@@ -1073,13 +1081,14 @@ struct WgKernel {
                     SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(m_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_V(t_f); SQPH_OPAQUE_V(qp_f);
                     load_A_tile(a.A + (long)qp_f * a.sA, n_f, m_f, r_f, c_f, at);
                     ok = factor(a.P + (long)qp_f * a.sP, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt);
-                    store_sq_tile(a.Sinv + (long)qp_f * 2 * n_f * n_f, n_f, r_f, c_f, wt);
+                    if (!(mode & MODE_NO_FACTOR_STORE)) store_sq_tile(a.Sinv + (long)qp_f * 2 * n_f * n_f, n_f, r_f, c_f, wt);
                 }
                 wsync();
                 need_factor = false;
                 have_A = true;
                 if (!solving) {
-                    info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;
+                    if (mode & (MODE_SETUP | MODE_UPDATE)) info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;
+                    else if (!ok) info.status = SQPH_NUMERICAL_ISSUES;
                 } else if (!ok) {
                     info.status = SQPH_NUMERICAL_ISSUES;
                     break;
@@ -1113,14 +1122,13 @@ struct WgKernel {
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                T *gvt_t = a.Sinv + (long)qp * 2 * n_t * n_t + (long)n_t * n_t;
-                build_B_inplace(at, wt, gvt_t, n_t, lds, r_t, c_t);
+                build_B_inplace(at, wt, n_t, lds, r_t, c_t);
             }
             }  // ---- end of the set-up part
             {
-                int n_t = n, r_t = r, c_t = c, qp_t = qp;
-                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t); SQPH_OPAQUE_V(qp_t);
-                load_vt(a.Sinv + (long)qp_t * 2 * n_t * n_t + (long)n_t * n_t, n_t, r_t, c_t, vt);
+                int n_t = n, r_t = r, c_t = c;
+                SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
+                load_vt_lds(lds, n_t, r_t, c_t, vt);
             }
             T (&bt)[TR][TC] = at;
 #define SQPH_G_PUBLISH()                                                                                         \

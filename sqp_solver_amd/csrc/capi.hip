@@ -130,6 +130,7 @@ struct sqph_solver {
     bool pin_busy = false;
     std::string err;
     const char *kernel_name = "none";
+    bool factor_resident = false;  // the workspace holds the factor of the last setup/update (see SQPH_FLAG_KEEP_FACTOR)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;  // one pair per launch while timing is on
     size_t ev_used = 0;
@@ -470,6 +471,10 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     a.m = s->m;
     a.batch = qp->batch;
     a.mode = mode | ((s->flags & SQPH_FLAG_LEGACY_COLD_START) ? MODE_COLD_RESET : 0);
+    // factor residency: a fused setup+solve writes no factor unless asked to; solve() on such a handle rebuilds it first
+    const bool fused = (mode & (MODE_SETUP | MODE_UPDATE)) && (mode & MODE_SOLVE);
+    if (fused && !(s->flags & SQPH_FLAG_KEEP_FACTOR)) a.mode |= MODE_NO_FACTOR_STORE;
+    if (!(mode & (MODE_SETUP | MODE_UPDATE)) && !s->factor_resident) a.mode |= MODE_REFACTOR;
     a.P = (const TIN *)P; a.q = (const TIN *)q; a.A = (const TIN *)A; a.l = (const TIN *)l; a.u = (const TIN *)u;
     a.sP = sP; a.sq = sq; a.sA = sA; a.sl = sl; a.su = su;
     a.x = (T *)s->x; a.z = (T *)s->z; a.y = (T *)s->y; a.rho_vec = (T *)s->rho_vec; a.ctype = s->ctype;
@@ -534,6 +539,10 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         SQPH_HIP(s, hipGetLastError());
         s->kernel_name = nt == 64 ? "generic_w1" : "generic_w4";
     }
+    // the generic kernel iterates out of the workspace: its factor is always resident
+    const bool generic = s->kernel_name[0] == 'g' && s->kernel_name[1] == 'e';
+    if (mode & (MODE_SETUP | MODE_UPDATE)) s->factor_resident = generic || !(a.mode & MODE_NO_FACTOR_STORE);
+    else if (a.mode & MODE_REFACTOR) s->factor_resident = generic || !(a.mode & MODE_NO_FACTOR_STORE);
     if (s->timing) {
         SQPH_HIP(s, hipEventRecord(s->evs[s->ev_used].second, s->stream));
         s->ev_used++;

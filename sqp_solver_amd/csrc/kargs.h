@@ -9,6 +9,11 @@ enum : int {
     MODE_UPDATE = 2,      // QPSolver::update_qp (src/qp.cpp:46-62): classify; rho; factor; keep x,z,y
     MODE_SOLVE = 4,       // QPSolver::solve   (src/qp.cpp:64-157)
     MODE_COLD_RESET = 8,  // legacy class: solve() zeroes x,z,y when !warm_start (unsupported/qp_solver.hpp:256-260)
+    // factor residency (host policy, capi.hip): a fused setup+solve does not write its factor to the workspace unless the
+    // solver was created with SQPH_FLAG_KEEP_FACTOR; a later solve() on such an instance rebuilds it first (same arithmetic,
+    // same results — the factor depends on P, A, sigma and the current rho vector only)
+    MODE_NO_FACTOR_STORE = 16,
+    MODE_REFACTOR = 32,
 };
 
 // T   = arithmetic / state type (always double in the shipped library)

@@ -287,6 +287,30 @@ def warm_start_and_resolve(make, n=8, m=12, batch=4, **kw):
     assert relerr(x, np.array(xs)) < TOL_F64 and relerr(y, np.array(ys)) < TOL_F64
 
 
+def fused_then_solve(make, n=8, m=12, batch=4, **kw):
+    """setup_solve() (fused: the factor is not written to the workspace unless keep_factor) followed by solve() with new
+    q, l, u — the second call rebuilds the factor (or finds it resident): same results as setup(); solve(); solve()."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=13)
+    q2, l2, u2 = q - 0.2, l - 0.1, u + 0.1
+    for keep in (False, True):
+        s = make(n, m, batch, keep_factor=keep, **kw)
+        s.settings.max_iter = 40
+        s.settings.check_termination = 0
+        s.settings.adaptive_rho, s.settings.adaptive_rho_interval = 1, 15  # the resident rho vector may have moved
+        s.setup_solve(P, q, A, l, u)
+        s.solve(P, q2, A, l2, u2)
+        x, y, z, info = s.solution()
+        for b in range(batch):
+            o = oracle.QPSolver()
+            o.settings.max_iter, o.settings.check_termination = 40, 0
+            o.settings.adaptive_rho, o.settings.adaptive_rho_interval = 1, 15
+            o.setup(P[b], q[b], A[b], l[b], u[b])
+            o.solve(P[b], q[b], A[b], l[b], u[b])
+            o.solve(P[b], q2[b], A[b], l2[b], u2[b])
+            assert info.rho_updates[b] == o.info.rho_updates and info.iter[b] == o.info.iter and info.status[b] == o.info.status
+            assert relerr(x[b][None], o.primal_solution()[None]) < TOL_F64 and relerr(y[b][None], o.dual_solution()[None]) < TOL_F64, (keep, b)
+
+
 def set_state_warm_start(make, n=6, m=9, batch=3, **kw):
     P, q, A, l, u = random_qp_batch(batch, n, m, seed=9)
     rng = np.random.default_rng(0)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SIMDIR = os.path.join(HERE, "sim")
 LIB = os.path.join(SIMDIR, "libsqph_sim.so")
 
-MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET = 1, 2, 4, 8
+MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET, MODE_NO_FACTOR_STORE, MODE_REFACTOR = 1, 2, 4, 8, 16, 32
 GENERIC, WG, CSR, G16, G32 = 0, 2, 3, 4, 5
 
 
@@ -49,11 +49,13 @@ def lib():
 class SimSolverBatch:
     """Same surface as sqp_solver_amd.QPSolverBatch, executed by the emulator (host arrays)."""
 
-    def __init__(self, n, m, batch, dtype=np.float64, variant=GENERIC, nt=64, legacy_cold_start=False):
+    def __init__(self, n, m, batch, dtype=np.float64, variant=GENERIC, nt=64, legacy_cold_start=False, keep_factor=False):
         self.n, self.m, self.batch = n, m, batch
         self.dtype = np.dtype(dtype)
         self.variant, self.nt = variant, nt
         self.legacy = legacy_cold_start
+        # factor residency policy of the host library (capi.hip launch_typed), mirrored
+        self.keep_factor, self.factor_resident = keep_factor, False
         self.settings = _capi.Settings()
         s = self.settings
         s.rho, s.sigma, s.alpha, s.eps_rel, s.eps_abs = 0.1, 1e-6, 1.0, 1e-3, 1e-3
@@ -90,6 +92,13 @@ class SimSolverBatch:
         a = SimArgs()
         a.n, a.m, a.batch = n, m, B
         a.mode = mode | (MODE_COLD_RESET if self.legacy else 0)
+        fused = bool(mode & (MODE_SETUP | MODE_UPDATE)) and bool(mode & MODE_SOLVE)
+        if fused and not self.keep_factor:
+            a.mode |= MODE_NO_FACTOR_STORE
+        if not (mode & (MODE_SETUP | MODE_UPDATE)) and not self.factor_resident:
+            a.mode |= MODE_REFACTOR
+        if (mode & (MODE_SETUP | MODE_UPDATE)) or (a.mode & MODE_REFACTOR):
+            self.factor_resident = self.variant == GENERIC or not (a.mode & MODE_NO_FACTOR_STORE)
         for name, arr, per in (("P", P, n * n), ("q", q, n), ("A", A, m * n), ("l", l, m), ("u", u, m)):
             setattr(a, name, arr.ctypes.data)
             shared = arr.ndim == (2 if name in ("P", "A") else 1)

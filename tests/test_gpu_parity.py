@@ -11,10 +11,11 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
-def make_gpu(n, m, batch, dtype=np.float64, legacy_cold_start=False, force_generic=False, **kw):
+def make_gpu(n, m, batch, dtype=np.float64, legacy_cold_start=False, force_generic=False, keep_factor=False, **kw):
     from sqp_solver_amd import QPSolverBatch
 
-    return QPSolverBatch(n, m, batch, dtype=dtype, device=0, legacy_cold_start=legacy_cold_start, force_generic=force_generic)
+    return QPSolverBatch(n, m, batch, dtype=dtype, device=0, legacy_cold_start=legacy_cold_start, force_generic=force_generic,
+                         keep_factor=keep_factor)
 
 
 def make_gpu_generic(n, m, batch, **kw):
@@ -70,6 +71,13 @@ def test_state_paths(make):
     cases.uninitialized_and_numerical_issues(make)
     cases.shared_matrices(make)
     cases.edge_shapes(make)
+
+
+@pytest.mark.parametrize("make", MAKERS, ids=IDS)
+@pytest.mark.parametrize("n,m", [(2, 3), (8, 12), (20, 40), (50, 100), (100, 200)])
+def test_fused_call_then_solve(n, m, make):
+    """a fused setup_solve keeps no factor by default; the following solve() rebuilds it (every kernel family)"""
+    cases.fused_then_solve(make, n=n, m=m, batch=5)
 
 
 def test_four_wave_shapes():

@@ -9,7 +9,8 @@ import simlib
 
 
 def make_generic(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
-    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.GENERIC, nt=kw.get("nt", 64), legacy_cold_start=legacy_cold_start)
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.GENERIC, nt=kw.get("nt", 64), legacy_cold_start=legacy_cold_start,
+                                 keep_factor=kw.get("keep_factor", False))
 
 
 @pytest.mark.parametrize("case", cases.REFERENCE_CASES, ids=lambda f: f.__name__)
@@ -52,7 +53,7 @@ def test_generic_shared_and_edges():
 
 # ---------------------------------------------------------------- workgroup-tiled kernel (matrices in VGPRs, vectors in LDS)
 def make_wg(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
-    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.WG, legacy_cold_start=legacy_cold_start)
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.WG, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
 
 
 @pytest.mark.parametrize("case", cases.REFERENCE_CASES, ids=lambda f: f.__name__)
@@ -118,7 +119,7 @@ def test_csr_kernel_adaptive_rho_refactors_in_kernel():
 
 # ------------------------------------------------------------------ four QPs per wavefront (admm_wg_kernel.h, run_group)
 def make_g16(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
-    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G16, legacy_cold_start=legacy_cold_start)
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G16, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
 
 
 @pytest.mark.parametrize("case", cases.REFERENCE_CASES, ids=lambda f: f.__name__)
@@ -159,7 +160,7 @@ def test_wg_four_wave_large_tile_shape():
 
 # ------------------------------------------------------------------ two QPs per wavefront (8 x 4 lane grid per QP)
 def make_g32(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
-    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G32, legacy_cold_start=legacy_cold_start)
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G32, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
 
 
 @pytest.mark.parametrize("n,m,batch", [(5, 7, 5), (20, 40, 5), (17, 33, 3)])
@@ -178,3 +179,10 @@ def test_g32_state_paths():
     cases.set_state_warm_start(make_g32)
     cases.uninitialized_and_numerical_issues(make_g32)
     cases.shared_matrices(make_g32)
+
+
+@pytest.mark.parametrize("make,n,m", [(make_generic, 6, 9), (make_wg, 8, 12), (make_wg, 50, 100), (make_g16, 8, 12), (make_g32, 20, 40)],
+                         ids=["generic", "wg1", "wg2", "g16", "g32"])
+def test_fused_call_then_solve(make, n, m):
+    """factor residency policy (capi.hip, mirrored by simlib): fused setup_solve without / with keep_factor, then solve()"""
+    cases.fused_then_solve(make, n=n, m=m, batch=2)
