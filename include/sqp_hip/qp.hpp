@@ -3,7 +3,7 @@
 //
 //   reference class                                         facade here
 //   ------------------------------------------------------  -------------------------------------------
-//   qp_solver::QuadraticProblem<Scalar>  solvers/qp.hpp:19-34    qp_solver::QuadraticProblem<Scalar> (raw pointers + dims)
+//   qp_solver::QuadraticProblem<Scalar>  solvers/qp.hpp:19-34    qp_solver::QuadraticProblem<Scalar>
 //   qp_solver::QPSolverSettings<Scalar>  solvers/qp.hpp:36-54    qp_solver::QPSolverSettings<Scalar>
 //   qp_solver::QPSolverInfo<Scalar>      solvers/qp.hpp:72-80    qp_solver::QPSolverInfo<Scalar>
 //   qp_solver::QPSolver<Scalar>          solvers/qp.hpp:118-248  qp_solver::QPSolver<Scalar>      (batch of 1)
@@ -11,11 +11,25 @@
 //   qp_solver::QP<n,m,Scalar> + QPSolver<QP<n,m>>  unsupported/qp_solver.hpp:18-49,135-592
 //                                                              qp_solver::legacy::QP<n,m,Scalar>, legacy::QPSolver<QPType>
 //
-// Method names, argument meaning, status values, iteration bookkeeping and the cold-start quirk of each
-// class follow the reference: the supported class does NOT reset x,z,y in solve() when warm_start=false
-// (src/qp.cpp:78-82 is a no-op), the legacy class does (unsupported/qp_solver.hpp:256-260).
-// Eigen users: matrices are taken through data() pointers; Eigen's default column-major layout is what
-// the C-ABI expects, so `qp.P = P.data(); qp.n = P.rows();` is all the glue needed.
+// Two build modes:
+//   * Eigen on the include path (SQP_HIP_HAVE_EIGEN): the DROP-IN mode.  QuadraticProblem holds the reference's five
+//     `const Eigen::Matrix*` members (`qp.P = &P;`), primal_solution()/dual_solution() return mutable Eigen vectors (a
+//     vector the caller modified is sent back to the device before the next solve(), like writing to the reference's
+//     x/y members), constr_type_init takes (const Vector&, const Vector&, Eigen::VectorXi&), the legacy QP<n,m> has Eigen
+//     members.  include/sqp_hip/compat/ mirrors the reference's include paths: `-I include/sqp_hip/compat` in place of
+//     the reference's `include/` makes `#include "solvers/qp.hpp"` (supported class) and
+//     `#include "unsupported/qp_solver.hpp"` / `"solvers/qp_solver.hpp"` (legacy class, SQP_HIP_LEGACY_API) resolve here.
+//   * no Eigen: the same classes over raw column-major pointers (RawQuadraticProblem; what the GPU box's tests use).
+// The supported and the legacy class share the name qp_solver::QPSolver in the reference (two alternative headers); here
+// they live in the inline namespace `supported` and the namespace `legacy` — SQP_HIP_LEGACY_API flips which one is inline.
+//
+// Method names, argument meaning, status values, iteration bookkeeping and the cold-start quirk of each class follow the
+// reference: the supported class does NOT reset x,z,y in solve() when warm_start=false (src/qp.cpp:78-82 is a no-op), the
+// legacy class does (unsupported/qp_solver.hpp:256-260).
+//
+// Behavioural difference (documented in sqp_hip.h and INTEGRATION.md): the device factorises the Schur complement
+// S = P + sigma I + A'RA, which must be positive definite; a P that makes S indefinite yields NUMERICAL_ISSUES where the
+// reference's pivoted LDL' of the indefinite KKT matrix would go on iterating (on a non-convex problem).
 #pragma once
 #include <cstdio>
 #include <limits>
@@ -25,38 +39,55 @@
 
 #include "../sqp_hip.h"
 
-// Eigen is optional: when its headers are on the include path the problem struct can be built straight from the
-// reference's five `const Eigen::Matrix*` (include/solvers/qp.hpp:29-33).  (Not compiled in this repository's own
-// test environment, which has no Eigen.)
-#if defined(__has_include)
+#if !defined(SQP_HIP_NO_EIGEN) && defined(__has_include)
 #if __has_include(<Eigen/Dense>)
 #include <Eigen/Dense>
 #define SQP_HIP_HAVE_EIGEN 1
 #endif
 #endif
 
+#ifdef SQP_HIP_LEGACY_API
+#define SQP_HIP_INLINE_SUPPORTED
+#define SQP_HIP_INLINE_LEGACY inline
+#else
+#define SQP_HIP_INLINE_SUPPORTED inline
+#define SQP_HIP_INLINE_LEGACY
+#endif
+
 namespace qp_solver {
+
+SQP_HIP_INLINE_SUPPORTED namespace supported {
 
 typedef enum { SOLVED, MAX_ITER_EXCEEDED, UNSOLVED, NUMERICAL_ISSUES, UNINITIALIZED } QPSolverStatus;
 
+// Problem data over raw pointers: P is n x n, A is m x n, both column-major (Eigen's default layout).  Borrowed.
 template <typename Scalar = double>
-struct QuadraticProblem {
-    int n = 0, m = 0;           // P is n x n, A is m x n (column-major)
+struct RawQuadraticProblem {
+    int n = 0, m = 0;
     const Scalar *P = nullptr;  // only the lower triangle enters the factor (reference: Eigen::LDLT<.,Lower>)
     const Scalar *q = nullptr;
     const Scalar *A = nullptr;
     const Scalar *l = nullptr;
     const Scalar *u = nullptr;
-
-    QuadraticProblem() = default;
-#ifdef SQP_HIP_HAVE_EIGEN
-    using Matrix = Eigen::Matrix<Scalar, Eigen::Dynamic, Eigen::Dynamic>;  // column-major, as qp.hpp:21
-    using Vector = Eigen::Matrix<Scalar, Eigen::Dynamic, 1>;
-    // borrowed, like the reference: the Eigen objects must outlive setup()/solve()
-    QuadraticProblem(const Matrix *P_, const Vector *q_, const Matrix *A_, const Vector *l_, const Vector *u_)
-        : n((int)P_->rows()), m((int)A_->rows()), P(P_->data()), q(q_->data()), A(A_->data()), l(l_->data()), u(u_->data()) {}
-#endif
 };
+
+#ifdef SQP_HIP_HAVE_EIGEN
+// The reference's struct, member for member (solvers/qp.hpp:19-34): five non-owning pointers to Eigen objects that must
+// outlive setup()/solve().
+template <typename Scalar = double>
+struct QuadraticProblem {
+    using Vector = Eigen::Matrix<Scalar, Eigen::Dynamic, 1>;
+    using Matrix = Eigen::Matrix<Scalar, Eigen::Dynamic, Eigen::Dynamic>;
+    const Matrix *P;
+    const Vector *q;
+    const Matrix *A;
+    const Vector *l;
+    const Vector *u;
+};
+#else
+template <typename Scalar = double>
+using QuadraticProblem = RawQuadraticProblem<Scalar>;
+#endif
 
 template <typename Scalar>
 struct QPSolverSettings {
@@ -168,11 +199,26 @@ class BatchQPSolver {
     const Scalar *dual_solution(int b) { fetch(); return &y_[(size_t)b * m_]; }
     const Scalar *z(int b) { fetch(); return &z_[(size_t)b * m_]; }  // the reference keeps z as solver state (qp.hpp:224)
     const Info &info(int b) { fetch(); return info_[b]; }
+    // overwrite iterates of the first `batch` instances (nullptr = leave): the reference's writable primal/dual accessors
+    void set_state(int batch, const Scalar *x, const Scalar *z, const Scalar *y) {
+        detail::check(sqph_set_state(h_, batch, SQPH_HOST, x, z, y), h_, "sqph_set_state");
+        fetched_ = false;
+    }
     sqph_solver *handle() { return h_; }
     int n() const { return n_; }
     int m() const { return m_; }
 
    private:
+    void push_settings() {
+        sqph_settings st;
+        st.rho = settings_.rho; st.sigma = settings_.sigma; st.alpha = settings_.alpha;
+        st.eps_rel = settings_.eps_rel; st.eps_abs = settings_.eps_abs;
+        st.max_iter = settings_.max_iter; st.check_termination = settings_.check_termination;
+        st.warm_start = settings_.warm_start; st.adaptive_rho = settings_.adaptive_rho;
+        st.adaptive_rho_tolerance = settings_.adaptive_rho_tolerance;
+        st.adaptive_rho_interval = settings_.adaptive_rho_interval; st.verbose = settings_.verbose;
+        detail::check(sqph_set_settings(h_, &st), h_, "sqph_set_settings");
+    }
     template <typename F>
     void call_csr(F fn, const CsrBatch &b, const char *what) {
         push_settings();
@@ -185,26 +231,9 @@ class BatchQPSolver {
         last_batch_ = b.batch;
         fetched_ = false;
     }
-    void push_settings() {
-        sqph_settings st;
-        st.rho = settings_.rho; st.sigma = settings_.sigma; st.alpha = settings_.alpha;
-        st.eps_rel = settings_.eps_rel; st.eps_abs = settings_.eps_abs;
-        st.max_iter = settings_.max_iter; st.check_termination = settings_.check_termination;
-        st.warm_start = settings_.warm_start; st.adaptive_rho = settings_.adaptive_rho;
-        st.adaptive_rho_tolerance = settings_.adaptive_rho_tolerance;
-        st.adaptive_rho_interval = settings_.adaptive_rho_interval; st.verbose = settings_.verbose;
-        detail::check(sqph_set_settings(h_, &st), h_, "sqph_set_settings");
-    }
     template <typename F>
     void call(F fn, const Batch &b, const char *what) {
-        sqph_settings st;
-        st.rho = settings_.rho; st.sigma = settings_.sigma; st.alpha = settings_.alpha;
-        st.eps_rel = settings_.eps_rel; st.eps_abs = settings_.eps_abs;
-        st.max_iter = settings_.max_iter; st.check_termination = settings_.check_termination;
-        st.warm_start = settings_.warm_start; st.adaptive_rho = settings_.adaptive_rho;
-        st.adaptive_rho_tolerance = settings_.adaptive_rho_tolerance;
-        st.adaptive_rho_interval = settings_.adaptive_rho_interval; st.verbose = settings_.verbose;
-        detail::check(sqph_set_settings(h_, &st), h_, "sqph_set_settings");
+        push_settings();
         sqph_qp_batch qb;
         qb.batch = b.batch; qb.memspace = b.memspace;
         qb.P = b.P; qb.q = b.q; qb.A = b.A; qb.l = b.l; qb.u = b.u;
@@ -242,8 +271,15 @@ class QPSolver {
    public:
     using Scalar = SCALAR;
     using QP = QuadraticProblem<Scalar>;
+    using RawQP = RawQuadraticProblem<Scalar>;
     using Settings = QPSolverSettings<Scalar>;
     using Info = QPSolverInfo<Scalar>;
+#ifdef SQP_HIP_HAVE_EIGEN
+    using Vector = Eigen::Matrix<Scalar, Eigen::Dynamic, 1>;
+    using Matrix = Eigen::Matrix<Scalar, Eigen::Dynamic, Eigen::Dynamic>;
+#else
+    using Vector = std::vector<Scalar>;
+#endif
 
     enum { INEQUALITY_CONSTRAINT, EQUALITY_CONSTRAINT, LOOSE_BOUNDS } ConstraintType;
     static constexpr Scalar RHO_MIN = 1e-6;
@@ -258,104 +294,235 @@ class QPSolver {
     QPSolver(const QPSolver &) = delete;
     QPSolver &operator=(const QPSolver &) = delete;
 
-    void setup(const QP &qp) {
+    void setup(const RawQP &qp) {
         if (!impl_ || impl_->n() != qp.n || impl_->m() != qp.m) {
             // a new shape starts a fresh instance, like the resize() cascade of src/qp.cpp:13-29
             delete impl_;
             impl_ = new BatchQPSolver<Scalar>(qp.n, qp.m, 1, device_, flags_);
         }
-        push();
+        push(false);
         impl_->setup(impl_->packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
         pull();
     }
-    void update_qp(const QP &qp) {
+    void update_qp(const RawQP &qp) {
         if (!impl_) return;
-        push();
+        push(true);
         impl_->update_qp(impl_->packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
         pull();
     }
-    void solve(const QP &qp) {
+    void solve(const RawQP &qp) {
         if (!impl_) return;  // UNINITIALIZED: solve() returns silently, src/qp.cpp:68-71
-        push();
+        push(true);
         impl_->solve(impl_->packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
         pull();
     }
+#ifdef SQP_HIP_HAVE_EIGEN
+    void setup(const QP &qp) { setup(raw(qp)); }
+    void update_qp(const QP &qp) { update_qp(raw(qp)); }
+    void solve(const QP &qp) { solve(raw(qp)); }
+    // static QPSolver::constr_type_init(l, u, constr_type), src/qp.cpp:283-294 — the caller sizes constr_type
+    static void constr_type_init(const Vector &l, const Vector &u, Eigen::VectorXi &constr_type) {
+        constr_type_init((int)l.rows(), l.data(), u.data(), constr_type.data());
+    }
+#endif
 
-    const std::vector<Scalar> &primal_solution() const { return x_; }
-    const std::vector<Scalar> &dual_solution() const { return y_; }
+    // mutable like the reference's (qp.hpp:160-164): what the caller writes here is the state the next solve() starts from
+    const Vector &primal_solution() const { return x_; }
+    Vector &primal_solution() { return x_; }
+    const Vector &dual_solution() const { return y_; }
+    Vector &dual_solution() { return y_; }
     Settings &settings() { return settings_; }
     const Settings &settings() const { return settings_; }
     Info &info() { return info_; }
     const Info &info() const { return info_; }
 
-    // static QPSolver::constr_type_init(l, u, constr_type), src/qp.cpp:283-294
     static void constr_type_init(int m, const Scalar *l, const Scalar *u, int *constr_type) {
         detail::check(sqph_constr_type_init(detail::dtype_of<Scalar>::value, m, l, u, constr_type), nullptr, "sqph_constr_type_init");
     }
 
    private:
-    void push() { impl_->settings() = settings_; }
+#ifdef SQP_HIP_HAVE_EIGEN
+    static RawQP raw(const QP &qp) {
+        RawQP r;
+        r.n = (int)qp.P->rows(); r.m = (int)qp.A->rows();
+        r.P = qp.P->data(); r.q = qp.q->data(); r.A = qp.A->data(); r.l = qp.l->data(); r.u = qp.u->data();
+        return r;
+    }
+#endif
+    void push(bool send_state) {
+        impl_->settings() = settings_;
+        if (!send_state) return;
+        // iterates the caller changed through the accessors since the last call go back to the device
+        const int n = impl_->n(), m = impl_->m();
+        bool dx = (int)x_.size() != n, dy = (int)y_.size() != m;
+        for (int i = 0; i < n && !dx; i++) dx = !(x_[i] == x_seen_[i]);
+        for (int i = 0; i < m && !dy; i++) dy = !(y_[i] == y_seen_[i]);
+        if ((int)x_.size() != n || (int)y_.size() != m) return;  // resized by the caller: nothing sensible to send
+        if (dx || dy) impl_->set_state(1, dx ? &x_[0] : nullptr, nullptr, (dy && m) ? &y_[0] : nullptr);
+    }
     void pull() {
-        x_.assign(impl_->primal_solution(0), impl_->primal_solution(0) + impl_->n());
-        y_.assign(impl_->dual_solution(0), impl_->dual_solution(0) + impl_->m());
+        const int n = impl_->n(), m = impl_->m();
+#ifdef SQP_HIP_HAVE_EIGEN
+        x_.resize(n);
+        y_.resize(m);
+#else
+        x_.resize(n);
+        y_.resize(m);
+#endif
+        for (int i = 0; i < n; i++) x_[i] = impl_->primal_solution(0)[i];
+        for (int i = 0; i < m; i++) y_[i] = impl_->dual_solution(0)[i];
+        x_seen_.assign(impl_->primal_solution(0), impl_->primal_solution(0) + n);
+        y_seen_.assign(impl_->dual_solution(0), impl_->dual_solution(0) + m);
         info_ = impl_->info(0);
     }
     int device_, flags_;
     BatchQPSolver<Scalar> *impl_ = nullptr;
     Settings settings_;
     Info info_;
-    std::vector<Scalar> x_, y_;
+    Vector x_, y_;
+    std::vector<Scalar> x_seen_, y_seen_;
 };
 
+}  // namespace supported
+
 // Fixed-size legacy API, reference include/unsupported/qp_solver.hpp:18-49,135-592.
-namespace legacy {
+SQP_HIP_INLINE_LEGACY namespace legacy {
+
+// the legacy header's own names for settings / info / status (unsupported/qp_solver.hpp:51-127): no NUMERICAL_ISSUES
+template <typename Scalar>
+using qp_sover_settings_t = supported::QPSolverSettings<Scalar>;
+typedef enum { SOLVED, MAX_ITER_EXCEEDED, UNSOLVED, UNINITIALIZED } status_t;
+template <typename Scalar>
+struct qp_solver_info_t {
+    status_t status = UNINITIALIZED;
+    int iter = 0;
+    int rho_updates = 0;
+    Scalar rho_estimate = 0;
+    Scalar res_prim = 0;
+    Scalar res_dual = 0;
+};
+
 template <int N_, int M_, typename Scalar_ = double>
 struct QP {
     using Scalar = Scalar_;
     enum { n = N_, m = M_ };
+#ifdef SQP_HIP_HAVE_EIGEN
+    Eigen::Matrix<Scalar, N_, N_> P;  // members as in unsupported/qp_solver.hpp:35-48
+    Eigen::Matrix<Scalar, N_, 1> q;
+    Eigen::Matrix<Scalar, M_, N_> A;
+    Eigen::Matrix<Scalar, M_, 1> l, u;
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#else
     Scalar P[N_ * N_];  // column-major
     Scalar q[N_];
     Scalar A[M_ * N_];  // column-major
     Scalar l[M_], u[M_];
+#endif
 };
 
+namespace detail {
+#ifdef SQP_HIP_HAVE_EIGEN
+template <typename T> inline const typename T::Scalar *ptr(const T &v) { return v.data(); }
+template <typename T> inline typename T::Scalar *ptr(T &v) { return v.data(); }
+#else
+template <typename S> inline const S *ptr(const S *v) { return v; }
+template <typename S> inline S *ptr(S *v) { return v; }
+#endif
+}  // namespace detail
+
+// LinearSolver / UpLo are accepted for source compatibility and ignored: the device always factors the Schur complement.
+#ifdef SQP_HIP_HAVE_EIGEN
+template <typename QPType, template <typename, int, typename...> class LinearSolver = Eigen::LDLT, int LinearSolver_UpLo = Eigen::Lower>
+#else
 template <typename QPType>
+#endif
 class QPSolver {
    public:
     enum { n = QPType::n, m = QPType::m };
+    using qp_t = QPType;
     using Scalar = typename QPType::Scalar;
-    using settings_t = QPSolverSettings<Scalar>;
-    using info_t = QPSolverInfo<Scalar>;
+    using settings_t = qp_sover_settings_t<Scalar>;
+    using info_t = qp_solver_info_t<Scalar>;
+    static constexpr Scalar RHO_MIN = 1e-6;
+    static constexpr Scalar RHO_MAX = 1e+6;
+    static constexpr Scalar RHO_TOL = 1e-4;
+    static constexpr Scalar RHO_EQ_FACTOR = 1e+3;
+    static constexpr Scalar LOOSE_BOUNDS_THRESH = 1e+16;
+    static constexpr Scalar DIV_BY_ZERO_REGUL = std::numeric_limits<Scalar>::epsilon();
     // public state, as in the reference (unsupported/qp_solver.hpp:172-200)
     int iter = 0;
+#ifdef SQP_HIP_HAVE_EIGEN
+    using var_t = Eigen::Matrix<Scalar, n, 1>;
+    using constraint_t = Eigen::Matrix<Scalar, m, 1>;
+    using dual_t = Eigen::Matrix<Scalar, m, 1>;
+    var_t x;
+    constraint_t z;
+    dual_t y;
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#else
     Scalar x[n], z[m > 0 ? m : 1], y[m > 0 ? m : 1];
-    int constr_type[m > 0 ? m : 1];  // INEQUALITY_CONSTRAINT / EQUALITY_CONSTRAINT / LOOSE_BOUNDS
+#endif
+    enum { INEQUALITY_CONSTRAINT, EQUALITY_CONSTRAINT, LOOSE_BOUNDS } constr_type[m > 0 ? m : 1];
     settings_t _settings;
     info_t _info;
 
-    explicit QPSolver(int device = 0) : impl_(n, m, 1, device, SQPH_FLAG_LEGACY_COLD_START) {}
-    void setup(const QPType &qp) { run(&BatchQPSolver<Scalar>::setup, qp); }
-    void update_qp(const QPType &qp) { run(&BatchQPSolver<Scalar>::update_qp, qp); }
-    void solve(const QPType &qp) { run(&BatchQPSolver<Scalar>::solve, qp); }
+    explicit QPSolver(int device = 0) : impl_(n, m, 1, device, SQPH_FLAG_LEGACY_COLD_START) {
+        for (int i = 0; i < n; i++) x[i] = 0;
+        for (int i = 0; i < m; i++) z[i] = y[i] = 0;
+    }
+    void setup(const qp_t &qp) { run(&supported::BatchQPSolver<Scalar>::setup, qp, false); }
+    void update_qp(const qp_t &qp) { run(&supported::BatchQPSolver<Scalar>::update_qp, qp, true); }
+    void solve(const qp_t &qp) {
+        if (_info.status == UNINITIALIZED) return;  // unsupported/qp_solver.hpp:246-249
+        run(&supported::BatchQPSolver<Scalar>::solve, qp, true);
+    }
+#ifdef SQP_HIP_HAVE_EIGEN
+    const var_t &primal_solution() const { return x; }
+    var_t &primal_solution() { return x; }
+    const dual_t &dual_solution() const { return y; }
+    dual_t &dual_solution() { return y; }
+#else
     const Scalar *primal_solution() const { return x; }
+    Scalar *primal_solution() { return x; }
     const Scalar *dual_solution() const { return y; }
+    Scalar *dual_solution() { return y; }
+#endif
+    const settings_t &settings() const { return _settings; }
     settings_t &settings() { return _settings; }
+    const info_t &info() const { return _info; }
     info_t &info() { return _info; }
 
    private:
     template <typename F>
-    void run(F fn, const QPType &qp) {
+    void run(F fn, const qp_t &qp, bool send_state) {
         impl_.settings() = _settings;
-        (impl_.*fn)(impl_.packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
-        for (int i = 0; i < n; i++) x[i] = impl_.primal_solution(0)[i];
-        for (int i = 0; i < m; i++) y[i] = impl_.dual_solution(0)[i];
-        for (int i = 0; i < m; i++) z[i] = impl_.z(0)[i];
-        if (m > 0) sqph_constr_type_init(detail::dtype_of<Scalar>::value, m, qp.l, qp.u, constr_type);
-        _info = impl_.info(0);
-        if (_info.status == NUMERICAL_ISSUES) _info.status = UNSOLVED;  // the legacy enum has no NUMERICAL_ISSUES (unsupported:84-89)
+        if (send_state) {  // x, z, y are public members in the reference: what the caller left there is the solver's state
+            bool d = false;
+            for (int i = 0; i < n && !d; i++) d = !(x[i] == seen_[i]);
+            for (int i = 0; i < m && !d; i++) d = !(z[i] == seen_[n + i]) || !(y[i] == seen_[n + m + i]);
+            if (d) impl_.set_state(1, detail::ptr(x), m > 0 ? detail::ptr(z) : nullptr, m > 0 ? detail::ptr(y) : nullptr);
+        }
+        (impl_.*fn)(impl_.packed(1, detail::ptr(qp.P), detail::ptr(qp.q), detail::ptr(qp.A), detail::ptr(qp.l), detail::ptr(qp.u)));
+        for (int i = 0; i < n; i++) seen_[i] = x[i] = impl_.primal_solution(0)[i];
+        for (int i = 0; i < m; i++) seen_[n + i] = z[i] = impl_.z(0)[i];
+        for (int i = 0; i < m; i++) seen_[n + m + i] = y[i] = impl_.dual_solution(0)[i];
+        if (m > 0) {
+            int ct[m > 0 ? m : 1];
+            sqph_constr_type_init(supported::detail::dtype_of<Scalar>::value, m, detail::ptr(qp.l), detail::ptr(qp.u), ct);
+            for (int i = 0; i < m; i++) constr_type[i] = static_cast<decltype(INEQUALITY_CONSTRAINT)>(ct[i]);
+        }
+        const auto &bi = impl_.info(0);
+        // the legacy enum has no NUMERICAL_ISSUES (unsupported/qp_solver.hpp:84-89): a failed factorisation leaves UNSOLVED
+        _info.status = bi.status == supported::SOLVED              ? SOLVED
+                       : bi.status == supported::MAX_ITER_EXCEEDED ? MAX_ITER_EXCEEDED
+                       : bi.status == supported::UNINITIALIZED     ? UNINITIALIZED
+                                                                   : UNSOLVED;
+        _info.iter = bi.iter; _info.rho_updates = bi.rho_updates; _info.rho_estimate = bi.rho_estimate;
+        _info.res_prim = bi.res_prim; _info.res_dual = bi.res_dual;
         iter = _info.iter;
     }
-    BatchQPSolver<Scalar> impl_;
+    supported::BatchQPSolver<Scalar> impl_;
+    Scalar seen_[n + 2 * (m > 0 ? m : 1)] = {};
 };
 }  // namespace legacy
 

@@ -876,7 +876,11 @@ __global__ __launch_bounds__(1024) void admm_csr_kernel(CsrLaunch<TIN> p) {
 }
 
 // tile edges compiled into the library (n <= 32*TT): first fit wins
+#ifdef SQPH_SLIM
+#define SQPH_CSR_SHAPES(X)
+#else
 #define SQPH_CSR_SHAPES(X) X(4) X(7)
+#endif
 // additional small edges for the host SIMT emulation in the CPU test-suite
 #define SQPH_CSR_SIM_SHAPES(X) X(1) X(2) X(4) X(7)
 

@@ -30,6 +30,17 @@
 #endif
 #endif
 
+// -DSQPH_SETUP_TIMING (debug builds, tools/setup_timing.py): s_memtime ticks of the set-up phases of wave 0, returned in x[0..8)
+#ifdef SQPH_SETUP_TIMING
+#define SQPH_STICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); sqph_stk[k] += tn_ - sqph_stp; sqph_stp = tn_; }
+#define SQPH_STICK_ARGS , unsigned long long (&sqph_stk)[8], unsigned long long &sqph_stp
+#define SQPH_STICK_PASS , sqph_stk, sqph_stp
+#else
+#define SQPH_STICK(k)
+#define SQPH_STICK_ARGS
+#define SQPH_STICK_PASS
+#endif
+
 namespace sqph {
 
 typedef double sqph_v2 __attribute__((vector_size(16)));
@@ -100,15 +111,16 @@ struct WgLayout {
     static constexpr int STAGE_X = NP * Rp;
     static constexpr int O_STAGE_Y = O_STAGE + STAGE_X;    // staging Y: partials reduced over c  [max(NR,MP)][Cp]
     static constexpr int STAGE_Y = mx(NR, MP) * Cp;
-    // set-up scratch, aliasing the staging areas:  rho[MP] | rowbuf[NP+2] | sj[NP] | As[R][SSTR] | Wl[NP][SSTR]
+    // set-up scratch, aliasing the staging areas:  rho[MP] | rowbuf[2][RBS] | sj[NP] | As[R][SSTR] | Wl[NP][SSTR]
     // As = one block of R rows of A, Wl = W transposed (Wl[j][slot(i')] = W[i'][j]); column groups are
     // padded to 8 (slot(j) = 8*(j/TC) + j%TC) so a lane's TC consecutive columns are one aligned 64-B read.
     // (the set-up scratch starts at offset 0: no vector is live in LDS while a factor is being built)
     static constexpr int SSTR = 8 * C + 2;  // As row stride (padded: the R rows are written by different lanes)
     static constexpr int WSTR = 8 * C;      // Wl row stride
     static constexpr int O_RHO = 0;
-    static constexpr int O_ROWBUF = O_RHO + MP;
-    static constexpr int O_SJ = O_ROWBUF + NP + 2;
+    static constexpr int O_ROWBUF = ev(O_RHO + MP);  // two pivot-row buffers (ping-pong), slot layout: [2][RBS]
+    static constexpr int RBS = 8 * C + 2;
+    static constexpr int O_SJ = O_ROWBUF + 2 * RBS;
     static constexpr int O_AS = ev(O_SJ + NP);
     static constexpr int O_WL = O_AS + R * SSTR;
     static constexpr int CH = (C + 1) / 2;  // W is staged half of its columns (CH column groups) at a time
@@ -319,7 +331,7 @@ struct WgKernel {
     // B = A W' IN PLACE over the A tile (bt[s][k] = sum_j A[R s + r][j] * W[TC c + k][j], W lower triangular).
     // W is staged once (transposed) in LDS from the register tile, A goes through LDS one block of R rows at
     // a time — nothing is re-read from global memory.
-    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c) {
+    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c SQPH_STICK_ARGS) {
         T *As = lds + L::O_AS, *Wl = lds + L::O_WL;
         const int myhalf = c / L::CH, cl = c - myhalf * L::CH;  // my column group inside its half
 
@@ -452,7 +464,7 @@ struct WgKernel {
     // Scratch inside the staging area: rho[MP] | rowbuf[NP + 1] | sj[NP]   (doubles)
     // `at` is the A register tile (rows R s + r, columns TC c + k); it is only read here.
     static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const T (&at)[TR][TC], int n, int m, T sigma,
-                                                  T *lds, int t, int r, int c, T (&wt)[TW][TC]) {
+                                                  T *lds, int t, int r, int c, T (&wt)[TW][TC] SQPH_STICK_ARGS) {
         T *rho_l = lds + L::O_RHO;
         T *rowbuf = lds + L::O_ROWBUF;
         T *sjv = lds + L::O_SJ;
@@ -468,10 +480,20 @@ struct WgKernel {
             const int j = TC * c + k;
             jc[k] = j < n ? j : 0;
         }
+        // S starts as P_sym + sigma I: these global loads are issued first, their latency hides behind the accumulation below
+        // (only the lower triangle of P reaches the reference's factor, Eigen::LDLT<.,Lower>)
 #pragma unroll
-        for (int u = 0; u < TW; u++)
+        for (int u = 0; u < TW; u++) {
+            const int i = R * u + r;
 #pragma unroll
-            for (int k = 0; k < TC; k++) wt[u][k] = 0;
+            for (int k = 0; k < TC; k++) {
+                const int j = TC * c + k;
+                const bool ok = i < n && j < n;
+                const int lo = i > j ? i : j, hi = i > j ? j : i;
+                const T p = ok ? (T)gP[(long)hi * n + lo] : T(0);
+                wt[u][k] = ok ? p + (i == j ? sigma : T(0)) : T(0);
+            }
+        }
         // S = A' diag(rho) A : the A tile goes through LDS one block of R rows at a time (row R s + il of A is
         // As[il][.]); every lane then reads the TW + TC entries of each row it needs. No global re-reads.
         int sl[TW];
@@ -499,11 +521,10 @@ struct WgKernel {
                     for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
             }
         }
+        SQPH_STICK(1)
         wsync();
-        for (int e = t; e < L::NP + 2; e += NT) {
-            rowbuf[e] = 0;
-            if (e < L::NP) sjv[e] = T(1);
-        }
+        for (int e = t; e < 2 * L::RBS; e += NT) rowbuf[e] = 0;
+        for (int e = t; e < L::NP; e += NT) sjv[e] = T(1);
         wsync();
 #pragma unroll
         for (int u = 0; u < TW; u++) {
@@ -512,10 +533,7 @@ struct WgKernel {
             for (int k = 0; k < TC; k++) {
                 const int j = TC * c + k;
                 const bool ok = i < n && j < n;
-                const int lo = i > j ? i : j, hi = i > j ? j : i;
-                // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>)
-                const T p = ok ? (T)gP[(long)hi * n + lo] : T(0);
-                wt[u][k] = ok ? (wt[u][k] + p + (i == j ? sigma : T(0))) : T(0);
+                wt[u][k] = ok ? wt[u][k] : T(0);  // rows beyond n gathered column 0 of A above
                 if (ok && i == j) sjv[j] = wt[u][k];  // the diagonal, for the Jacobi scaling
             }
         }
@@ -543,6 +561,7 @@ struct WgKernel {
         for (int u = 0; u < TW; u++)
 #pragma unroll
             for (int k = 0; k < TC; k++) wt[u][k] = wt[u][k] * srow[u] * scol[k];
+        SQPH_STICK(2)
         // forward elimination of [S~ | I] in place; row k = R*u + rr is broadcast through LDS
         bool ok_all = true;
         T dsave[TW];
@@ -554,30 +573,30 @@ struct WgKernel {
             for (int rr = 0; rr < R; rr++) {
                 const int k = R * u + rr;
                 if (k >= n || !ok_all) break;
+                // ping-pong pivot-row buffers: the row of pivot k + 1 goes to the other buffer, so ONE workgroup barrier per
+                // pivot suffices (a lane still reading pivot k's row is at most one barrier behind the writer of pivot k + 2's)
+                T *rb = rowbuf + (k & 1) * L::RBS;
                 if (r == rr) {
 #pragma unroll
-                    for (int q = 0; q < TC; q++) rowbuf[TC * c + q] = wt[u][q];
+                    for (int q = 0; q < TC; q++) rb[8 * c + q] = wt[u][q];
                 }
                 wsync();
-                const T d = rowbuf[k];
+                const T d = rb[L::slot(k)];
                 if (!(d > T(0)) || !(d * T(0) == T(0))) {
                     ok_all = false;
                     break;
                 }
                 const T dinv = T(1) / d;
-                T g[TC], f[TW];
+                T g[TC], f[TW], g8[8];
+                wg_read<8>(rb + 8 * c, g8);
 #pragma unroll
-                for (int q = 0; q < TC; q++) {
-                    const T gq = rowbuf[TC * c + q];
-                    g[q] = (TC * c + q == k) ? d + T(1) : gq;
-                }
+                for (int q = 0; q < TC; q++) g[q] = (TC * c + q == k) ? d + T(1) : g8[q];
 #pragma unroll
                 for (int v = 0; v < TW; v++) {
                     const int i = R * v + r;
-                    const T gi = rowbuf[i < L::NP ? i : 0];
+                    const T gi = rb[sl[v]];
                     f[v] = (i > k && i < n) ? gi * dinv : T(0);
                 }
-                wsync();
 #pragma unroll
                 for (int v = 0; v < TW; v++)
 #pragma unroll
@@ -585,6 +604,7 @@ struct WgKernel {
                 dsave[u] = (r == rr) ? d : dsave[u];
             }
         }
+        SQPH_STICK(3)
         // W = D^-1/2 L^-1 D_J^-1/2
 #pragma unroll
         for (int u = 0; u < TW; u++) {
@@ -675,6 +695,9 @@ struct WgKernel {
             }
         }
 
+#ifdef SQPH_SETUP_TIMING
+        unsigned long long sqph_stk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sqph_stp = __builtin_amdgcn_s_memtime();
+#endif
         T vt[TW][TC];  // the tile of W' the iteration runs on (the W tile itself lives only inside the set-up block)
         T at[TR][TC];  // the A tile; turned into B = A W' in place once the factor is known
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
@@ -698,8 +721,11 @@ struct WgKernel {
                 const TIN *gA_f = gA, *gP_f = gP;
                 SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(m_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_V(t_f);
                 SQPH_OPAQUE_S(gA_f); SQPH_OPAQUE_S(gP_f);
+                SQPH_STICK(7)
                 load_A_tile(gA_f, n_f, m_f, r_f, c_f, at);  // the only read of A from global memory per factorisation
-                const bool ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt);
+                SQPH_STICK(0)
+                const bool ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt SQPH_STICK_PASS);
+                SQPH_STICK(4)
                 // the factor is kept for later solve() calls unless the host asked for a fused setup+solve without it
                 if (!(mode & MODE_NO_FACTOR_STORE)) store_sq_tile(gW, n_f, r_f, c_f, wt);
                 __syncthreads();
@@ -733,13 +759,16 @@ struct WgKernel {
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                build_B_inplace(at, wt, n_t, lds, r_t, c_t);
+                SQPH_STICK(7)
+                build_B_inplace(at, wt, n_t, lds, r_t, c_t SQPH_STICK_PASS);
+                SQPH_STICK(5)
             }
             }  // ---- end of the set-up part
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
                 load_vt_lds(lds, n_t, r_t, c_t, vt);
+                SQPH_STICK(6)
             }
             T (&bt)[TR][TC] = at;
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
@@ -923,6 +952,9 @@ struct WgKernel {
             info.iter = iter;
         }
 
+#ifdef SQPH_SETUP_TIMING
+        if (t < 8) x = (T)sqph_stk[t];
+#endif
         if (state_dirty) {
             if (nown) sx[t] = x;
             if (mown) {
@@ -1353,6 +1385,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
 }
 
 // shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins
+// (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
+#ifdef SQPH_SLIM
+#define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
+#define SQPH_G32_SHAPES(X)
+#define SQPH_G16_SHAPES(X)
+#else
 #define SQPH_WG_SHAPES(X)        \
     X(1, 8, 8, 1, 1, 1, 4)       \
     X(1, 8, 8, 3, 2, 2, 4)       \
@@ -1394,6 +1432,7 @@ __global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a)
     X(1, 1, 4)             \
     X(3, 2, 4)             \
     X(6, 3, 2)
+#endif  // SQPH_SLIM
 
 #ifdef SQPH_SIM
 template <typename TIN>
