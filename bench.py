@@ -6,7 +6,10 @@ kernel launch) for every QP of this rank's shard, inputs already resident in HBM
 workload = BASELINE.json configs[2] sharded weakly: 8,192 dense QPs (n=50, m=100, fp64) per GPU,
 i.e. the 65,536-QP batch at 8 GPUs; `--mode fixed` runs exactly `--iters` ADMM iterations per QP
 (check_termination=0), `--mode default` uses the reference's default settings (eps 1e-3, check
-every 25, max_iter 1000).
+every 25, max_iter 1000), `--mode sqp` the settings the reference's SQP driver gives its QP solver (src/sqp.cpp:15-23: eps 1e-4,
+check every 10, max_iter 100, adaptive rho every 50, alpha 1.6 — short solves, the regime where the HBM fraction means something).
+`--global-batch N` fixes the TOTAL batch (strong scaling: rank r solves block shard_bounds(N, world, r); with one GPU that is the whole
+BASELINE configs[2] batch of 65,536 in one launch).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (HBM, from HIP
 events recorded on the launch stream around every timed launch) and `cpu_baseline` (the CPU oracle,
@@ -36,7 +39,8 @@ def parse():
     ap.add_argument("--n", type=int, default=50)
     ap.add_argument("--m", type=int, default=100)
     ap.add_argument("--batch-per-gpu", type=int, default=8192)
-    ap.add_argument("--mode", choices=["fixed", "default"], default="fixed")
+    ap.add_argument("--global-batch", type=int, default=0, help="total batch over all GPUs (strong scaling); 0 = --batch-per-gpu on every GPU (weak)")
+    ap.add_argument("--mode", choices=["fixed", "default", "sqp"], default="fixed")
     ap.add_argument("--iters", type=int, default=200, help="ADMM iterations per QP in --mode fixed")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -75,6 +79,13 @@ def main():
     elif args.workload == "c5":
         args.n, args.m = 200, 400
     n, m, B = args.n, args.m, args.batch_per_gpu
+    strong = args.global_batch > 0
+    if strong:
+        from sqp_solver_amd.dist import shard_bounds
+
+        lo, hi = shard_bounds(args.global_batch, world, rank)
+        B = hi - lo
+        args.batch_per_gpu = B
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     ndt = np.float64 if args.dtype == "f64" else np.float32
 
@@ -96,6 +107,9 @@ def main():
     if args.mode == "fixed":
         st.max_iter = args.iters
         st.check_termination = 0
+    elif args.mode == "sqp":  # SQP constructor, src/sqp.cpp:15-23
+        st.warm_start, st.check_termination, st.eps_abs, st.eps_rel = 1, 10, 1e-4, 1e-4
+        st.max_iter, st.adaptive_rho, st.adaptive_rho_interval, st.alpha = 100, 1, 50, 1.6
     solver.set_stream(torch.cuda.current_stream().cuda_stream)
 
     # device views of the resident results for the gather
@@ -158,7 +172,8 @@ def main():
     else:
         iters_total, solved_total = iters_local, n_solved
 
-    total_qps = B * world * args.steps
+    total_batch = args.global_batch if strong else B * world
+    total_qps = total_batch * args.steps
     value = total_qps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     admm_iters_per_sec = iters_total * args.steps / elapsed
@@ -184,23 +199,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d %s QPs n=%d m=%d per GPU (%d total), %s" % (
                     {"c3": "BASELINE configs[2] shard", "c2": "BASELINE configs[1]", "c5": "BASELINE configs[4]"}[args.workload],
-                    B, "CSR-A (5 % dense)" if csr is not None else "dense", n, m, B * world,
+                    B, "CSR-A (5 % dense)" if csr is not None else "dense", n, m, total_batch,
                     ("fixed %d ADMM iterations (check_termination=0)" % args.iters) if args.mode == "fixed"
-                    else "reference default settings (eps 1e-3, check 25, max_iter 1000)"),
-                "n": n, "m": m, "batch_per_gpu": B, "global_batch": B * world, "mode": args.mode,
+                    else "reference default settings (eps 1e-3, check 25, max_iter 1000)" if args.mode == "default"
+                    else "the SQP driver's QP settings (src/sqp.cpp:15-23: eps 1e-4, check 10, max_iter 100, adaptive rho / 50, alpha 1.6)"),
+                "n": n, "m": m, "batch_per_gpu": B, "global_batch": total_batch, "mode": args.mode,
                 "admm_iters_per_qp": iters_per_qp, "kernel": solver.kernel_name(),
                 "parallelism": "batch-sharded x%d" % world,
                 "gather": bool(gather_bufs is not None),
             },
             "admm_iters_per_sec": admm_iters_per_sec,
-            "solved_fraction": solved_total / float(B * world),
+            "solved_fraction": solved_total / float(total_batch),
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -230,22 +246,36 @@ def main():
             # sanity: the gathered record of rank 0's own shard equals its resident state
             xs = gather_bufs.stacked()[0]
             assert torch.equal(xs[:B], gather_bufs.local[0]), "gather mismatch"
-            assert xs.shape[0] == B * world
+            assert xs.shape[0] == total_batch
         dist.barrier()
         dist.destroy_process_group()
     return out
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources (sqp_solver_amd/csrc/*): a PMC traffic record is only valid for the code it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sqp_solver_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def pmc_traffic(kernel, n, m, batch, mode):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 calibration in
-    profiles/r01_fetch_size_calibration.txt). None when no profile of this exact kernel/workload exists."""
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in separate passes;
+    FETCH_SIZE x2 per the gfx950 calibration in profiles/r01_fetch_size_calibration.txt).  The table (profiles/pmc_traffic.json,
+    written by tools/record_traffic.py from a tools/profile_gpu.sh run) is keyed by kernel, workload AND the hash of the kernel
+    sources: None when this exact code has not been profiled on this workload (rocprofv3 cannot run inside this process)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         table = json.load(open(path))
     except Exception:
         return None
-    return table.get("%s|n=%d|m=%d|batch=%d|%s" % (kernel, n, m, batch, mode))
+    return table.get("%s|n=%d|m=%d|batch=%d|%s|src=%s" % (kernel, n, m, batch, mode, kernel_source_hash()))
 
 
 def cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt):

@@ -179,6 +179,29 @@ int sqph_device_state(sqph_solver *s, void **x, void **y, void **z, sqph_info **
 
 int sqph_synchronize(sqph_solver *s);
 
+/* ---- multi-GPU (single process, one handle per device): SURVEY.md §8(e).  The batch shards contiguously over the devices
+ * (sqph_shard_bounds), every device solves its shard on its own stream with no data-path exchange, and the only
+ * communication is the collection of the result records on a root device: peer-to-peer copies over xGMI
+ * (hipMemcpyPeerAsync), posted on the producing solver's stream right behind its solve. */
+/* Contiguous block split of `total` QPs over `parts` devices/ranks (the first total % parts get one more): [lo, hi). */
+void sqph_shard_bounds(long long total, int parts, int part, long long *lo, long long *hi);
+/* Number of HIP devices visible to this process (0 when none / on error). */
+int sqph_device_count(void);
+/* Give the solver a private non-blocking stream on its device (destroyed with the solver) so that solvers on different
+ * devices — or several solvers on one — run concurrently from one host thread. */
+int sqph_own_stream(sqph_solver *s);
+/* Root-side buffers for the gathered records of `total` QPs (fp64 x [total][n], y [total][m], sqph_info [total]) on `device`. */
+typedef struct sqph_gather sqph_gather;
+int sqph_gather_create(sqph_gather **out, int device, int n, int m, long long total);
+void sqph_gather_destroy(sqph_gather *g);
+/* Enqueue, on src's stream, the copy of src's first `count` result records to positions [offset, offset+count) of the
+ * gather buffers (peer copy when src lives on another device).  Asynchronous. */
+int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int count);
+/* Wait for every posted copy, then copy the gathered records to host buffers (NULL = skip; x/y narrowed to `dtype`). */
+int sqph_gather_fetch(sqph_gather *g, int dtype, void *x, void *y, sqph_info *info);
+/* Wait for every posted copy and expose the device buffers (valid until sqph_gather_destroy). */
+int sqph_gather_device_ptrs(sqph_gather *g, void **x, void **y, sqph_info **info);
+
 /* Name of the kernel variant the last launch used ("generic_w1", "tile_13x7", ...). */
 const char *sqph_kernel_name(const sqph_solver *s);
 /* Last launch duration helpers: records HIP events around every launch when enabled. */

@@ -110,6 +110,7 @@ struct sqph_solver {
     int device = 0, n = 0, m = 0, cap = 0, dtype = SQPH_F64, flags = 0;
     int num_simds = 1024;  // 4 per CU
     hipStream_t stream = nullptr;
+    bool stream_owned = false;
     sqph_settings settings{};
     // persistent device state
     void *x = nullptr, *z = nullptr, *y = nullptr, *rho_vec = nullptr, *rho = nullptr;
@@ -266,6 +267,7 @@ void sqph_destroy(sqph_solver *s) {
     DeviceGuard g(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     else (void)hipDeviceSynchronize();
+    if (s->stream_owned) (void)hipStreamDestroy(s->stream);
     void *ptrs[] = {s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su, s->cRow, s->cCol, s->cVal, s->cA, s->cBad};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -283,8 +285,39 @@ void sqph_destroy(sqph_solver *s) {
 
 int sqph_set_stream(sqph_solver *s, void *hip_stream) {
     if (!s) return SQPH_ERR_INVALID;
+    if (s->stream_owned) {
+        DeviceGuard g(s->device);
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipStreamDestroy(s->stream);
+        s->stream_owned = false;
+    }
     s->stream = (hipStream_t)hip_stream;
     return SQPH_OK;
+}
+
+int sqph_own_stream(sqph_solver *s) {
+    if (!s) return SQPH_ERR_INVALID;
+    if (s->stream_owned) return SQPH_OK;
+    DeviceGuard g(s->device);
+    hipStream_t st = nullptr;
+    SQPH_HIP(s, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    s->stream = st;
+    s->stream_owned = true;
+    return SQPH_OK;
+}
+
+void sqph_shard_bounds(long long total, int parts, int part, long long *lo, long long *hi) {
+    if (parts <= 0) parts = 1;
+    const long long base = total / parts, rem = total % parts;
+    const long long a = (long long)part * base + (part < rem ? part : rem);
+    if (lo) *lo = a;
+    if (hi) *hi = a + base + (part < rem ? 1 : 0);
+}
+
+int sqph_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
 }
 
 int sqph_set_settings(sqph_solver *s, const sqph_settings *st) {
@@ -773,6 +806,132 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
 }
 
 }  // namespace
+
+
+struct sqph_gather {
+    int device = 0, n = 0, m = 0;
+    long long total = 0;
+    double *x = nullptr, *y = nullptr;
+    sqph_info *info = nullptr;
+    std::vector<hipEvent_t> pending;   // one per posted copy, recorded on the producer's stream
+    std::vector<int> pending_dev;
+    std::string err;
+};
+
+extern "C" {
+int sqph_gather_create(sqph_gather **out, int device, int n, int m, long long total) {
+    if (!out) return SQPH_ERR_INVALID;
+    *out = nullptr;
+    if (n <= 0 || m < 0 || total <= 0) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_gather_create: bad shape");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_NO_DEVICE, "sqph_gather_create: no HIP device visible");
+    if (device < 0 || device >= ndev) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_gather_create: device %d out of range", device);
+    sqph_gather *g = new (std::nothrow) sqph_gather();
+    if (!g) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_gather_create: out of host memory");
+    g->device = device; g->n = n; g->m = m; g->total = total;
+    DeviceGuard dg(device);
+    const size_t mm = (size_t)(m > 0 ? m : 1);
+    hipError_t e = hipMalloc((void **)&g->x, (size_t)total * n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->y, (size_t)total * mm * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->info, (size_t)total * sizeof(sqph_info));
+    if (e != hipSuccess) {
+        g_err = std::string("sqph_gather_create: ") + hipGetErrorString(e);
+        sqph_gather_destroy(g);
+        return SQPH_ERR_HIP;
+    }
+    *out = g;
+    return SQPH_OK;
+}
+
+void sqph_gather_destroy(sqph_gather *g) {
+    if (!g) return;
+    for (size_t i = 0; i < g->pending.size(); i++) {
+        DeviceGuard dg(g->pending_dev[i]);
+        (void)hipEventSynchronize(g->pending[i]);
+        (void)hipEventDestroy(g->pending[i]);
+    }
+    DeviceGuard dg(g->device);
+    if (g->x) (void)hipFree(g->x);
+    if (g->y) (void)hipFree(g->y);
+    if (g->info) (void)hipFree(g->info);
+    delete g;
+}
+
+int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int count) {
+    if (!g || !src) return SQPH_ERR_INVALID;
+    if (src->n != g->n || src->m != g->m) SQPH_FAIL(src, SQPH_ERR_INVALID, "sqph_gather_post: shape mismatch");
+    if (count < 0 || count > src->cap || offset < 0 || offset + count > g->total) SQPH_FAIL(src, SQPH_ERR_INVALID, "sqph_gather_post: range [%lld, %lld) outside the gather buffers / solver capacity", offset, offset + count);
+    if (count == 0) return SQPH_OK;
+    DeviceGuard dg(src->device);
+    const size_t n = g->n, m = g->m, c = (size_t)count;
+    if (src->device != g->device) {
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, src->device, g->device);
+        if (can) (void)hipDeviceEnablePeerAccess(g->device, 0);  // idempotent (an "already enabled" error is cleared below)
+        (void)hipGetLastError();
+    }
+    SQPH_HIP(src, hipMemcpyPeerAsync(g->x + (size_t)offset * n, g->device, src->x, src->device, c * n * sizeof(double), src->stream));
+    if (m) SQPH_HIP(src, hipMemcpyPeerAsync(g->y + (size_t)offset * m, g->device, src->y, src->device, c * m * sizeof(double), src->stream));
+    SQPH_HIP(src, hipMemcpyPeerAsync(g->info + offset, g->device, src->info, src->device, c * sizeof(sqph_info), src->stream));
+    hipEvent_t ev;
+    SQPH_HIP(src, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    SQPH_HIP(src, hipEventRecord(ev, src->stream));
+    g->pending.push_back(ev);
+    g->pending_dev.push_back(src->device);
+    return SQPH_OK;
+}
+
+static int gather_wait(sqph_gather *g) {
+    for (size_t i = 0; i < g->pending.size(); i++) {
+        DeviceGuard dg(g->pending_dev[i]);
+        hipError_t e = hipEventSynchronize(g->pending[i]);
+        (void)hipEventDestroy(g->pending[i]);
+        if (e != hipSuccess) {
+            g_err = std::string("sqph_gather: ") + hipGetErrorString(e);
+            g->pending.clear();
+            g->pending_dev.clear();
+            return SQPH_ERR_HIP;
+        }
+    }
+    g->pending.clear();
+    g->pending_dev.clear();
+    return SQPH_OK;
+}
+
+int sqph_gather_device_ptrs(sqph_gather *g, void **x, void **y, sqph_info **info) {
+    if (!g) return SQPH_ERR_INVALID;
+    const int rc = gather_wait(g);
+    if (rc != SQPH_OK) return rc;
+    if (x) *x = g->x;
+    if (y) *y = g->y;
+    if (info) *info = g->info;
+    return SQPH_OK;
+}
+
+int sqph_gather_fetch(sqph_gather *g, int dtype, void *x, void *y, sqph_info *info) {
+    if (!g) return SQPH_ERR_INVALID;
+    if (dtype != SQPH_F64 && dtype != SQPH_F32) return SQPH_ERR_INVALID;
+    const int rc = gather_wait(g);
+    if (rc != SQPH_OK) return rc;
+    DeviceGuard dg(g->device);
+    const size_t T = (size_t)g->total;
+    struct Item { void *dst; const double *src; size_t elems; };
+    const Item items[2] = {{x, g->x, T * g->n}, {y, g->y, T * g->m}};
+    for (const Item &it : items) {
+        if (!it.dst || !it.elems) continue;
+        if (dtype == SQPH_F64) {
+            SQPH_HIP((sqph_solver *)nullptr, hipMemcpy(it.dst, it.src, it.elems * sizeof(double), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<double> tmp(it.elems);
+            SQPH_HIP((sqph_solver *)nullptr, hipMemcpy(tmp.data(), it.src, it.elems * sizeof(double), hipMemcpyDeviceToHost));
+            float *d = (float *)it.dst;
+            for (size_t i = 0; i < it.elems; i++) d[i] = (float)tmp[i];
+        }
+    }
+    if (info) SQPH_HIP((sqph_solver *)nullptr, hipMemcpy(info, g->info, T * sizeof(sqph_info), hipMemcpyDeviceToHost));
+    return SQPH_OK;
+}
+}  // extern "C"
 
 extern "C" {
 int sqph_setup_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s, qp, sqph::MODE_SETUP, "sqph_setup_csr"); }
