@@ -13,6 +13,7 @@
 //   sqp::Info / Status             sqp.hpp:33-38       sqp::Info / Status
 //   sqp::SQP<Scalar>::solve        sqp.cpp:26-41       sqp::BatchSQP<Scalar>::solve (N instances)
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <vector>
@@ -193,6 +194,7 @@ class BatchSQP {
     const Scalar *dual_solution(int i) const { return inst_[i].lambda.data(); }
     const Info &info(int i) const { return inst_[i].info; }
     int qp_launches() const { return launches_; }
+    double qp_backend_ms() const { return qp_ms_; }  // wall time spent inside the QP backend (staging, launch, fetch)
 
    private:
     struct Inst {
@@ -218,7 +220,10 @@ class BatchSQP {
         std::copy(I.qu.begin(), I.qu.begin() + m, u_.begin() + k * m);
     }
     void run_qp(const std::vector<int> &live) {
+        const auto t0 = std::chrono::steady_clock::now();
         qp_.setup_solve(qp_.packed((int)live.size(), P_.data(), q_.data(), A_.data(), l_.data(), u_.data()));
+        (void)qp_.info(0);  // fetch the results (one packed D2H)
+        qp_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         launches_++;
         for (size_t k = 0; k < live.size(); k++) {
             Inst &I = inst_[live[k]];
@@ -327,6 +332,7 @@ class BatchSQP {
 
     int n_, m_, batch_;
     int launches_ = 0;
+    double qp_ms_ = 0;
     Settings settings_;
     QPBackend qp_;
     trace_fn trace_ = nullptr;

@@ -1,0 +1,414 @@
+// Lane-per-QP ADMM kernel for tiny problems (n <= NMAX, m <= MMAX; the SQP driver's subproblems, BASELINE config 4: n = 2, m = 3).
+//
+// For a 2 x 3 QP the workgroup- and group-tiled kernels spend their time on LDS round trips and wave-level hand-offs that a problem
+// of 17 numbers does not need: here ONE LANE owns one QP — P, A, the factor W and every vector live in that lane's registers, there
+// is no LDS, no cross-lane operation and no barrier; 64 QPs per wavefront, lanes diverge freely (different iteration counts,
+// refactorisations).  A solve that is latency-bound at ~1 us per iteration in the 16-lanes-per-QP kernel runs at the FMA dependency
+// chain of a handful of operations instead.
+//
+// Numerics: the formulas of admm_generic.h (reference src/qp.cpp:84-144 on the Schur-ordered system, factor W of factor_schur:
+// S = P_sym + sigma I + A'RA = D_J^1/2 (L D L') D_J^1/2, W = D^-1/2 L^-1 D_J^-1/2, x~ = W'(W (sigma x - q + A'w)), z~ = A x~), fp64
+// arithmetic, TIN inputs.  Modes, status / iteration bookkeeping and the factor's layout in the workspace are those of the other
+// kernels (kargs.h), so setup() with this kernel and solve() with another — or the reverse — compose.
+#pragma once
+#include "block_ops.h"
+#include "kargs.h"
+
+namespace sqph {
+
+// EXACT: n == NMAX and m == MMAX are compile-time constants (every bound check folds away; the SQP driver's shapes);
+// otherwise the arrays are padded to NMAX x MMAX and the run-time n, m guard every row and column.
+template <typename TIN, int NMAX, int MMAX, bool EXACT>
+struct LaneKernel {
+    using T = double;
+    static constexpr int MM = MMAX > 0 ? MMAX : 1;
+
+    // S = P_sym + sigma I + A' diag(rho) A ; Jacobi scaling ; forward elimination of [S~ | I] ; W = D^-1/2 L^-1 D_J^-1/2.
+    // false on a non-positive / non-finite pivot (this QP only).
+    static __device__ __forceinline__ bool factor(const T (&P)[NMAX][NMAX], const T (&A)[MM][NMAX], const T (&rho)[MM], int n, int m, T sigma,
+                                                  T (&W)[NMAX][NMAX]) {
+        T S[NMAX][NMAX], sj[NMAX], dsv[NMAX];
+#pragma unroll
+        for (int i = 0; i < NMAX; i++)
+#pragma unroll
+            for (int j = 0; j < NMAX; j++) {
+                S[i][j] = 0;
+                W[i][j] = 0;
+            }
+#pragma unroll
+        for (int i = 0; i < NMAX; i++) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                if (i < n) {
+                    // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>, qp.hpp:129)
+                    const T acc = P[i][j] + (i == j ? sigma : T(0));
+                    T s = 0;
+#pragma unroll
+                    for (int k = 0; k < MMAX; k++)
+                        if (k < m) s += A[k][i] * rho[k] * A[k][j];
+                    S[i][j] = acc + s;
+                    S[j][i] = S[i][j];
+                }
+            }
+        }
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < NMAX; j++) {
+            sj[j] = T(1);
+            dsv[j] = T(1);
+            if (j < n) {
+                const T d = S[j][j];
+                if (!(d > T(0)) || !(d * T(0) == T(0))) ok = false;
+                sj[j] = T(1) / (T)sqrt((double)d);
+            }
+        }
+        if (!ok) return false;
+#pragma unroll
+        for (int i = 0; i < NMAX; i++)
+#pragma unroll
+            for (int j = 0; j < NMAX; j++) S[i][j] = S[i][j] * sj[i] * sj[j];
+#pragma unroll
+        for (int k = 0; k < NMAX; k++) {
+            if (k < n && ok) {
+                const T d = S[k][k];
+                if (!(d > T(0)) || !(d * T(0) == T(0))) {
+                    ok = false;
+                } else {
+                    const T dinv = T(1) / d;
+                    dsv[k] = d;
+                    T row[NMAX];
+#pragma unroll
+                    for (int j = 0; j < NMAX; j++) row[j] = S[k][j];
+#pragma unroll
+                    for (int i = 0; i < NMAX; i++) {
+                        if (i > k && i < n) {
+                            const T f = row[i] * dinv;
+#pragma unroll
+                            for (int j = 0; j < NMAX; j++) {
+                                const T g = (j == k) ? d + T(1) : row[j];
+                                S[i][j] = S[i][j] - f * g;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!ok) return false;
+#pragma unroll
+        for (int i = 0; i < NMAX; i++) {
+            const T rs = T(1) / (T)sqrt((double)dsv[i]);
+#pragma unroll
+            for (int j = 0; j < NMAX; j++) {
+                const T v = i > j ? S[i][j] * rs : (i == j ? rs : T(0));
+                W[i][j] = (i < n && j < n) ? v * sj[j] : T(0);
+            }
+        }
+        return true;
+    }
+
+    static __device__ __forceinline__ void run(const KArgs<T, TIN> &a) {
+        const int qp = blockIdx.x * blockDim.x + threadIdx.x;
+        if (qp >= a.batch) return;
+        const int n = EXACT ? NMAX : a.n, m = EXACT ? MMAX : a.m;
+        const TIN *gP = a.P + (long)qp * a.sP;
+        const TIN *gq = a.q + (long)qp * a.sq;
+        const TIN *gA = a.A + (long)qp * a.sA;
+        const TIN *gl = a.l + (long)qp * a.sl;
+        const TIN *gu = a.u + (long)qp * a.su;
+        T *sx = a.x + (long)qp * n;
+        T *sz = a.z + (long)qp * m;
+        T *sy = a.y + (long)qp * m;
+        T *srho = a.rho_vec + (long)qp * m;
+        int *sct = a.ctype + (long)qp * m;
+        T *gW = a.Sinv + (long)qp * 2 * n * n;
+
+        sqph_info info = a.info[qp];
+        T rho_s = a.rho[qp];
+        const int mode = a.mode;
+        if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
+            return;  // qp.cpp:68-71
+
+        const T INF = T(1) / T(0);
+        T P[NMAX][NMAX], A[MM][NMAX], W[NMAX][NMAX];
+        T q[NMAX], x[NMAX], l[MM], u[MM], z[MM], y[MM], rho[MM], rinv[MM];
+        int ct[MM];
+#pragma unroll
+        for (int j = 0; j < NMAX; j++) {
+            q[j] = j < n ? (T)gq[j] : T(0);
+            x[j] = 0;
+#pragma unroll
+            for (int i = 0; i < NMAX; i++) P[i][j] = (i < n && j < n) ? (T)gP[(long)j * n + i] : T(0);  // column-major
+#pragma unroll
+            for (int i = 0; i < MMAX; i++) A[i][j] = (i < m && j < n) ? (T)gA[(long)j * m + i] : T(0);
+        }
+#pragma unroll
+        for (int i = 0; i < MMAX; i++) {
+            l[i] = i < m ? (T)gl[i] : -INF;
+            u[i] = i < m ? (T)gu[i] : INF;
+            z[i] = y[i] = 0;
+            rho[i] = rinv[i] = T(1);
+            ct[i] = SQPH_INEQUALITY_CONSTRAINT;
+        }
+        // the reference's factor reads the lower triangle only: mirror it so that S is built from P_sym; the residual check uses
+        // the full P as given (qp.cpp:324)
+        T Pl[NMAX][NMAX];
+#pragma unroll
+        for (int i = 0; i < NMAX; i++)
+#pragma unroll
+            for (int j = 0; j < NMAX; j++) Pl[i][j] = i >= j ? P[i][j] : P[j][i];
+
+        if (mode & (MODE_SETUP | MODE_UPDATE)) {
+            rho_s = a.rho0;
+#pragma unroll
+            for (int i = 0; i < MMAX; i++) {
+                if (i < m) {
+                    int c = SQPH_INEQUALITY_CONSTRAINT;
+                    if (l[i] < -a.loose_thresh && u[i] > a.loose_thresh)
+                        c = SQPH_LOOSE_BOUNDS;
+                    else if (u[i] - l[i] < a.eq_tol)
+                        c = SQPH_EQUALITY_CONSTRAINT;
+                    ct[i] = c;
+                    rho[i] = rho_for_type<T>(c, rho_s, a.rho_min, a.rho_eq_factor);
+                    rinv[i] = T(1) / rho[i];
+                    sct[i] = c;
+                    srho[i] = rho[i];
+                }
+            }
+            info.rho_updates += 1;
+            if (!(mode & MODE_SETUP)) {
+#pragma unroll
+                for (int j = 0; j < NMAX; j++)
+                    if (j < n) x[j] = sx[j];
+#pragma unroll
+                for (int i = 0; i < MMAX; i++)
+                    if (i < m) {
+                        z[i] = sz[i];
+                        y[i] = sy[i];
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NMAX; j++)
+                if (j < n) x[j] = sx[j];
+#pragma unroll
+            for (int i = 0; i < MMAX; i++)
+                if (i < m) {
+                    z[i] = sz[i];
+                    y[i] = sy[i];
+                    rho[i] = srho[i];
+                    rinv[i] = T(1) / rho[i];
+                    ct[i] = sct[i];
+                }
+        }
+
+        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
+        bool solving = false;
+        bool state_dirty = (mode & MODE_SETUP) != 0;
+        const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
+        int iter = 1;
+        int next_check = a.check_termination > 0 ? a.check_termination : -1;
+        int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
+        if (!need_factor) {
+#pragma unroll
+            for (int i = 0; i < NMAX; i++)
+#pragma unroll
+                for (int j = 0; j < NMAX; j++) W[i][j] = (i < n && j < n) ? gW[(long)j * n + i] : T(0);
+        }
+        for (;;) {
+            if (need_factor) {
+                const bool ok = factor(Pl, A, rho, n, m, sigma, W);
+                if (!(mode & MODE_NO_FACTOR_STORE)) {
+#pragma unroll
+                    for (int i = 0; i < NMAX; i++)
+#pragma unroll
+                        for (int j = 0; j < NMAX; j++)
+                            if (i < n && j < n) gW[(long)j * n + i] = W[i][j];
+                }
+                need_factor = false;
+                if (!solving) {
+                    if (mode & (MODE_SETUP | MODE_UPDATE)) info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
+                    else if (!ok) info.status = SQPH_NUMERICAL_ISSUES;
+                } else if (!ok) {
+                    info.status = SQPH_NUMERICAL_ISSUES;  // qp.cpp:139-142: break, iter not advanced
+                    break;
+                } else {
+                    iter++;  // the for-loop increment of the iteration that requested the new factor
+                }
+            }
+            if (!(mode & MODE_SOLVE) || info.status == SQPH_NUMERICAL_ISSUES || info.status == SQPH_UNINITIALIZED) break;
+            if (!solving) {
+                solving = true;
+                state_dirty = true;
+                if ((mode & MODE_COLD_RESET) && !a.warm_start) {
+#pragma unroll
+                    for (int j = 0; j < NMAX; j++) x[j] = 0;
+#pragma unroll
+                    for (int i = 0; i < MMAX; i++) z[i] = y[i] = 0;
+                }
+            }
+            for (; iter <= a.max_iter; iter++) {
+                T b[NMAX], t[NMAX], xt[NMAX];
+#pragma unroll
+                for (int j = 0; j < NMAX; j++) b[j] = 0;
+#pragma unroll
+                for (int i = 0; i < MMAX; i++) {
+                    const T w = rho[i] * (z[i] - rinv[i] * y[i]);  // rhs tail of qp.cpp:275 pre-multiplied by R
+#pragma unroll
+                    for (int j = 0; j < NMAX; j++) b[j] += A[i][j] * w;
+                }
+#pragma unroll
+                for (int j = 0; j < NMAX; j++) b[j] = (sigma * x[j] - q[j]) + b[j];
+#pragma unroll
+                for (int i = 0; i < NMAX; i++) {
+                    T s = 0;
+#pragma unroll
+                    for (int j = 0; j <= i; j++) s += W[i][j] * b[j];
+                    t[i] = s;
+                }
+#pragma unroll
+                for (int j = 0; j < NMAX; j++) {
+                    T s = 0;
+#pragma unroll
+                    for (int i = j; i < NMAX; i++) s += W[i][j] * t[i];
+                    xt[j] = s;
+                }
+#pragma unroll
+                for (int j = 0; j < NMAX; j++) x[j] = alpha * xt[j] + oma * x[j];
+#pragma unroll
+                for (int i = 0; i < MMAX; i++) {
+                    T zt = 0;
+#pragma unroll
+                    for (int j = 0; j < NMAX; j++) zt += A[i][j] * xt[j];
+                    const T zr = alpha * zt + oma * z[i];
+                    T zn = zr + rinv[i] * y[i];
+                    zn = zn < l[i] ? l[i] : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
+                    zn = zn > u[i] ? u[i] : zn;
+                    y[i] = y[i] + rho[i] * (zr - zn);
+                    z[i] = zn;
+                }
+                bool check = false, adapt = false;
+                if (--next_check == 0) {
+                    check = true;
+                    next_check = a.check_termination;
+                }
+                if (--next_adapt == 0) {
+                    adapt = true;
+                    next_adapt = a.adaptive_rho_interval;
+                }
+                if (check || adapt) {
+                    // update_state + residuals, qp.cpp:316-331, 353-361
+                    T v[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int i = 0; i < MMAX; i++) {
+                        if (i < m) {
+                            T Ax = 0;
+#pragma unroll
+                            for (int j = 0; j < NMAX; j++) Ax += A[i][j] * x[j];
+                            v[0] = nanmax(v[0], tabs(Ax));
+                            v[1] = nanmax(v[1], tabs(z[i]));
+                            v[2] = nanmax(v[2], tabs(Ax - z[i]));
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NMAX; j++) {
+                        if (j < n) {
+                            T Px = 0, ATy = 0;
+#pragma unroll
+                            for (int k = 0; k < NMAX; k++) Px += P[j][k] * x[k];
+#pragma unroll
+                            for (int i = 0; i < MMAX; i++) ATy += A[i][j] * y[i];
+                            v[3] = nanmax(v[3], tabs(Px));
+                            v[4] = nanmax(v[4], tabs(ATy));
+                            v[5] = nanmax(v[5], tabs(q[j]));
+                            v[6] = nanmax(v[6], tabs(Px + q[j] + ATy));
+                        }
+                    }
+                    const T nrm_prim = nanmax(v[0], v[1]);
+                    const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
+                    info.res_prim = (double)v[2];
+                    info.res_dual = (double)v[6];
+                    if (check) {
+                        if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                            info.status = SQPH_SOLVED;
+                            break;
+                        }
+                    }
+                    if (adapt) {
+                        const T eps = a.regul;
+                        const T rp_norm = v[2] / (nrm_prim + eps);
+                        const T rd_norm = v[6] / (nrm_dual + eps);
+                        T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
+                        new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
+                        new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
+                        info.rho_estimate = (double)new_rho;
+                        if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
+                            rho_s = new_rho;
+#pragma unroll
+                            for (int i = 0; i < MMAX; i++) {
+                                rho[i] = rho_for_type<T>(ct[i], rho_s, a.rho_min, a.rho_eq_factor);
+                                rinv[i] = T(1) / rho[i];
+                            }
+                            info.rho_updates += 1;
+                            need_factor = true;
+                            break;  // leave the iteration loop WITHOUT advancing iter; the factor block does it
+                        }
+                    }
+                }
+            }
+            if (!need_factor) break;
+        }
+        if (solving) {
+            if (iter > a.max_iter) info.status = SQPH_MAX_ITER_EXCEEDED;
+            info.iter = iter;
+        }
+        if (state_dirty) {
+#pragma unroll
+            for (int j = 0; j < NMAX; j++)
+                if (j < n) sx[j] = x[j];
+#pragma unroll
+            for (int i = 0; i < MMAX; i++)
+                if (i < m) {
+                    sz[i] = z[i];
+                    sy[i] = y[i];
+                    srho[i] = rho[i];
+                }
+        }
+        a.info[qp] = info;
+        a.rho[qp] = rho_s;
+    }
+};
+
+template <typename TIN, int NMAX, int MMAX, bool EXACT>
+__global__ __launch_bounds__(64) void admm_lane_kernel(KArgs<double, TIN> a) {
+    LaneKernel<TIN, NMAX, MMAX, EXACT>::run(a);
+}
+
+// shapes compiled into the library: {NMAX, MMAX, EXACT}; first match wins (exact: n == NMAX && m == MMAX; else n <= NMAX && m <= MMAX).
+// The exact ones are the shapes of the reference's SQP test problems (tests/sqp_test.cpp, tests/sqp_test_autodiff.cpp).
+#ifdef SQPH_SLIM
+#define SQPH_LANE_SHAPES(X)
+#else
+#define SQPH_LANE_SHAPES(X) \
+    X(2, 3, true)           \
+    X(2, 2, true)           \
+    X(3, 3, true)           \
+    X(2, 1, true)           \
+    X(4, 6, false)
+#endif
+#define SQPH_LANE_MATCH(a, N_, M_, E_) ((E_) ? ((a).n == N_ && (a).m == M_) : ((a).n <= N_ && (a).m <= M_))
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_lane(const KArgs<double, TIN> &a) {
+#define SQPH_SIM_CASE(N_, M_, E_)                                                                          \
+    if (SQPH_LANE_MATCH(a, N_, M_, E_)) {                                                                  \
+        ::sqph_sim::launch(admm_lane_kernel<TIN, N_, M_, E_>, dim3((a.batch + 63) / 64), dim3(64), 0, a);  \
+        return 0;                                                                                          \
+    }
+    SQPH_LANE_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
+
+}  // namespace sqph

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -56,6 +57,23 @@ __global__ void pack_words(const unsigned long long *s0, size_t n0, const unsign
 }
 
 constexpr size_t SMALL_CALL_BYTES = 4u << 20;
+constexpr size_t ZERO_COPY_BYTES = 256u << 10;  // beyond this the kernels' re-reads of A and P at termination checks should hit HBM, not PCIe
+
+// Small host-memspace calls (the SQP driver's per-iteration subproblem batches) are latency-bound: the kernels read the
+// problem data straight from a pinned, device-mapped host buffer and the results are packed straight into another one
+// (no H2D / D2H copy commands), and the host waits by polling the stream for a bounded time before it falls back to the
+// blocking wait (whose wake-up latency is tens of microseconds).  SQPH_NO_ZEROCOPY=1 restores the copy path (A/B).
+bool zero_copy_enabled() {
+    static const bool off = getenv("SQPH_NO_ZEROCOPY") != nullptr;
+    return !off;
+}
+hipError_t wait_stream_low_latency(hipStream_t st) {
+    for (int spin = 0; spin < 20000; spin++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+    return hipStreamSynchronize(st);
+}
 
 // CSR -> dense column-major expansion of the constraint matrices (one thread per (QP, row): duplicates within a row
 // are summed in storage order, so the result is deterministic).  `dst` must be zero-filled.
@@ -126,6 +144,7 @@ struct sqph_solver {
     // small host-memspace calls (the SQP driver's n = 2..50 subproblems): one pinned staging buffer each way, one
     // H2D / D2H per call instead of one per array
     void *hpin = nullptr, *dpin = nullptr, *hout = nullptr, *dout = nullptr;
+    void *hpin_dev = nullptr, *hout_dev = nullptr;  // device addresses of the two pinned buffers (zero-copy path)
     size_t hpin_cap = 0, hout_cap = 0;
     hipEvent_t pin_ev = nullptr;
     bool pin_busy = false;
@@ -400,19 +419,22 @@ int sqph_get_solution(sqph_solver *s, int batch, int memspace, void *x, void *y,
             if (words * 8 > s->hout_cap) {
                 if (s->hout) (void)hipHostFree(s->hout);
                 if (s->dout) (void)hipFree(s->dout);
-                s->hout = s->dout = nullptr;
+                s->hout = s->dout = s->hout_dev = nullptr;
                 s->hout_cap = 0;
                 const size_t cap = words * 8 < 65536 ? 65536 : words * 8;
-                SQPH_HIP(s, hipHostMalloc(&s->hout, cap, hipHostMallocDefault));
+                SQPH_HIP(s, hipHostMalloc(&s->hout, cap, hipHostMallocMapped));
                 SQPH_HIP(s, hipMalloc(&s->dout, cap));
+                if (hipHostGetDevicePointer(&s->hout_dev, s->hout, 0) != hipSuccess) s->hout_dev = nullptr;
                 s->hout_cap = cap;
             }
+            const bool zc = zero_copy_enabled() && s->hout_dev;
             hipLaunchKernelGGL(pack_words, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s->stream,
                                (const unsigned long long *)s->x, w0, (const unsigned long long *)s->y, w1,
-                               (const unsigned long long *)s->z, w2, (const unsigned long long *)s->info, w3, (unsigned long long *)s->dout);
+                               (const unsigned long long *)s->z, w2, (const unsigned long long *)s->info, w3,
+                               (unsigned long long *)(zc ? s->hout_dev : s->dout));
             SQPH_HIP(s, hipGetLastError());
-            SQPH_HIP(s, hipMemcpyAsync(s->hout, s->dout, words * 8, hipMemcpyDeviceToHost, s->stream));
-            SQPH_HIP(s, hipStreamSynchronize(s->stream));
+            if (!zc) SQPH_HIP(s, hipMemcpyAsync(s->hout, s->dout, words * 8, hipMemcpyDeviceToHost, s->stream));
+            SQPH_HIP(s, wait_stream_low_latency(s->stream));
             const double *h = (const double *)s->hout;
             void *dsts[3] = {x, y, z};
             const size_t ws[3] = {w0, w1, w2};
@@ -550,7 +572,8 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     }
     if (!launched && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
         int rc = 0;
-        rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
+        rc = lane_try_launch<TIN>(a, s->stream, &s->kernel_name);
+        if (rc == 0) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = g32_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "tiled kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -598,9 +621,9 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
     long long sP = qp->stride_P, sq = qp->stride_q, sA = qp->stride_A, sl = qp->stride_l, su = qp->stride_u;
     const size_t e = dsize(s->dtype);
     const size_t n = s->n, m = s->m;
-    bool staged = false;
+    bool staged = false, pin_zero_copy = false;
     if (qp->memspace == SQPH_HOST) {
-        // small calls: pack everything into one pinned buffer, one H2D
+        // small calls: pack everything into one pinned buffer (read in place by the kernel, or one H2D)
         struct PItem { const void *src; size_t elems; long long *stride; const void **out; size_t off, bytes; };
         PItem pit[5] = {{qp->P, n * n, &sP, &P, 0, 0}, {qp->q, n, &sq, &q, 0, 0}, {qp->A, csr ? 0 : m * n, &sA, &A, 0, 0},
                         {qp->l, m, &sl, &l, 0, 0}, {qp->u, m, &su, &u, 0, 0}};
@@ -616,15 +639,18 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
                 s->pin_busy = false;
                 if (s->hpin) (void)hipHostFree(s->hpin);
                 if (s->dpin) (void)hipFree(s->dpin);
-                s->hpin = s->dpin = nullptr;
+                s->hpin = s->dpin = s->hpin_dev = nullptr;
                 s->hpin_cap = 0;
                 const size_t cap = total < 65536 ? 65536 : total;
-                SQPH_HIP(s, hipHostMalloc(&s->hpin, cap, hipHostMallocDefault));
+                SQPH_HIP(s, hipHostMalloc(&s->hpin, cap, hipHostMallocMapped));
                 SQPH_HIP(s, hipMalloc(&s->dpin, cap));
+                if (hipHostGetDevicePointer(&s->hpin_dev, s->hpin, 0) != hipSuccess) s->hpin_dev = nullptr;
                 s->hpin_cap = cap;
             }
             if (!s->pin_ev) SQPH_HIP(s, hipEventCreateWithFlags(&s->pin_ev, hipEventDisableTiming));
-            if (s->pin_busy) SQPH_HIP(s, hipEventSynchronize(s->pin_ev));  // the previous call's H2D has consumed the buffer
+            if (s->pin_busy) SQPH_HIP(s, hipEventSynchronize(s->pin_ev));  // the previous call has consumed the buffer
+            s->pin_busy = false;
+            const bool zc = zero_copy_enabled() && s->hpin_dev && !csr && total <= ZERO_COPY_BYTES;
             for (auto &it : pit) {
                 if (it.elems == 0) continue;
                 char *dstp = (char *)s->hpin + it.off;
@@ -635,11 +661,14 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
                         memcpy(dstp + (size_t)b * it.elems * e, (const char *)it.src + (size_t)b * (size_t)*it.stride * e, it.elems * e);
                     *it.stride = (long long)it.elems;
                 }
-                *it.out = (const char *)s->dpin + it.off;
+                *it.out = (const char *)(zc ? s->hpin_dev : s->dpin) + it.off;
             }
-            SQPH_HIP(s, hipMemcpyAsync(s->dpin, s->hpin, total, hipMemcpyHostToDevice, s->stream));
-            SQPH_HIP(s, hipEventRecord(s->pin_ev, s->stream));
-            s->pin_busy = true;
+            if (!zc) {
+                SQPH_HIP(s, hipMemcpyAsync(s->dpin, s->hpin, total, hipMemcpyHostToDevice, s->stream));
+                SQPH_HIP(s, hipEventRecord(s->pin_ev, s->stream));
+                s->pin_busy = true;
+            }
+            pin_zero_copy = zc;  // the kernel itself reads the pinned buffer: it is busy until the launch below has finished
             staged = true;
         }
     }
@@ -666,8 +695,13 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
         // only after the stream reaches them; make the borrow end with the call.
         SQPH_HIP(s, hipStreamSynchronize(s->stream));
     }
-    if (s->dtype == SQPH_F32) return launch_typed<float>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su, csr);
-    return launch_typed<double>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su, csr);
+    const int rc = s->dtype == SQPH_F32 ? launch_typed<float>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su, csr)
+                                        : launch_typed<double>(s, qp, mode, P, q, A, l, u, sP, sq, sA, sl, su, csr);
+    if (rc == SQPH_OK && pin_zero_copy) {
+        SQPH_HIP(s, hipEventRecord(s->pin_ev, s->stream));
+        s->pin_busy = true;
+    }
+    return rc;
 }
 
 // CSR entry points: expand A on the device, then the dense path.

@@ -262,21 +262,42 @@ def test_full_size_properties_c5():
     assert np.array_equal(x2[::-1], x) and np.array_equal(y2[::-1], y) and np.array_equal(info2.iter[::-1], info.iter)
 
 
-def test_small_shapes_take_the_four_per_wave_kernel():
-    """n <= 12 / m <= 24 (SQP-sized subproblems): four QPs per wavefront; a large odd batch against the oracle"""
+def test_small_shapes_take_the_lane_and_four_per_wave_kernels():
+    """n <= 4 / m <= 6 (the SQP driver's subproblems): one QP per lane; up to n = 12 / m = 24: four QPs per wavefront;
+    a large odd batch against the oracle"""
     from sqp_solver_amd.problems import random_qp_batch
 
-    for (n, m, B) in ((2, 3, 4099), (8, 12, 2051), (12, 24, 1027)):
+    for (n, m, B, kern) in ((2, 3, 4099, "lane_2x3_exact"), (4, 6, 3001, "lane_4x6"), (3, 3, 1500, "lane_3x3_exact"), (4, 5, 700, "lane_4x6"), (8, 12, 2051, "g16_"), (12, 24, 1027, "g16_")):
         P, q, A, l, u = random_qp_batch(B, n, m, seed=31)
         s = make_gpu(n, m, B)
         s.setup_solve(P, q, A, l, u)
-        assert s.kernel_name().startswith("g16_"), s.kernel_name()
+        assert s.kernel_name().startswith(kern), s.kernel_name()
         x, y, z, info = s.solution()
         xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, oracle.default_settings(), nthreads=0)
         assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all()
         # tiny QPs can have every constraint inactive (y == 0 up to rounding): scale the dual error by max(1, |y|)
         assert cases.relerr(x, xo) < cases.TOL_F64
         assert (np.max(np.abs(y - yo), axis=1) <= cases.TOL_F64 * np.maximum(1.0, np.max(np.abs(yo), axis=1))).all()
+
+
+def test_lane_kernel_paths():
+    """the one-QP-per-lane kernel through the C-ABI: fixed iterations, alpha, float interface, termination / adaptive / SQP
+    settings (QPs without a stable reference answer excluded by parity_termination), state paths, fused-then-solve"""
+    for (n, m, B) in ((2, 3, 257), (1, 1, 65), (2, 1, 64), (3, 3, 130), (4, 6, 300)):
+        cases.parity_fixed_iters(make_gpu, n, m, B, iters=150, dual_floor=True)
+    cases.parity_fixed_iters(make_gpu, 2, 3, 64, iters=100, alpha=1.6)
+    cases.parity_fixed_iters(make_gpu, 4, 6, 64, iters=100, dtype=np.float32)
+    for kw in (dict(), dict(adaptive=True), dict(sqp_settings=True)):
+        cases.parity_termination(make_gpu, 4, 6, 200, diagnostics=not kw, **kw)
+        cases.parity_termination(make_gpu, 2, 3, 200, diagnostics=not kw, **kw)
+    cases.warm_start_and_resolve(make_gpu, n=4, m=6)
+    cases.set_state_warm_start(make_gpu, n=3, m=5)
+    cases.shared_matrices(make_gpu, n=4, m=6)
+    cases.fused_then_solve(make_gpu, n=4, m=5, batch=70, adaptive=False)  # (adaptive rho on QPs this small: no stable reference answer)
+    cases.fused_then_solve(make_gpu, n=4, m=5, batch=3)
+    s = make_gpu(2, 3, 4)
+    s.setup_solve(*cases.simple(4))
+    assert s.kernel_name() == "lane_2x3_exact"
 
 
 def test_full_size_fixed_iters_c2():

@@ -186,3 +186,36 @@ def test_g32_state_paths():
 def test_fused_call_then_solve(make, n, m):
     """factor residency policy (capi.hip, mirrored by simlib): fused setup_solve without / with keep_factor, then solve()"""
     cases.fused_then_solve(make, n=n, m=m, batch=2)
+
+
+# ---------------------------------------------------------------- one QP per lane (tiny problems)
+def make_lane(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.LANE, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
+
+
+@pytest.mark.parametrize("case", [c for c in cases.REFERENCE_CASES if c.__name__ != "ref_legacy_TestConstraint"], ids=lambda f: f.__name__)
+def test_lane_reference_cases(case):
+    case(make_lane)  # (the 5 x 5 legacy constraint case is beyond the lane kernel's shapes)
+
+
+@pytest.mark.parametrize("n,m,batch", [(2, 3, 70), (1, 1, 5), (2, 1, 9), (3, 3, 66), (4, 6, 130), (3, 0, 4)])
+def test_lane_parity_fixed(n, m, batch):
+    if m == 0:
+        cases.edge_shapes(make_lane, shapes=((1, 1), (3, 0), (4, 1), (2, 3)))
+        return
+    cases.parity_fixed_iters(make_lane, n, m, batch, iters=150, dual_floor=True)
+
+
+def test_lane_parity_alpha_float_termination_and_state_paths():
+    cases.parity_fixed_iters(make_lane, 2, 3, 9, iters=100, alpha=1.6)
+    cases.parity_fixed_iters(make_lane, 4, 6, 5, iters=100, dtype=np.float32)
+    for kw in (dict(), dict(adaptive=True), dict(sqp_settings=True)):
+        cases.parity_termination(make_lane, 4, 6, 40, **kw)
+        cases.parity_termination(make_lane, 2, 3, 40, **kw)
+    cases.warm_start_and_resolve(make_lane, n=4, m=6)
+    cases.set_state_warm_start(make_lane, n=3, m=5)
+    cases.uninitialized_and_numerical_issues(make_lane)
+    cases.shared_matrices(make_lane, n=4, m=6)
+    cases.fused_then_solve(make_lane, n=4, m=5, batch=3)
+    for kind in ("all_eq", "half_eq", "illcond"):  # (the adaptive kinds are chaotic on QPs this small: see parity_termination)
+        cases.stress_parity(make_lane, 4, 6, 8, kind, iters=120)
