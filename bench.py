@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--mode", choices=["fixed", "default", "sqp"], default="fixed")
     ap.add_argument("--iters", type=int, default=200, help="ADMM iterations per QP in --mode fixed")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--f32-arith", action="store_true", help="with --dtype f32: true fp32 arithmetic where a kernel exists (SQPH_FLAG_F32_ARITH)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--force-generic", action="store_true")
@@ -102,7 +103,7 @@ def main():
         P, q, A_cm, l, u = random_qp_batch_torch(B, n, m, seed=20250228 + 3 + 1000 * rank, dtype=tdt, device=dev)
     torch.cuda.synchronize()
 
-    solver = QPSolverBatch(n, m, B, dtype=ndt, device=local_rank, force_generic=args.force_generic)
+    solver = QPSolverBatch(n, m, B, dtype=ndt, device=local_rank, force_generic=args.force_generic, f32_arith=args.f32_arith)
     st = solver.settings
     if args.mode == "fixed":
         st.max_iter = args.iters

@@ -138,7 +138,13 @@ enum {
      * it a fused call writes no factor, and a later sqph_solve* on that handle rebuilds the factor first — same arithmetic,
      * same results, one extra factorisation.  sqph_setup / sqph_update_qp always leave their factor resident.  Set this for
      * callers that follow a fused call with sqph_solve on new q, l, u (SQP second-order correction, MPC). */
-    SQPH_FLAG_KEEP_FACTOR = 16
+    SQPH_FLAG_KEEP_FACTOR = 16,
+    /* QPSolver<float> in TRUE single precision where a kernel for it exists (the one-QP-per-lane kernel, n <= 4, m <= 6):
+     * iterates, factor and residuals in fp32.  Default (flag clear): fp32 at the interface only, fp64 arithmetic — the
+     * Schur-complement factor loses ~3 digits more than the reference's KKT LDL' in fp32, so the true-fp32 solve
+     * agrees with the reference's QPSolver<float> to ~1e-3, not to fp32 round-off.  Ignored for dtype SQPH_F64 and for shapes
+     * without an fp32 kernel (they iterate in fp64). */
+    SQPH_FLAG_F32_ARITH = 32
 };
 
 void sqph_default_settings(sqph_settings *s);

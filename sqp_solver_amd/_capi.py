@@ -10,7 +10,7 @@ F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 SOLVED, MAX_ITER_EXCEEDED, UNSOLVED, NUMERICAL_ISSUES, UNINITIALIZED = range(5)
 INEQUALITY_CONSTRAINT, EQUALITY_CONSTRAINT, LOOSE_BOUNDS = range(3)
-FLAG_LEGACY_COLD_START, FLAG_FORCE_GENERIC, FLAG_CSR_EXPAND, FLAG_KEEP_FACTOR = 1, 2, 8, 16
+FLAG_LEGACY_COLD_START, FLAG_FORCE_GENERIC, FLAG_CSR_EXPAND, FLAG_KEEP_FACTOR, FLAG_F32_ARITH = 1, 2, 8, 16, 32
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 
 # every symbol include/sqp_hip.h declares

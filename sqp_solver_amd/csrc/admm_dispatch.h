@@ -10,14 +10,15 @@
 namespace sqph {
 
 // one QP per lane for tiny shapes (admm_lane_kernel.h): >0 launched, 0 not covered, <0 error
-template <typename TIN>
+template <typename TIN, typename TA = double>
 inline int lane_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
     static const bool off = getenv("SQPH_NO_LANE") != nullptr;  // experiments only
     if (off) return 0;
 #define SQPH_LANE_CASE(N_, M_, E_)                                                                                    \
     if (SQPH_LANE_MATCH(a, N_, M_, E_)) {                                                                             \
-        hipLaunchKernelGGL((admm_lane_kernel<TIN, N_, M_, E_>), dim3((a.batch + 63) / 64), dim3(64), 0, stream, a);   \
-        *name = (E_) ? "lane_" #N_ "x" #M_ "_exact" : "lane_" #N_ "x" #M_;                                            \
+        hipLaunchKernelGGL((admm_lane_kernel<TA, TIN, N_, M_, E_>), dim3((a.batch + 63) / 64), dim3(64), 0, stream, a);   \
+        *name = sizeof(TA) == 4 ? ((E_) ? "lane_" #N_ "x" #M_ "_exact_f32" : "lane_" #N_ "x" #M_ "_f32")                \
+                                : ((E_) ? "lane_" #N_ "x" #M_ "_exact" : "lane_" #N_ "x" #M_);                          \
         return hipGetLastError() == hipSuccess ? 1 : -1;                                                              \
     }
     SQPH_LANE_SHAPES(SQPH_LANE_CASE)

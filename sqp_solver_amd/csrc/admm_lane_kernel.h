@@ -18,9 +18,12 @@ namespace sqph {
 
 // EXACT: n == NMAX and m == MMAX are compile-time constants (every bound check folds away; the SQP driver's shapes);
 // otherwise the arrays are padded to NMAX x MMAX and the run-time n, m guard every row and column.
-template <typename TIN, int NMAX, int MMAX, bool EXACT>
+// TA = arithmetic type: double (default: fp64 whatever the interface Scalar is) or float (SQPH_FLAG_F32_ARITH with a float
+// interface: a true single-precision solve — iterates, factor and residuals in fp32; the resident state arrays stay fp64 and are
+// converted at the kernel's boundary).
+template <typename TA, typename TIN, int NMAX, int MMAX, bool EXACT>
 struct LaneKernel {
-    using T = double;
+    using T = TA;
     static constexpr int MM = MMAX > 0 ? MMAX : 1;
 
     // S = P_sym + sigma I + A' diag(rho) A ; Jacobi scaling ; forward elimination of [S~ | I] ; W = D^-1/2 L^-1 D_J^-1/2.
@@ -106,7 +109,7 @@ struct LaneKernel {
         return true;
     }
 
-    static __device__ __forceinline__ void run(const KArgs<T, TIN> &a) {
+    static __device__ __forceinline__ void run(const KArgs<double, TIN> &a) {
         const int qp = blockIdx.x * blockDim.x + threadIdx.x;
         if (qp >= a.batch) return;
         const int n = EXACT ? NMAX : a.n, m = EXACT ? MMAX : a.m;
@@ -115,15 +118,18 @@ struct LaneKernel {
         const TIN *gA = a.A + (long)qp * a.sA;
         const TIN *gl = a.l + (long)qp * a.sl;
         const TIN *gu = a.u + (long)qp * a.su;
-        T *sx = a.x + (long)qp * n;
-        T *sz = a.z + (long)qp * m;
-        T *sy = a.y + (long)qp * m;
-        T *srho = a.rho_vec + (long)qp * m;
+        double *sx = a.x + (long)qp * n;
+        double *sz = a.z + (long)qp * m;
+        double *sy = a.y + (long)qp * m;
+        double *srho = a.rho_vec + (long)qp * m;
         int *sct = a.ctype + (long)qp * m;
-        T *gW = a.Sinv + (long)qp * 2 * n * n;
+        double *gW = a.Sinv + (long)qp * 2 * n * n;
 
         sqph_info info = a.info[qp];
-        T rho_s = a.rho[qp];
+        T rho_s = (T)a.rho[qp];
+        // settings and class constants in the arithmetic type
+        const T a_rho0 = (T)a.rho0, a_loose = (T)a.loose_thresh, a_eq_tol = (T)a.eq_tol, a_rho_min = (T)a.rho_min, a_rho_max = (T)a.rho_max;
+        const T a_eqf = (T)a.rho_eq_factor, a_eps_abs = (T)a.eps_abs, a_eps_rel = (T)a.eps_rel, a_regul = (T)a.regul, a_rho_tol = (T)a.rho_tol;
         const int mode = a.mode;
         if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
             return;  // qp.cpp:68-71
@@ -158,44 +164,44 @@ struct LaneKernel {
             for (int j = 0; j < NMAX; j++) Pl[i][j] = i >= j ? P[i][j] : P[j][i];
 
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
-            rho_s = a.rho0;
+            rho_s = a_rho0;
 #pragma unroll
             for (int i = 0; i < MMAX; i++) {
                 if (i < m) {
                     int c = SQPH_INEQUALITY_CONSTRAINT;
-                    if (l[i] < -a.loose_thresh && u[i] > a.loose_thresh)
+                    if (l[i] < -a_loose && u[i] > a_loose)
                         c = SQPH_LOOSE_BOUNDS;
-                    else if (u[i] - l[i] < a.eq_tol)
+                    else if (u[i] - l[i] < a_eq_tol)
                         c = SQPH_EQUALITY_CONSTRAINT;
                     ct[i] = c;
-                    rho[i] = rho_for_type<T>(c, rho_s, a.rho_min, a.rho_eq_factor);
+                    rho[i] = rho_for_type<T>(c, rho_s, a_rho_min, a_eqf);
                     rinv[i] = T(1) / rho[i];
                     sct[i] = c;
-                    srho[i] = rho[i];
+                    srho[i] = (double)rho[i];
                 }
             }
             info.rho_updates += 1;
             if (!(mode & MODE_SETUP)) {
 #pragma unroll
                 for (int j = 0; j < NMAX; j++)
-                    if (j < n) x[j] = sx[j];
+                    if (j < n) x[j] = (T)sx[j];
 #pragma unroll
                 for (int i = 0; i < MMAX; i++)
                     if (i < m) {
-                        z[i] = sz[i];
-                        y[i] = sy[i];
+                        z[i] = (T)sz[i];
+                        y[i] = (T)sy[i];
                     }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NMAX; j++)
-                if (j < n) x[j] = sx[j];
+                if (j < n) x[j] = (T)sx[j];
 #pragma unroll
             for (int i = 0; i < MMAX; i++)
                 if (i < m) {
-                    z[i] = sz[i];
-                    y[i] = sy[i];
-                    rho[i] = srho[i];
+                    z[i] = (T)sz[i];
+                    y[i] = (T)sy[i];
+                    rho[i] = (T)srho[i];
                     rinv[i] = T(1) / rho[i];
                     ct[i] = sct[i];
                 }
@@ -204,7 +210,7 @@ struct LaneKernel {
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
-        const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
+        const T alpha = (T)a.alpha, sigma = (T)a.sigma, oma = T(1) - (T)a.alpha;
         int iter = 1;
         int next_check = a.check_termination > 0 ? a.check_termination : -1;
         int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
@@ -212,7 +218,7 @@ struct LaneKernel {
 #pragma unroll
             for (int i = 0; i < NMAX; i++)
 #pragma unroll
-                for (int j = 0; j < NMAX; j++) W[i][j] = (i < n && j < n) ? gW[(long)j * n + i] : T(0);
+                for (int j = 0; j < NMAX; j++) W[i][j] = (i < n && j < n) ? (T)gW[(long)j * n + i] : T(0);
         }
         for (;;) {
             if (need_factor) {
@@ -222,7 +228,7 @@ struct LaneKernel {
                     for (int i = 0; i < NMAX; i++)
 #pragma unroll
                         for (int j = 0; j < NMAX; j++)
-                            if (i < n && j < n) gW[(long)j * n + i] = W[i][j];
+                            if (i < n && j < n) gW[(long)j * n + i] = (double)W[i][j];
                 }
                 need_factor = false;
                 if (!solving) {
@@ -328,24 +334,24 @@ struct LaneKernel {
                     info.res_prim = (double)v[2];
                     info.res_dual = (double)v[6];
                     if (check) {
-                        if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                        if (v[2] <= a_eps_abs + a_eps_rel * nrm_prim && v[6] <= a_eps_abs + a_eps_rel * nrm_dual) {
                             info.status = SQPH_SOLVED;
                             break;
                         }
                     }
                     if (adapt) {
-                        const T eps = a.regul;
+                        const T eps = a_regul;
                         const T rp_norm = v[2] / (nrm_prim + eps);
                         const T rd_norm = v[6] / (nrm_dual + eps);
                         T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
-                        new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
-                        new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
+                        new_rho = new_rho < a_rho_max ? new_rho : a_rho_max;
+                        new_rho = new_rho > a_rho_min ? new_rho : a_rho_min;
                         info.rho_estimate = (double)new_rho;
-                        if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
+                        if (new_rho < rho_s / a_rho_tol || new_rho > rho_s * a_rho_tol) {
                             rho_s = new_rho;
 #pragma unroll
                             for (int i = 0; i < MMAX; i++) {
-                                rho[i] = rho_for_type<T>(ct[i], rho_s, a.rho_min, a.rho_eq_factor);
+                                rho[i] = rho_for_type<T>(ct[i], rho_s, a_rho_min, a_eqf);
                                 rinv[i] = T(1) / rho[i];
                             }
                             info.rho_updates += 1;
@@ -364,23 +370,23 @@ struct LaneKernel {
         if (state_dirty) {
 #pragma unroll
             for (int j = 0; j < NMAX; j++)
-                if (j < n) sx[j] = x[j];
+                if (j < n) sx[j] = (double)x[j];
 #pragma unroll
             for (int i = 0; i < MMAX; i++)
                 if (i < m) {
-                    sz[i] = z[i];
-                    sy[i] = y[i];
-                    srho[i] = rho[i];
+                    sz[i] = (double)z[i];
+                    sy[i] = (double)y[i];
+                    srho[i] = (double)rho[i];
                 }
         }
         a.info[qp] = info;
-        a.rho[qp] = rho_s;
+        a.rho[qp] = (double)rho_s;
     }
 };
 
-template <typename TIN, int NMAX, int MMAX, bool EXACT>
+template <typename TA, typename TIN, int NMAX, int MMAX, bool EXACT>
 __global__ __launch_bounds__(64) void admm_lane_kernel(KArgs<double, TIN> a) {
-    LaneKernel<TIN, NMAX, MMAX, EXACT>::run(a);
+    LaneKernel<TA, TIN, NMAX, MMAX, EXACT>::run(a);
 }
 
 // shapes compiled into the library: {NMAX, MMAX, EXACT}; first match wins (exact: n == NMAX && m == MMAX; else n <= NMAX && m <= MMAX).
@@ -398,11 +404,11 @@ __global__ __launch_bounds__(64) void admm_lane_kernel(KArgs<double, TIN> a) {
 #define SQPH_LANE_MATCH(a, N_, M_, E_) ((E_) ? ((a).n == N_ && (a).m == M_) : ((a).n <= N_ && (a).m <= M_))
 
 #ifdef SQPH_SIM
-template <typename TIN>
+template <typename TIN, typename TA = double>
 inline int sim_run_lane(const KArgs<double, TIN> &a) {
 #define SQPH_SIM_CASE(N_, M_, E_)                                                                          \
     if (SQPH_LANE_MATCH(a, N_, M_, E_)) {                                                                  \
-        ::sqph_sim::launch(admm_lane_kernel<TIN, N_, M_, E_>, dim3((a.batch + 63) / 64), dim3(64), 0, a);  \
+        ::sqph_sim::launch(admm_lane_kernel<TA, TIN, N_, M_, E_>, dim3((a.batch + 63) / 64), dim3(64), 0, a);  \
         return 0;                                                                                          \
     }
     SQPH_LANE_SHAPES(SQPH_SIM_CASE)

@@ -41,6 +41,11 @@
 #define SQPH_STICK_PASS
 #endif
 
+// unroll factor of the residual check's streaming loops over A and P (global loads in flight per lane = factor x TR resp. TC)
+#ifndef SQPH_CHECK_UNROLL
+#define SQPH_CHECK_UNROLL 1
+#endif
+
 namespace sqph {
 
 typedef double sqph_v2 __attribute__((vector_size(16)));
@@ -423,7 +428,7 @@ struct WgKernel {
         for (int s = 0; s < TR; s++) pz[s] = 0;
         T *stx = lds + L::O_STAGE;
         const T *xv = lds + L::O_COLV + c * L::TCp;
-#pragma unroll 1
+#pragma unroll SQPH_CHECK_UNROLL
         for (int k = 0; k < TC; k++) {
             const int j = TC * c + k;
             const T xk = xv[k];
@@ -446,7 +451,7 @@ struct WgKernel {
         T xc[TC];
         get_colv(lds, c, xc);
         T *sty = lds + L::O_STAGE_Y;
-#pragma unroll 1
+#pragma unroll SQPH_CHECK_UNROLL
         for (int u = 0; u < TW; u++) {
             const int i = R * u + r;
             T acc = 0;

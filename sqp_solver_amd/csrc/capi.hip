@@ -572,7 +572,8 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     }
     if (!launched && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
         int rc = 0;
-        rc = lane_try_launch<TIN>(a, s->stream, &s->kernel_name);
+        if (sizeof(TIN) == 4 && (s->flags & SQPH_FLAG_F32_ARITH)) rc = lane_try_launch<TIN, float>(a, s->stream, &s->kernel_name);
+        if (rc == 0) rc = lane_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = g32_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);

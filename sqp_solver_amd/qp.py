@@ -74,7 +74,7 @@ def constr_type_init(l, u, dtype=np.float64):
 
 class QPSolverBatch:
     def __init__(self, n, m, batch, dtype=np.float64, device=0, legacy_cold_start=False, force_generic=False, csr_expand=False,
-                 keep_factor=False):
+                 keep_factor=False, f32_arith=False):
         self._L = _capi.load()
         self.n, self.m, self.batch = int(n), int(m), int(batch)
         self.dtype = np.dtype(dtype)
@@ -83,7 +83,7 @@ class QPSolverBatch:
         self._dt = _capi.F32 if self.dtype == np.float32 else _capi.F64
         self.device = int(device)
         flags = ((_capi.FLAG_LEGACY_COLD_START if legacy_cold_start else 0) | (_capi.FLAG_FORCE_GENERIC if force_generic else 0)
-                 | (_capi.FLAG_CSR_EXPAND if csr_expand else 0) | (_capi.FLAG_KEEP_FACTOR if keep_factor else 0))
+                 | (_capi.FLAG_CSR_EXPAND if csr_expand else 0) | (_capi.FLAG_KEEP_FACTOR if keep_factor else 0) | (_capi.FLAG_F32_ARITH if f32_arith else 0))
         h = ctypes.c_void_p()
         rc = self._L.sqph_create(ctypes.byref(h), self.device, self.n, self.m, self.batch, self._dt, flags)
         if rc != 0:

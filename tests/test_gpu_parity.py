@@ -11,11 +11,11 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
-def make_gpu(n, m, batch, dtype=np.float64, legacy_cold_start=False, force_generic=False, keep_factor=False, **kw):
+def make_gpu(n, m, batch, dtype=np.float64, legacy_cold_start=False, force_generic=False, keep_factor=False, f32_arith=False, **kw):
     from sqp_solver_amd import QPSolverBatch
 
     return QPSolverBatch(n, m, batch, dtype=dtype, device=0, legacy_cold_start=legacy_cold_start, force_generic=force_generic,
-                         keep_factor=keep_factor)
+                         keep_factor=keep_factor, f32_arith=f32_arith)
 
 
 def make_gpu_generic(n, m, batch, **kw):
@@ -278,6 +278,32 @@ def test_small_shapes_take_the_lane_and_four_per_wave_kernels():
         # tiny QPs can have every constraint inactive (y == 0 up to rounding): scale the dual error by max(1, |y|)
         assert cases.relerr(x, xo) < cases.TOL_F64
         assert (np.max(np.abs(y - yo), axis=1) <= cases.TOL_F64 * np.maximum(1.0, np.max(np.abs(yo), axis=1))).all()
+
+
+def test_true_fp32_variant():
+    """SQPH_FLAG_F32_ARITH on the shapes that have an fp32 kernel (one QP per lane): within TOL_F32 = 5e-3 of the
+    reference's QPSolver<float> (float oracle), no further from the fp64 solution than 4x the float oracle is (floor 2e-3);
+    status / iteration counts equal to the float oracle's; shapes without an fp32 kernel silently iterate in fp64."""
+    mk = lambda n, m, b, **kw: make_gpu(n, m, b, dtype=np.float32, f32_arith=True)  # noqa: E731
+    for (n, m) in ((2, 3), (4, 6), (3, 3)):
+        ex, ey, ez = cases.parity_fixed_iters(mk, n, m, 2048, iters=150, dtype=np.float32, dual_floor=True, f32_floor=2e-3)
+        assert ex < 2e-3 and ey < 2e-3, (ex, ey)
+    s = mk(2, 3, 4)
+    s.setup_solve(*cases.simple(4, dtype=np.float32))
+    assert s.kernel_name() == "lane_2x3_exact_f32", s.kernel_name()
+    from sqp_solver_amd.problems import random_qp_batch
+
+    P, q, A, l, u = random_qp_batch(4096, 4, 6, seed=7, dtype=np.float32)
+    s = mk(4, 6, 4096)
+    s.setup_solve(P, q, A, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings), dtype=np.float32)
+    assert ((info.status == io["status"]) & (info.iter == io["iter"])).mean() > 0.995  # fp32 stop tests sit on fp32-noisy residuals
+    assert np.percentile(np.max(np.abs(x - xo), axis=1) / np.maximum(np.max(np.abs(xo), axis=1), 1e-30), 99) < cases.TOL_F32
+    s = mk(20, 40, 8)  # no fp32 kernel for this shape: fp64 arithmetic behind the float interface, as without the flag
+    s.settings.max_iter, s.settings.check_termination = 50, 0
+    s.setup_solve(*random_qp_batch(8, 20, 40, seed=1, dtype=np.float32))
+    assert not s.kernel_name().endswith("_f32")
 
 
 def test_lane_kernel_paths():

@@ -219,3 +219,26 @@ def test_lane_parity_alpha_float_termination_and_state_paths():
     cases.fused_then_solve(make_lane, n=4, m=5, batch=3)
     for kind in ("all_eq", "half_eq", "illcond"):  # (the adaptive kinds are chaotic on QPs this small: see parity_termination)
         cases.stress_parity(make_lane, 4, 6, 8, kind, iters=120)
+
+
+def make_lane_f32(n, m, batch, dtype=np.float32, legacy_cold_start=False, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=np.float32, variant=simlib.LANE_F32, legacy_cold_start=legacy_cold_start)
+
+
+def test_lane_true_fp32_variant():
+    """SQPH_FLAG_F32_ARITH: iterates, factor and residuals in fp32.  Stated tolerance: within TOL_F32 = 5e-3 of the
+    reference's QPSolver<float> (the float oracle), and no further from the fp64 solution of the same float-valued problem than
+    4x the float oracle is (floor 2e-3); status and iteration counts equal to the float oracle's under default termination."""
+    for (n, m) in ((2, 3), (4, 6), (3, 3)):
+        ex, ey, ez = cases.parity_fixed_iters(make_lane_f32, n, m, 128, iters=150, dtype=np.float32, dual_floor=True, f32_floor=2e-3)
+        assert ex < 2e-3 and ey < 2e-3, (ex, ey)
+    from sqp_solver_amd.problems import random_qp_batch
+
+    P, q, A, l, u = random_qp_batch(128, 4, 6, seed=7, dtype=np.float32)
+    s = make_lane_f32(4, 6, 128)
+    s.setup_solve(P, q, A, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings), dtype=np.float32)
+    assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all()
+    assert cases.relerr(x, xo) < cases.TOL_F32
+    cases.ref_testSinglePrecisionFloat(make_lane_f32)
