@@ -164,6 +164,12 @@ int sqph_setup(sqph_solver *s, const sqph_qp_batch *qp);       /* QPSolver::setu
 int sqph_update_qp(sqph_solver *s, const sqph_qp_batch *qp);   /* QPSolver::update_qp             */
 int sqph_solve(sqph_solver *s, const sqph_qp_batch *qp);       /* QPSolver::solve                 */
 int sqph_setup_solve(sqph_solver *s, const sqph_qp_batch *qp); /* setup()+solve(), single launch  */
+/* setup()+solve() of QPs whose P and A are those of this handle's previous setup/update (only q, l, u differ): what the SQP
+ * driver's second-order correction asks for (src/sqp.cpp:244-276; "only l and u change", TODO at :273).  Semantics and results
+ * are exactly sqph_setup_solve's (iterates reset, constraints re-classified, rho back to settings.rho); the factorisation is
+ * skipped for every QP whose rho vector comes out equal to the one the resident factor was built with.  Needs the factor
+ * resident (SQPH_FLAG_KEEP_FACTOR, or a preceding sqph_setup/sqph_update_qp); otherwise identical to sqph_setup_solve. */
+int sqph_setup_solve_reuse(sqph_solver *s, const sqph_qp_batch *qp);
 
 /* CSR-A variants of the four calls above (legacy sparse QPSolver, unsupported/qp_solver.hpp:215-330). */
 int sqph_setup_csr(sqph_solver *s, const sqph_csr_batch *qp);

@@ -174,6 +174,9 @@ class BatchQPSolver {
     void update_qp(const Batch &b) { call(sqph_update_qp, b, "sqph_update_qp"); }
     void solve(const Batch &b) { call(sqph_solve, b, "sqph_solve"); }
     void setup_solve(const Batch &b) { call(sqph_setup_solve, b, "sqph_setup_solve"); }  // what SQP::run_solve_qp does (src/sqp.cpp:221-222)
+    // the same for QPs whose P and A are those of the previous setup (only q, l, u differ — the SQP second-order correction,
+    // src/sqp.cpp:244-276): the resident factor is reused where the rho vector did not move (create with SQPH_FLAG_KEEP_FACTOR)
+    void setup_solve_reuse(const Batch &b) { call(sqph_setup_solve_reuse, b, "sqph_setup_solve_reuse"); }
 
     // The same calls with the constraint matrices in CSR (legacy sparse class, unsupported/qp_solver.hpp:17-32; BASELINE
     // config 5).  Per-QP arrays: rowptr [m+1], colind/val [nnz_max]; packed_csr lays QPs back to back.

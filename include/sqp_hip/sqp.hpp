@@ -66,8 +66,10 @@ class BatchSQP {
     using Settings = sqp_settings_t<Scalar>;
     static constexpr Scalar DIV_BY_ZERO_REGUL = std::numeric_limits<Scalar>::epsilon();
 
+    // The QP backend keeps its factors resident (SQPH_FLAG_KEEP_FACTOR): the second-order correction re-solves with new bounds
+    // only and reuses them (the reference's TODO at src/sqp.cpp:273).
     BatchSQP(int num_var, int num_constr, int batch, int device = 0)
-        : n_(num_var), m_(num_constr), batch_(batch), qp_(num_var, num_constr, batch, device), inst_(batch) {
+        : n_(num_var), m_(num_constr), batch_(batch), qp_(num_var, num_constr, batch, device, SQPH_FLAG_KEEP_FACTOR), inst_(batch) {
         // QP settings of the reference's SQP constructor, src/sqp.cpp:15-23
         auto &s = qp_.settings();
         s.warm_start = true;
@@ -150,7 +152,7 @@ class BatchSQP {
                     }
                     pack(k, I);
                 }
-                run_qp(live);
+                run_qp(live, /*same_matrices=*/true);
             }
             // ---- step, line search, termination (src/sqp.cpp:76-96)
             std::vector<int> still;
@@ -219,9 +221,11 @@ class BatchSQP {
         std::copy(I.ql.begin(), I.ql.begin() + m, l_.begin() + k * m);
         std::copy(I.qu.begin(), I.qu.begin() + m, u_.begin() + k * m);
     }
-    void run_qp(const std::vector<int> &live) {
+    void run_qp(const std::vector<int> &live, bool same_matrices = false) {
         const auto t0 = std::chrono::steady_clock::now();
-        qp_.setup_solve(qp_.packed((int)live.size(), P_.data(), q_.data(), A_.data(), l_.data(), u_.data()));
+        const auto batch = qp_.packed((int)live.size(), P_.data(), q_.data(), A_.data(), l_.data(), u_.data());
+        if (same_matrices) qp_.setup_solve_reuse(batch);  // P, A of the call before (same live set, same order): factor reuse
+        else qp_.setup_solve(batch);
         (void)qp_.info(0);  // fetch the results (one packed D2H)
         qp_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         launches_++;

@@ -163,6 +163,7 @@ struct LaneKernel {
 #pragma unroll
             for (int j = 0; j < NMAX; j++) Pl[i][j] = i >= j ? P[i][j] : P[j][i];
 
+        bool rho_unchanged = (mode & MODE_SAME_MATRICES) != 0;  // the resident factor was built with exactly this rho vector
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
             rho_s = a_rho0;
 #pragma unroll
@@ -176,6 +177,7 @@ struct LaneKernel {
                     ct[i] = c;
                     rho[i] = rho_for_type<T>(c, rho_s, a_rho_min, a_eqf);
                     rinv[i] = T(1) / rho[i];
+                    if (rho_unchanged && !((double)rho[i] == srho[i])) rho_unchanged = false;
                     sct[i] = c;
                     srho[i] = (double)rho[i];
                 }
@@ -208,6 +210,10 @@ struct LaneKernel {
         }
 
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
+        if ((mode & (MODE_SETUP | MODE_UPDATE)) && !(mode & MODE_REFACTOR) && rho_unchanged) {
+            need_factor = false;  // sqph_setup_solve_reuse: same P, A, rho vector => the resident factor is the one setup() would build
+            info.status = SQPH_UNSOLVED;
+        }
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         const T alpha = (T)a.alpha, sigma = (T)a.sigma, oma = T(1) - (T)a.alpha;

@@ -668,6 +668,7 @@ struct WgKernel {
         T rho = T(1);
         if (t < L::MP) rinvv[t] = T(1);  // 1/rho lives in LDS (see O_RINV)
 
+        bool rho_differs = false;
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
             rho_s = a.rho0;
             if (mown) {
@@ -679,6 +680,7 @@ struct WgKernel {
                     ctype = SQPH_EQUALITY_CONSTRAINT;
                 rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
                 rinvv[t] = T(1) / rho;
+                rho_differs = !(rho == srho[t]);  // against the vector the resident factor was built with (MODE_SAME_MATRICES)
                 sct[t] = ctype;
                 srho[t] = rho;
             }
@@ -706,6 +708,20 @@ struct WgKernel {
         T vt[TW][TC];  // the tile of W' the iteration runs on (the W tile itself lives only inside the set-up block)
         T at[TR][TC];  // the A tile; turned into B = A W' in place once the factor is known
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
+        if ((mode & MODE_SAME_MATRICES) && (mode & (MODE_SETUP | MODE_UPDATE)) && !(mode & MODE_REFACTOR)) {
+            // sqph_setup_solve_reuse: same P and A as the resident factor; it is also the factor setup() would build if no lane's
+            // rho differs from the vector it was built with (workgroup-wide OR through one LDS word of the idle staging area)
+            T *flag = lds + L::O_STAGE;
+            if (t == 0) *flag = T(0);
+            __syncthreads();
+            if (rho_differs) *flag = T(1);
+            __syncthreads();
+            if (*flag == T(0)) {
+                need_factor = false;
+                info.status = SQPH_UNSOLVED;  // qp.cpp:39-43
+            }
+            __syncthreads();
+        }
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         bool have_A = false;  // `at` currently holds A (as opposed to B)

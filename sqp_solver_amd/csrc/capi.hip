@@ -530,6 +530,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     const bool fused = (mode & (MODE_SETUP | MODE_UPDATE)) && (mode & MODE_SOLVE);
     if (fused && !(s->flags & SQPH_FLAG_KEEP_FACTOR)) a.mode |= MODE_NO_FACTOR_STORE;
     if (!(mode & (MODE_SETUP | MODE_UPDATE)) && !s->factor_resident) a.mode |= MODE_REFACTOR;
+    if ((mode & MODE_SAME_MATRICES) && !s->factor_resident) a.mode &= ~MODE_SAME_MATRICES;  // nothing to reuse: plain setup
     a.P = (const TIN *)P; a.q = (const TIN *)q; a.A = (const TIN *)A; a.l = (const TIN *)l; a.u = (const TIN *)u;
     a.sP = sP; a.sq = sq; a.sA = sA; a.sl = sl; a.su = su;
     a.x = (T *)s->x; a.z = (T *)s->z; a.y = (T *)s->y; a.rho_vec = (T *)s->rho_vec; a.ctype = s->ctype;
@@ -980,5 +981,8 @@ int sqph_update_qp(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, 
 int sqph_solve(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_SOLVE, "sqph_solve"); }
 int sqph_setup_solve(sqph_solver *s, const sqph_qp_batch *qp) {
     return run(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE, "sqph_setup_solve");
+}
+int sqph_setup_solve_reuse(sqph_solver *s, const sqph_qp_batch *qp) {
+    return run(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE | sqph::MODE_SAME_MATRICES, "sqph_setup_solve_reuse");
 }
 }

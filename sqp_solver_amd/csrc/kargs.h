@@ -14,6 +14,11 @@ enum : int {
     // same results — the factor depends on P, A, sigma and the current rho vector only)
     MODE_NO_FACTOR_STORE = 16,
     MODE_REFACTOR = 32,
+    // with MODE_SETUP / MODE_UPDATE: P and A are those of the resident factor (sqph_setup_solve_reuse: the SQP second-order
+    // correction re-solves with new bounds only, src/sqp.cpp:244-276 and the TODO at :273) — a QP whose freshly classified rho
+    // vector equals the one the resident factor was built with skips the factorisation.  A hint: kernels without support for
+    // it factor as usual (same results either way).
+    MODE_SAME_MATRICES = 64,
 };
 
 // T   = arithmetic / state type (always double in the shipped library)

@@ -212,6 +212,11 @@ class QPSolverBatch:
         """setup(); solve() in one kernel launch (what SQP::run_solve_qp does, src/sqp.cpp:221-222)."""
         self._call(self._L.sqph_setup_solve, "sqph_setup_solve", P, q, A, l, u, colmajor)
 
+    def setup_solve_reuse(self, P, q, A, l, u, colmajor=False):
+        """setup(); solve() for QPs whose P and A are those of the previous setup (only q, l, u differ): the factor is rebuilt
+        only where the rho vector changed (the SQP driver's second-order correction, src/sqp.cpp:244-276)."""
+        self._call(self._L.sqph_setup_solve_reuse, "sqph_setup_solve_reuse", P, q, A, l, u, colmajor)
+
     # ------------------------------------------------------------------ CSR-A variants (BASELINE config 5)
     def _csr_desc(self, P, q, rowptr, colind, val, l, u):
         """P [B,n,n] or [n,n] (row- or column-major is irrelevant only for symmetric P: pass logical P), q [B,n],

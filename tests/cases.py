@@ -366,6 +366,31 @@ def fused_then_solve(make, n=8, m=12, batch=4, adaptive=True, **kw):
             assert relerr(x[b][None], o.primal_solution()[None]) < TOL_F64 and relerr(y[b][None], o.dual_solution()[None]) < TOL_F64, (keep, b)
 
 
+def soc_factor_reuse(make, n=8, m=12, batch=6, **kw):
+    """setup_solve(); then setup_solve_reuse() with new q, l, u (the SQP second-order correction, src/sqp.cpp:244-276): results
+    are those of a plain second setup()+solve() — with the factor kept resident (it is reused where rho did not move) and without."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=17)
+    q2, l2, u2 = q + 0.3, l - 0.2, u + 0.05
+    for keep in (True, False):
+        for adaptive in (0, 1):  # adaptive: the first solve may leave a different rho vector behind => those QPs refactor
+            s = make(n, m, batch, keep_factor=keep, **kw)
+            s.settings.max_iter, s.settings.check_termination = 60, 0
+            s.settings.adaptive_rho, s.settings.adaptive_rho_interval = adaptive, 20
+            s.setup_solve(P, q, A, l, u)
+            s.setup_solve_reuse(P, q2, A, l2, u2)
+            x, y, z, info = s.solution()
+            s2 = make(n, m, batch, **kw)
+            s2.settings.max_iter, s2.settings.check_termination = 60, 0
+            s2.settings.adaptive_rho, s2.settings.adaptive_rho_interval = adaptive, 20
+            s2.setup_solve(P, q2, A, l2, u2)
+            x2, y2, z2, info2 = s2.solution()
+            assert np.array_equal(x, x2) and np.array_equal(y, y2) and np.array_equal(z, z2), (keep, adaptive)
+            assert (info.iter == info2.iter).all() and (info.status == info2.status).all()
+            assert (info.rho_updates >= info2.rho_updates + 1).all()  # the counter accumulates over setups (qp.cpp:309)
+            xo, yo, zo, io = oracle.solve_batch(P, q2, A, l2, u2, oracle_settings(s.settings))
+            assert relerr(x, xo) < TOL_F64 and relerr1(y, yo) < TOL_F64
+
+
 def set_state_warm_start(make, n=6, m=9, batch=3, **kw):
     P, q, A, l, u = random_qp_batch(batch, n, m, seed=9)
     rng = np.random.default_rng(0)

@@ -227,7 +227,7 @@ class OracleBatchQP {
     using Settings = qp_solver::QPSolverSettings<double>;
     using Info = qp_solver::QPSolverInfo<double>;
     struct Batch { int batch; const double *P, *q, *A, *l, *u; };
-    OracleBatchQP(int n, int m, int batch, int /*device*/ = 0) : n_(n), m_(m), x_((size_t)batch * n), y_((size_t)batch * (m > 0 ? m : 1)), info_(batch) {
+    OracleBatchQP(int n, int m, int batch, int /*device*/ = 0, int /*flags*/ = 0) : n_(n), m_(m), x_((size_t)batch * n), y_((size_t)batch * (m > 0 ? m : 1)), info_(batch) {
         qp_ = qpo_create_f64();
     }
     ~OracleBatchQP() { qpo_destroy_f64(qp_); }
@@ -252,6 +252,7 @@ class OracleBatchQP {
             if (m) std::memcpy(&y_[k * m], qpo_dual_f64(qp_), sizeof(double) * m);
         }
     }
+    void setup_solve_reuse(const Batch &b) { setup_solve(b); }  // the reference re-runs setup() for the SOC pass (sqp.cpp:274)
     const Info &info(int k) const { return info_[k]; }
     const double *primal_solution(int k) const { return &x_[(size_t)k * n_]; }
     const double *dual_solution(int k) const { return &y_[(size_t)k * m_]; }

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SIMDIR = os.path.join(HERE, "sim")
 LIB = os.path.join(SIMDIR, "libsqph_sim.so")
 
-MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET, MODE_NO_FACTOR_STORE, MODE_REFACTOR = 1, 2, 4, 8, 16, 32
+MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET, MODE_NO_FACTOR_STORE, MODE_REFACTOR, MODE_SAME_MATRICES = 1, 2, 4, 8, 16, 32, 64
 GENERIC, WG, CSR, G16, G32, LANE, LANE_F32 = 0, 2, 3, 4, 5, 6, 7
 
 
@@ -97,6 +97,8 @@ class SimSolverBatch:
             a.mode |= MODE_NO_FACTOR_STORE
         if not (mode & (MODE_SETUP | MODE_UPDATE)) and not self.factor_resident:
             a.mode |= MODE_REFACTOR
+        if (mode & MODE_SAME_MATRICES) and not self.factor_resident:
+            a.mode &= ~MODE_SAME_MATRICES
         if (mode & (MODE_SETUP | MODE_UPDATE)) or (a.mode & MODE_REFACTOR):
             self.factor_resident = self.variant == GENERIC or not (a.mode & MODE_NO_FACTOR_STORE)
         for name, arr, per in (("P", P, n * n), ("q", q, n), ("A", A, m * n), ("l", l, m), ("u", u, m)):
@@ -140,6 +142,9 @@ class SimSolverBatch:
 
     def setup_solve(self, P, q, A, l, u):
         self._run(MODE_SETUP | MODE_SOLVE, P, q, A, l, u)
+
+    def setup_solve_reuse(self, P, q, A, l, u):
+        self._run(MODE_SETUP | MODE_SOLVE | MODE_SAME_MATRICES, P, q, A, l, u)
 
     def setup_csr(self, P, q, rp, ci, v, l, u):
         self._run(MODE_SETUP, P, q, None, l, u, csr=(rp, ci, v))

@@ -80,6 +80,12 @@ def test_fused_call_then_solve(n, m, make):
     cases.fused_then_solve(make, n=n, m=m, batch=5)
 
 
+@pytest.mark.parametrize("n,m", [(2, 3), (4, 6), (8, 12), (20, 40), (50, 100), (100, 200)])
+def test_setup_solve_reuse(n, m):
+    """sqph_setup_solve_reuse (the SQP second-order correction): bit-identical to a plain setup+solve, every kernel family"""
+    cases.soc_factor_reuse(make_gpu, n=n, m=m, batch=5)
+
+
 def test_four_wave_shapes():
     """m <= 208, n <= 112: four wavefronts per QP (13 x 7 + 7 x 7 doubles of tiles per lane, one wave per SIMD)"""
     s = make_gpu(100, 200, 2)

@@ -242,3 +242,11 @@ def test_lane_true_fp32_variant():
     assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all()
     assert cases.relerr(x, xo) < cases.TOL_F32
     cases.ref_testSinglePrecisionFloat(make_lane_f32)
+
+
+@pytest.mark.parametrize("make,n,m", [(make_lane, 2, 3), (make_lane, 4, 6), (make_wg, 8, 12), (make_wg, 50, 100), (make_g16, 8, 12), (make_generic, 6, 9)],
+                         ids=["lane2x3", "lane4x6", "wg1", "wg2", "g16", "generic"])
+def test_setup_solve_reuse(make, n, m):
+    """sqph_setup_solve_reuse (SOC): bit-identical to a plain setup+solve whether the factor is reused (lane, wg), rebuilt because
+    rho moved, or the kernel ignores the hint (g16, generic)"""
+    cases.soc_factor_reuse(make, n=n, m=m, batch=3)
