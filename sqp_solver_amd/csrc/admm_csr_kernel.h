@@ -876,7 +876,9 @@ __global__ __launch_bounds__(1024) void admm_csr_kernel(CsrLaunch<TIN> p) {
 }
 
 // tile edges compiled into the library (n <= 32*TT): first fit wins
-#ifdef SQPH_SLIM
+#if defined(SQPH_SLIM) && defined(SQPH_SLIM_CSR)
+#define SQPH_CSR_SHAPES(X) X(7)
+#elif defined(SQPH_SLIM)
 #define SQPH_CSR_SHAPES(X)
 #else
 #define SQPH_CSR_SHAPES(X) X(4) X(7)

@@ -116,16 +116,15 @@ struct WgLayout {
     static constexpr int STAGE_X = NP * Rp;
     static constexpr int O_STAGE_Y = O_STAGE + STAGE_X;    // staging Y: partials reduced over c  [max(NR,MP)][Cp]
     static constexpr int STAGE_Y = mx(NR, MP) * Cp;
-    // set-up scratch, aliasing the staging areas:  rho[MP] | rowbuf[2][RBS] | sj[NP] | As[R][SSTR] | Wl[NP][SSTR]
+    // set-up scratch, aliasing the staging areas:  rho[MP] | rowbuf[NP+2] | sj[NP] | As[R][SSTR] | Wl[NP][SSTR]
     // As = one block of R rows of A, Wl = W transposed (Wl[j][slot(i')] = W[i'][j]); column groups are
     // padded to 8 (slot(j) = 8*(j/TC) + j%TC) so a lane's TC consecutive columns are one aligned 64-B read.
     // (the set-up scratch starts at offset 0: no vector is live in LDS while a factor is being built)
     static constexpr int SSTR = 8 * C + 2;  // As row stride (padded: the R rows are written by different lanes)
     static constexpr int WSTR = 8 * C;      // Wl row stride
     static constexpr int O_RHO = 0;
-    static constexpr int O_ROWBUF = ev(O_RHO + MP);  // two pivot-row buffers (ping-pong), slot layout: [2][RBS]
-    static constexpr int RBS = 8 * C + 2;
-    static constexpr int O_SJ = O_ROWBUF + 2 * RBS;
+    static constexpr int O_ROWBUF = O_RHO + MP;
+    static constexpr int O_SJ = O_ROWBUF + NP + 2;
     static constexpr int O_AS = ev(O_SJ + NP);
     static constexpr int O_WL = O_AS + R * SSTR;
     static constexpr int CH = (C + 1) / 2;  // W is staged half of its columns (CH column groups) at a time
@@ -485,20 +484,10 @@ struct WgKernel {
             const int j = TC * c + k;
             jc[k] = j < n ? j : 0;
         }
-        // S starts as P_sym + sigma I: these global loads are issued first, their latency hides behind the accumulation below
-        // (only the lower triangle of P reaches the reference's factor, Eigen::LDLT<.,Lower>)
 #pragma unroll
-        for (int u = 0; u < TW; u++) {
-            const int i = R * u + r;
+        for (int u = 0; u < TW; u++)
 #pragma unroll
-            for (int k = 0; k < TC; k++) {
-                const int j = TC * c + k;
-                const bool ok = i < n && j < n;
-                const int lo = i > j ? i : j, hi = i > j ? j : i;
-                const T p = ok ? (T)gP[(long)hi * n + lo] : T(0);
-                wt[u][k] = ok ? p + (i == j ? sigma : T(0)) : T(0);
-            }
-        }
+            for (int k = 0; k < TC; k++) wt[u][k] = 0;
         // S = A' diag(rho) A : the A tile goes through LDS one block of R rows at a time (row R s + il of A is
         // As[il][.]); every lane then reads the TW + TC entries of each row it needs. No global re-reads.
         int sl[TW];
@@ -526,10 +515,11 @@ struct WgKernel {
                     for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
             }
         }
-        SQPH_STICK(1)
         wsync();
-        for (int e = t; e < 2 * L::RBS; e += NT) rowbuf[e] = 0;
-        for (int e = t; e < L::NP; e += NT) sjv[e] = T(1);
+        for (int e = t; e < L::NP + 2; e += NT) {
+            rowbuf[e] = 0;
+            if (e < L::NP) sjv[e] = T(1);
+        }
         wsync();
 #pragma unroll
         for (int u = 0; u < TW; u++) {
@@ -538,7 +528,10 @@ struct WgKernel {
             for (int k = 0; k < TC; k++) {
                 const int j = TC * c + k;
                 const bool ok = i < n && j < n;
-                wt[u][k] = ok ? wt[u][k] : T(0);  // rows beyond n gathered column 0 of A above
+                const int lo = i > j ? i : j, hi = i > j ? j : i;
+                // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>)
+                const T p = ok ? (T)gP[(long)hi * n + lo] : T(0);
+                wt[u][k] = ok ? (wt[u][k] + p + (i == j ? sigma : T(0))) : T(0);
                 if (ok && i == j) sjv[j] = wt[u][k];  // the diagonal, for the Jacobi scaling
             }
         }
@@ -566,7 +559,6 @@ struct WgKernel {
         for (int u = 0; u < TW; u++)
 #pragma unroll
             for (int k = 0; k < TC; k++) wt[u][k] = wt[u][k] * srow[u] * scol[k];
-        SQPH_STICK(2)
         // forward elimination of [S~ | I] in place; row k = R*u + rr is broadcast through LDS
         bool ok_all = true;
         T dsave[TW];
@@ -578,30 +570,30 @@ struct WgKernel {
             for (int rr = 0; rr < R; rr++) {
                 const int k = R * u + rr;
                 if (k >= n || !ok_all) break;
-                // ping-pong pivot-row buffers: the row of pivot k + 1 goes to the other buffer, so ONE workgroup barrier per
-                // pivot suffices (a lane still reading pivot k's row is at most one barrier behind the writer of pivot k + 2's)
-                T *rb = rowbuf + (k & 1) * L::RBS;
                 if (r == rr) {
 #pragma unroll
-                    for (int q = 0; q < TC; q++) rb[8 * c + q] = wt[u][q];
+                    for (int q = 0; q < TC; q++) rowbuf[TC * c + q] = wt[u][q];
                 }
                 wsync();
-                const T d = rb[L::slot(k)];
+                const T d = rowbuf[k];
                 if (!(d > T(0)) || !(d * T(0) == T(0))) {
                     ok_all = false;
                     break;
                 }
                 const T dinv = T(1) / d;
-                T g[TC], f[TW], g8[8];
-                wg_read<8>(rb + 8 * c, g8);
+                T g[TC], f[TW];
 #pragma unroll
-                for (int q = 0; q < TC; q++) g[q] = (TC * c + q == k) ? d + T(1) : g8[q];
+                for (int q = 0; q < TC; q++) {
+                    const T gq = rowbuf[TC * c + q];
+                    g[q] = (TC * c + q == k) ? d + T(1) : gq;
+                }
 #pragma unroll
                 for (int v = 0; v < TW; v++) {
                     const int i = R * v + r;
-                    const T gi = rb[sl[v]];
+                    const T gi = rowbuf[i < L::NP ? i : 0];
                     f[v] = (i > k && i < n) ? gi * dinv : T(0);
                 }
+                wsync();
 #pragma unroll
                 for (int v = 0; v < TW; v++)
 #pragma unroll
@@ -609,7 +601,6 @@ struct WgKernel {
                 dsave[u] = (r == rr) ? d : dsave[u];
             }
         }
-        SQPH_STICK(3)
         // W = D^-1/2 L^-1 D_J^-1/2
 #pragma unroll
         for (int u = 0; u < TW; u++) {

@@ -3,11 +3,12 @@ import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sqp_solver_amd import build as b
-b.FLAGS.append("-DSQPH_PHASE_TIMING")
-for f in os.environ.get("SQPH_EXTRA_FLAGS", "").split():
-    b.FLAGS.append(f)
-b.LIB = b.LIB.replace("libsqp_hip.so", "libsqp_hip_timing.so")
-subprocess.check_call([b.HIPCC] + b.FLAGS + ["-o", b.LIB, os.path.join(b.CSRC, "capi.hip")])
+if not os.environ.get("SQPH_LIB"):  # SQPH_LIB = a prebuilt -DSQPH_PHASE_TIMING library (tools/slim_build.sh ... -DSQPH_SLIM_CSR -DSQPH_PHASE_TIMING)
+    b.FLAGS.append("-DSQPH_PHASE_TIMING")
+    for f in os.environ.get("SQPH_EXTRA_FLAGS", "").split():
+        b.FLAGS.append(f)
+    b.LIB = b.LIB.replace("libsqp_hip.so", "libsqp_hip_timing.so")
+    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-o", b.LIB, os.path.join(b.CSRC, "capi.hip")])
 from sqp_solver_amd import QPSolverBatch
 from sqp_solver_amd.problems import random_csr_qp_batch
 n, m, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
