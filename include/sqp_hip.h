@@ -77,7 +77,7 @@ typedef struct sqph_settings {
     int adaptive_rho;              /* 0 */
     double adaptive_rho_tolerance; /* 5 */
     int adaptive_rho_interval;     /* 25 */
-    int verbose;                   /* 0 (ignored on device) */
+    int verbose;                   /* 0; non-zero: record the per-check status line of one QP (sqph_get_trace) */
 } sqph_settings;
 
 /* QPSolverInfo<Scalar>, qp.hpp:72-80 (40 bytes; Scalar fields widened to double) */
@@ -190,6 +190,14 @@ int sqph_set_state(sqph_solver *s, int batch, int memspace, const void *x, const
 int sqph_device_state(sqph_solver *s, void **x, void **y, void **z, sqph_info **info);
 
 int sqph_synchronize(sqph_solver *s);
+
+/* settings.verbose (reference QP_SOLVER_PRINTING, src/qp.cpp:72-76, 113-117, 152-156, 373-383): when non-zero, solve calls
+ * record for ONE QP of the batch (sqph_set_trace_qp, default 0) the line print_status prints at every termination check —
+ * iteration, objective 0.5 x'Px + q'x, primal and dual residual.  The library prints nothing itself; sqph_get_trace returns the
+ * records of the last call (4 doubles each: iter, obj, res_prim, res_dual) and the C++ facade prints them in the reference's
+ * format.  Verbose calls run on the generic or the one-QP-per-lane kernel (the ones that record) — a debugging mode. */
+int sqph_set_trace_qp(sqph_solver *s, int index);
+int sqph_get_trace(sqph_solver *s, double *records, int cap_records, int *count);
 
 /* ---- multi-GPU (single process, one handle per device): SURVEY.md §8(e).  The batch shards contiguously over the devices
  * (sqph_shard_bounds), every device solves its shard on its own stream with no data-path exchange, and the only

@@ -207,6 +207,25 @@ class BatchQPSolver {
         detail::check(sqph_set_state(h_, batch, SQPH_HOST, x, z, y), h_, "sqph_set_state");
         fetched_ = false;
     }
+    // settings().verbose: which QP of the batch is traced (default 0), and the records of the last solve call — one per
+    // termination check: {iter, objective, res_prim, res_dual} (reference print_status, src/qp.cpp:373-383)
+    void set_trace_qp(int b) { detail::check(sqph_set_trace_qp(h_, b), h_, "sqph_set_trace_qp"); }
+    std::vector<double> trace() {
+        int count = 0;
+        detail::check(sqph_get_trace(h_, nullptr, 0, &count), h_, "sqph_get_trace");
+        std::vector<double> rec((size_t)4 * count);
+        if (count) detail::check(sqph_get_trace(h_, rec.data(), count, &count), h_, "sqph_get_trace");
+        return rec;
+    }
+    // prints what the reference prints for a verbose solve: the per-check table, then the info record
+    void print_trace(int b = 0) {
+        const std::vector<double> rec = trace();
+        for (size_t k = 0; k < rec.size() / 4; k++) {
+            if (k == 0) printf("iter   obj       rp        rd\n");
+            printf("%4d  %.2e  %.2e  %.2e\n", (int)rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+        }
+        info(b).print();
+    }
     sqph_solver *handle() { return h_; }
     int n() const { return n_; }
     int m() const { return m_; }
@@ -315,9 +334,12 @@ class QPSolver {
     }
     void solve(const RawQP &qp) {
         if (!impl_) return;  // UNINITIALIZED: solve() returns silently, src/qp.cpp:68-71
+        if (info_.status == UNINITIALIZED || info_.status == NUMERICAL_ISSUES) return;
+        if (settings_.verbose) settings_.print();  // QP_SOLVER_PRINTING, src/qp.cpp:72-76
         push(true);
         impl_->solve(impl_->packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
         pull();
+        if (settings_.verbose) impl_->print_trace(0);  // print_status lines + info_.print(), src/qp.cpp:113-117, 152-156
     }
 #ifdef SQP_HIP_HAVE_EIGEN
     void setup(const QP &qp) { setup(raw(qp)); }

@@ -250,6 +250,18 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
             rho[i] = r;
             rinv[i] = T(1) / r;
         }
+        if (mode & MODE_REFACTOR) {
+            // solve() on an instance whose factor this kernel cannot use (not kept, or built by another kernel family):
+            // rebuild the row-major copy of A and the factor from the current rho vector
+            for (int e = tid; e < m * n; e += nt) {
+                const int i = e / n, j = e - i * n;
+                At[e] = (T)gA[(long)j * m + i];
+            }
+            __syncthreads();
+            const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, a.sigma, Wm, Wt, gjrow, gjcol, Px);
+            __syncthreads();
+            if (!ok) info.status = SQPH_NUMERICAL_ISSUES;
+        }
     }
     __syncthreads();
 
@@ -311,6 +323,20 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
                 nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
                 info.res_prim = (double)v[2];
                 info.res_dual = (double)v[6];
+                if (check && a.trace && qp == a.trace_qp) {  // print_status, qp.cpp:373-383 (recorded; the host prints)
+                    if (tid == 0) {
+                        T obj = 0;
+                        for (int j = 0; j < n; j++) obj += x[j] * (T(0.5) * Px[j] + q[j]);
+                        const int k = (int)a.trace[0];
+                        if (k < a.trace_cap) {
+                            a.trace[1 + 4 * k] = (double)iter;
+                            a.trace[2 + 4 * k] = (double)obj;
+                            a.trace[3 + 4 * k] = (double)v[2];
+                            a.trace[4 + 4 * k] = (double)v[6];
+                            a.trace[0] = (double)(k + 1);
+                        }
+                    }
+                }
                 if (check) {
                     // termination_criteria, qp.cpp:343-351, 363-371
                     if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {

@@ -339,6 +339,24 @@ struct LaneKernel {
                     const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
                     info.res_prim = (double)v[2];
                     info.res_dual = (double)v[6];
+                    if (check && a.trace && qp == a.trace_qp) {  // print_status, qp.cpp:373-383 (recorded; the host prints)
+                        T obj = 0;
+#pragma unroll
+                        for (int j = 0; j < NMAX; j++) {
+                            T Px = 0;
+#pragma unroll
+                            for (int k = 0; k < NMAX; k++) Px += P[j][k] * x[k];
+                            obj += x[j] * (T(0.5) * Px + q[j]);
+                        }
+                        const int k = (int)a.trace[0];
+                        if (k < a.trace_cap) {
+                            a.trace[1 + 4 * k] = (double)iter;
+                            a.trace[2 + 4 * k] = (double)obj;
+                            a.trace[3 + 4 * k] = (double)v[2];
+                            a.trace[4 + 4 * k] = (double)v[6];
+                            a.trace[0] = (double)(k + 1);
+                        }
+                    }
                     if (check) {
                         if (v[2] <= a_eps_abs + a_eps_rel * nrm_prim && v[6] <= a_eps_abs + a_eps_rel * nrm_dual) {
                             info.status = SQPH_SOLVED;

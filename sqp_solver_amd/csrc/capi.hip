@@ -151,6 +151,9 @@ struct sqph_solver {
     std::string err;
     const char *kernel_name = "none";
     bool factor_resident = false;  // the workspace holds the factor of the last setup/update (see SQPH_FLAG_KEEP_FACTOR)
+    char factor_family = 0;        // kernel family that built it: 't' register-tiled / lane (canonical W), 'c' sparse, 'g' generic
+    double *trace = nullptr;       // verbose trace of one QP: [0] = count, then 4 doubles per termination check
+    int trace_qp = 0, trace_cap = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;  // one pair per launch while timing is on
     size_t ev_used = 0;
@@ -287,7 +290,7 @@ void sqph_destroy(sqph_solver *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     else (void)hipDeviceSynchronize();
     if (s->stream_owned) (void)hipStreamDestroy(s->stream);
-    void *ptrs[] = {s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su, s->cRow, s->cCol, s->cVal, s->cA, s->cBad};
+    void *ptrs[] = {s->trace, s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su, s->cRow, s->cCol, s->cVal, s->cA, s->cBad};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->hpin) (void)hipHostFree(s->hpin);
@@ -311,6 +314,29 @@ int sqph_set_stream(sqph_solver *s, void *hip_stream) {
         s->stream_owned = false;
     }
     s->stream = (hipStream_t)hip_stream;
+    return SQPH_OK;
+}
+
+int sqph_set_trace_qp(sqph_solver *s, int index) {
+    if (!s) return SQPH_ERR_INVALID;
+    if (index < 0 || index >= s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "sqph_set_trace_qp: index %d outside [0, %d)", index, s->cap);
+    s->trace_qp = index;
+    return SQPH_OK;
+}
+
+int sqph_get_trace(sqph_solver *s, double *records, int cap_records, int *count) {
+    if (!s || !count) return SQPH_ERR_INVALID;
+    *count = 0;
+    if (!s->trace) return SQPH_OK;
+    DeviceGuard g(s->device);
+    std::vector<double> h(1 + 4 * (size_t)s->trace_cap);
+    SQPH_HIP(s, hipMemcpyAsync(h.data(), s->trace, h.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    SQPH_HIP(s, hipStreamSynchronize(s->stream));
+    int k = (int)h[0];
+    if (k > s->trace_cap) k = s->trace_cap;
+    *count = k;
+    for (int i = 0; i < k && i < cap_records && records; i++)
+        for (int e = 0; e < 4; e++) records[4 * i + e] = h[1 + 4 * i + e];
     return SQPH_OK;
 }
 
@@ -526,11 +552,24 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     a.m = s->m;
     a.batch = qp->batch;
     a.mode = mode | ((s->flags & SQPH_FLAG_LEGACY_COLD_START) ? MODE_COLD_RESET : 0);
-    // factor residency: a fused setup+solve writes no factor unless asked to; solve() on such a handle rebuilds it first
+    // factor residency: a fused setup+solve writes no factor unless asked to; solve() on such a handle — or on one whose factor
+    // was built by another kernel family (the layouts differ) — rebuilds it first (MODE_REFACTOR, set per family below)
     const bool fused = (mode & (MODE_SETUP | MODE_UPDATE)) && (mode & MODE_SOLVE);
     if (fused && !(s->flags & SQPH_FLAG_KEEP_FACTOR)) a.mode |= MODE_NO_FACTOR_STORE;
-    if (!(mode & (MODE_SETUP | MODE_UPDATE)) && !s->factor_resident) a.mode |= MODE_REFACTOR;
-    if ((mode & MODE_SAME_MATRICES) && !s->factor_resident) a.mode &= ~MODE_SAME_MATRICES;  // nothing to reuse: plain setup
+    const bool solve_only = !(mode & (MODE_SETUP | MODE_UPDATE));
+    auto for_family = [&](char fam) {  // mode bits for a launch by kernel family `fam`
+        int mbits = a.mode & ~(MODE_REFACTOR | (fam == 'g' ? MODE_NO_FACTOR_STORE : 0));
+        if (solve_only && (!s->factor_resident || s->factor_family != fam)) mbits |= MODE_REFACTOR;
+        if ((mbits & MODE_SAME_MATRICES) && (!s->factor_resident || s->factor_family != fam)) mbits &= ~MODE_SAME_MATRICES;
+        return mbits;
+    };
+    auto launched_by = [&](char fam, int mbits) {
+        if ((mbits & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR))) {
+            s->factor_resident = fam == 'g' || !(mbits & MODE_NO_FACTOR_STORE);  // the generic kernel iterates out of the workspace
+            s->factor_family = fam;
+        }
+    };
+    const int mode_in = a.mode;
     a.P = (const TIN *)P; a.q = (const TIN *)q; a.A = (const TIN *)A; a.l = (const TIN *)l; a.u = (const TIN *)u;
     a.sP = sP; a.sq = sq; a.sA = sA; a.sl = sl; a.su = su;
     a.x = (T *)s->x; a.z = (T *)s->z; a.y = (T *)s->y; a.rho_vec = (T *)s->rho_vec; a.ctype = s->ctype;
@@ -542,6 +581,24 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     a.loose_thresh = (T)(TIN)1e+16; a.regul = (T)std::numeric_limits<TIN>::epsilon();
     a.max_iter = st.max_iter; a.check_termination = st.check_termination; a.warm_start = st.warm_start;
     a.adaptive_rho = st.adaptive_rho; a.adaptive_rho_interval = st.adaptive_rho_interval;
+
+    const bool verbose = st.verbose != 0 && (mode & MODE_SOLVE);
+    if (verbose) {
+        const int cap = (st.check_termination > 0 ? st.max_iter / st.check_termination : 0) + 2;
+        if (cap > s->trace_cap) {
+            if (s->trace) (void)hipFree(s->trace);
+            s->trace = nullptr;
+            s->trace_cap = 0;
+            SQPH_HIP(s, hipMalloc((void **)&s->trace, (1 + 4 * (size_t)cap) * sizeof(double)));
+            s->trace_cap = cap;
+        }
+        SQPH_HIP(s, hipMemsetAsync(s->trace, 0, sizeof(double), s->stream));
+        a.trace = s->trace;
+        a.trace_qp = s->trace_qp;
+        a.trace_cap = s->trace_cap;
+    } else if (s->trace) {
+        SQPH_HIP(s, hipMemsetAsync(s->trace, 0, sizeof(double), s->stream));  // the last call recorded nothing
+    }
 
     if (s->timing) {
         if (s->ev_used == s->evs.size()) {
@@ -556,6 +613,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     bool launched = false;
     if (csr) {
         CsrLaunch<TIN> p;
+        a.mode = for_family('c');
         p.a = a;
         p.ca = CsrArgs<TIN>{csr->rowptr, csr->colind, (const TIN *)csr->val, csr->s_rowptr, csr->s_colind, csr->s_val, csr->nnz_cap};
 #define SQPH_CSR_CASE(TT_)                                                                                                          \
@@ -570,9 +628,19 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         SQPH_CSR_SHAPES(SQPH_CSR_CASE)
 #undef SQPH_CSR_CASE
         if (!launched) SQPH_FAIL(s, SQPH_ERR_UNSUPPORTED, "no sparse kernel for tile edge %d", csr->TT);
+        launched_by('c', a.mode);
     }
-    if (!launched && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
+    if (!launched && verbose && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
+        // only the one-QP-per-lane and the generic kernel record the trace
+        a.mode = for_family('t');
+        int rc = lane_try_launch<TIN>(a, s->stream, &s->kernel_name);
+        if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        launched = rc > 0;
+        if (launched) launched_by('t', a.mode);
+    }
+    if (!launched && !verbose && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
         int rc = 0;
+        a.mode = for_family('t');
         if (sizeof(TIN) == 4 && (s->flags & SQPH_FLAG_F32_ARITH)) rc = lane_try_launch<TIN, float>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = lane_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
@@ -580,6 +648,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         if (rc == 0) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "tiled kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         launched = rc > 0;
+        if (launched) launched_by('t', a.mode);
     }
     if (!launched) {
         if (!s->At) {
@@ -587,6 +656,8 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
             SQPH_HIP(s, hipMalloc(&s->At, bytes));
         }
         a.At = (T *)s->At;
+        a.mode = mode_in;
+        a.mode = for_family('g');
         const int big = s->n > s->m ? s->n : s->m;
         const int nt = big <= 128 ? 64 : 256;
         const size_t lds = generic_lds_elems<T>(s->n, s->m, nt) * sizeof(T);
@@ -596,11 +667,8 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         hipLaunchKernelGGL((admm_generic_kernel<T, TIN>), dim3(qp->batch), dim3(nt), lds, s->stream, a);
         SQPH_HIP(s, hipGetLastError());
         s->kernel_name = nt == 64 ? "generic_w1" : "generic_w4";
+        launched_by('g', a.mode);
     }
-    // the generic kernel iterates out of the workspace: its factor is always resident
-    const bool generic = s->kernel_name[0] == 'g' && s->kernel_name[1] == 'e';
-    if (mode & (MODE_SETUP | MODE_UPDATE)) s->factor_resident = generic || !(a.mode & MODE_NO_FACTOR_STORE);
-    else if (a.mode & MODE_REFACTOR) s->factor_resident = generic || !(a.mode & MODE_NO_FACTOR_STORE);
     if (s->timing) {
         SQPH_HIP(s, hipEventRecord(s->evs[s->ev_used].second, s->stream));
         s->ev_used++;
@@ -763,7 +831,7 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
     }
     // native sparse kernel (admm_csr_kernel.h) where it applies: shapes beyond the dense register-tiled kernels, rows
     // sorted and duplicate-free, CSR + CSC index + vectors within one CU's LDS
-    if (!(s->flags & (SQPH_FLAG_CSR_EXPAND | SQPH_FLAG_FORCE_GENERIC)) && !(m <= 128 && n <= 64) && m <= 512 && n <= 224 &&
+    if (!(s->flags & (SQPH_FLAG_CSR_EXPAND | SQPH_FLAG_FORCE_GENERIC)) && !s->settings.verbose && !(m <= 128 && n <= 64) && m <= 512 && n <= 224 &&
         c->nnz_max >= 1 && c->nnz_max <= 65535) {
         int TT = 0;
         size_t lds_bytes = 0;

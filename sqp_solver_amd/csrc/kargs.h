@@ -45,6 +45,11 @@ struct KArgs {
     // class constants (qp.hpp:136-141), rounded through Scalar on the host
     T rho_min, rho_max, eq_tol, rho_eq_factor, loose_thresh, regul;
     int max_iter, check_termination, warm_start, adaptive_rho, adaptive_rho_interval;
+    // verbose trace of ONE QP (settings.verbose; reference print_status, src/qp.cpp:373-383): at every termination check the
+    // kernel appends {iter, objective 0.5 x'Px + q'x, res_prim, res_dual} to trace[1 + 4 k ..], k = trace[0]++ (< trace_cap).
+    // Null = off.  Only the generic and the one-QP-per-lane kernels record; the host routes verbose calls to them.
+    double *trace;
+    int trace_qp, trace_cap;
 };
 
 }  // namespace sqph

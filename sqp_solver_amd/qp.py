@@ -212,6 +212,19 @@ class QPSolverBatch:
         """setup(); solve() in one kernel launch (what SQP::run_solve_qp does, src/sqp.cpp:221-222)."""
         self._call(self._L.sqph_setup_solve, "sqph_setup_solve", P, q, A, l, u, colmajor)
 
+    def set_trace_qp(self, index):
+        self._check(self._L.sqph_set_trace_qp(self._h, int(index)), "sqph_set_trace_qp")
+
+    def trace(self):
+        """settings.verbose: the records of the last solve call for the traced QP, one row per termination check:
+        [iter, objective 0.5 x'Px + q'x, res_prim, res_dual] (what the reference's print_status prints, src/qp.cpp:373-383)."""
+        cnt = ctypes.c_int()
+        self._check(self._L.sqph_get_trace(self._h, None, 0, ctypes.byref(cnt)), "sqph_get_trace")
+        rec = np.zeros((cnt.value, 4))
+        if cnt.value:
+            self._check(self._L.sqph_get_trace(self._h, rec.ctypes.data_as(ctypes.c_void_p), cnt.value, ctypes.byref(cnt)), "sqph_get_trace")
+        return rec
+
     def setup_solve_reuse(self, P, q, A, l, u, colmajor=False):
         """setup(); solve() for QPs whose P and A are those of the previous setup (only q, l, u differ): the factor is rebuilt
         only where the rho vector changed (the SQP driver's second-order correction, src/sqp.cpp:244-276)."""

@@ -52,6 +52,14 @@ static void testSimpleQP() {
     CHECK(solver.info().status == SOLVED);
     CHECK(solver.info().iter == 125);  // oracle-pinned
 }
+static void testVerboseTrace() {  // QP_SOLVER_PRINTING: settings, "iter obj rp rd" table at every check, info (src/qp.cpp:72-76,113-117,152-156)
+    SimpleQP<double> qp;
+    QPSolver<double> solver;
+    solver.settings().verbose = true;
+    solver.setup(qp);
+    solver.solve(qp);  // prints to stdout; the test driver greps for the table
+    CHECK(solver.info().status == SOLVED && solver.info().iter == 125);
+}
 static void testSinglePrecisionFloat() {
     SimpleQP<float> qp;
     QPSolver<float> solver;
@@ -173,6 +181,7 @@ int main() {
     try {
         TestConstraint();  // host-only, no device needed
         testSimpleQP();
+        testVerboseTrace();
         testSinglePrecisionFloat();
         testConstraintViolation();
         testAdaptiveRho();

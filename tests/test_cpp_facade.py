@@ -38,3 +38,5 @@ def test_reference_gtest_cases_through_cpp_facade():
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "all passed" in p.stdout
+    # the verbose solve printed the reference's table: header, one line per check (25, 50, ... 125), then the info record
+    assert "iter   obj       rp        rd" in p.stdout and "\n 125  " in p.stdout and "ADMM info:" in p.stdout and "ADMM settings:" in p.stdout

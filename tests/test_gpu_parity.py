@@ -312,6 +312,46 @@ def test_true_fp32_variant():
     assert not s.kernel_name().endswith("_f32")
 
 
+def test_verbose_trace():
+    """settings.verbose (reference print_status, src/qp.cpp:373-383): one record per termination check for the traced QP — the
+    iteration, the objective, the residuals; the last one is the info record's; a verbose call composes with non-verbose ones
+    on the same handle (the recording kernels are another kernel family: the factor is rebuilt across the switch)"""
+    from sqp_solver_amd.problems import random_qp_batch
+
+    for (n, m, B, tq) in ((2, 3, 5, 0), (20, 40, 7, 3), (50, 100, 4, 2)):
+        P, q, A, l, u = (cases.simple(B) if n == 2 else random_qp_batch(B, n, m, seed=4))
+        s = make_gpu(n, m, B)
+        s.settings.verbose = 1
+        s.set_trace_qp(tq)
+        s.setup(P, q, A, l, u)
+        s.solve(P, q, A, l, u)
+        x, y, z, info = s.solution()
+        rec = s.trace()
+        ct = s.settings.check_termination
+        assert len(rec) == int(info.iter[tq]) // ct and len(rec) >= 1
+        assert (rec[:, 0] == ct * np.arange(1, len(rec) + 1)).all()
+        assert rec[-1, 2] == info.res_prim[tq] and rec[-1, 3] == info.res_dual[tq]
+        obj = 0.5 * x[tq] @ P[tq] @ x[tq] + q[tq] @ x[tq]
+        assert abs(rec[-1, 1] - obj) <= 1e-9 * max(1.0, abs(obj))
+        xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings))
+        assert (info.iter == io["iter"]).all() and cases.relerr(x, xo) < cases.TOL_F64
+        # non-verbose solve() on the same handle afterwards (fast kernel, factor rebuilt), then verbose again
+        s.settings.verbose = 0
+        s.solve(P, q + 0.1, A, l, u)
+        assert len(s.trace()) == 0
+        x1, y1, z1, info1 = s.solution()
+        s.settings.verbose = 1
+        s.solve(P, q, A, l, u)
+        assert len(s.trace()) >= 1
+        o = oracle.QPSolver()
+        o.setup(P[tq], q[tq], A[tq], l[tq], u[tq])
+        o.solve(P[tq], q[tq], A[tq], l[tq], u[tq])
+        o.solve(P[tq], q[tq] + 0.1, A[tq], l[tq], u[tq])
+        assert info1.iter[tq] == o.info.iter and cases.relerr(x1[tq][None], o.primal_solution()[None]) < cases.TOL_F64
+        o.solve(P[tq], q[tq], A[tq], l[tq], u[tq])
+        assert s.info().iter[tq] == o.info.iter and cases.relerr(s.solution()[0][tq][None], o.primal_solution()[None]) < cases.TOL_F64
+
+
 def test_lane_kernel_paths():
     """the one-QP-per-lane kernel through the C-ABI: fixed iterations, alpha, float interface, termination / adaptive / SQP
     settings (QPs without a stable reference answer excluded by parity_termination), state paths, fused-then-solve"""
