@@ -47,8 +47,34 @@ def csr_case():
         print(name, "status", np.bincount(info["status"], minlength=2), "iters", info["iter"].min(), info["iter"].max())
 
 
+def tiny_cases():
+    """BASELINE config 4's subproblem shapes (n = 2, m = 3 and n = 3, m = 3; one QP per lane on the GPU) under the SQP driver's QP
+    settings (src/sqp.cpp:15-23) and with a fixed iteration count.  Only QPs with a stable reference answer are kept: the double
+    oracle and its x87 extended-precision instance agree on status / iterations / rho updates and to 1e-9 on x (adaptive rho on
+    QPs this small can hinge on a residual at rounding level)."""
+    sqp = dict(warm_start=1, check_termination=10, eps_abs=1e-4, eps_rel=1e-4, max_iter=100, adaptive_rho=1, adaptive_rho_interval=50, alpha=1.6)
+    ld = np.longdouble
+    for name, n, m, B, seed, over in (("c4_n2_m3_sqp_settings", 2, 3, 96, 20250232, sqp), ("c4_n3_m3_sqp_settings", 3, 3, 96, 20250234, sqp),
+                                      ("c4_n2_m3_fixed100", 2, 3, 64, 20250232, dict(max_iter=100, check_termination=0))):
+        P, q, A, l, u = random_qp_batch(B, n, m, seed=seed)
+        st = oracle.default_settings(**over)
+        x, y, z, info = oracle.solve_batch(P, q, A, l, u, st, nthreads=1)
+        x80, y80, z80, i80 = oracle.solve_batch(P.astype(ld), q.astype(ld), A.astype(ld), l.astype(ld), u.astype(ld), st, nthreads=1, dtype=ld)
+        ex = np.max(np.abs(x - x80.astype(np.float64)), axis=1) / np.maximum(np.max(np.abs(x), axis=1), 1e-300)
+        ey = np.max(np.abs(y - y80.astype(np.float64)), axis=1) / np.maximum(np.max(np.abs(y), axis=1), 1.0)
+        keep = (info["status"] == i80["status"]) & (info["iter"] == i80["iter"]) & (info["rho_updates"] == i80["rho_updates"]) & (ex < 1e-9) & (ey < 1e-9)
+        P, q, A, l, u, x, y, z, info = P[keep], q[keep], A[keep], l[keep], u[keep], x[keep], y[keep], z[keep], info[keep]
+        d = dict(n=n, m=m, P=P, q=q, A=A, l=l, u=u, x=x, y=y, z=z, status=info["status"], iter=info["iter"],
+                 rho_updates=info["rho_updates"], res_prim=info["res_prim"], res_dual=info["res_dual"])
+        for k in SETTING_KEYS:
+            d["set_" + k] = getattr(st, k)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        print(name, "kept", int(keep.sum()), "of", B, "status", np.bincount(info["status"], minlength=2), "iters", info["iter"].min(), info["iter"].max())
+
+
 def main():
     csr_case()
+    tiny_cases()
     for name, n, m, B, seed, over in CASES:
         if seed is None:
             S = SIMPLE_QP

@@ -250,3 +250,21 @@ def test_setup_solve_reuse(make, n, m):
     """sqph_setup_solve_reuse (SOC): bit-identical to a plain setup+solve whether the factor is reused (lane, wg), rebuilt because
     rho moved, or the kernel ignores the hint (g16, generic)"""
     cases.soc_factor_reuse(make, n=n, m=m, batch=3)
+
+
+def test_lane_golden_fixtures():
+    """the config-4 golden fixtures (tests/golden/c4_*.npz) through the one-QP-per-lane kernel under the emulator"""
+    import golden_io
+
+    seen = 0
+    for name, g in golden_io.load_all():
+        if not name.startswith("c4_"):
+            continue
+        seen += 1
+        s = make_lane(g["n"], g["m"], g["P"].shape[0])
+        golden_io.apply_settings(s.settings, g)
+        s.setup_solve(g["P"], g["q"], g["A"], g["l"], g["u"])
+        x, y, z, info = s.solution()
+        assert cases.relerr(x, g["x"]) < cases.TOL_F64 and cases.relerr1(y, g["y"]) < cases.TOL_F64, name
+        assert (info.status == g["status"]).all() and (info.iter == g["iter"]).all() and (info.rho_updates == g["rho_updates"]).all(), name
+    assert seen == 3
