@@ -191,6 +191,16 @@ def main():
         avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         achieved = bytes_per_qp * B / (avg_kernel_ms * 1e-3) / 1e9
         iters_per_qp = iters_local / B
+        # the arithmetic type of the path: fp64 unless the true-fp32 kernel variant ran (fp32 at the interface alone is not fp32 arithmetic)
+        arith_dtype = "f32" if solver.kernel_name().endswith("_f32") else "f64"
+        if args.workload == "c2":
+            label = "BASELINE configs[1]"
+        elif args.workload == "c5":
+            label = "BASELINE configs[4]"
+        elif (n, m) == (50, 100):
+            label = "BASELINE configs[2] whole batch" if total_batch >= 65536 else "BASELINE configs[2] shard"
+        else:
+            label = "custom shape (not a BASELINE config)"
         out = {
             "metric": "qp_solves_per_sec",
             "value": value,
@@ -202,16 +212,16 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": args.dtype,
+            "dtype": arith_dtype,
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d %s QPs n=%d m=%d per GPU (%d total), %s" % (
-                    {"c3": "BASELINE configs[2] shard", "c2": "BASELINE configs[1]", "c5": "BASELINE configs[4]"}[args.workload],
+                    label,
                     B, "CSR-A (5 % dense)" if csr is not None else "dense", n, m, total_batch,
                     ("fixed %d ADMM iterations (check_termination=0)" % args.iters) if args.mode == "fixed"
                     else "reference default settings (eps 1e-3, check 25, max_iter 1000)" if args.mode == "default"
                     else "the SQP driver's QP settings (src/sqp.cpp:15-23: eps 1e-4, check 10, max_iter 100, adaptive rho / 50, alpha 1.6)"),
-                "n": n, "m": m, "batch_per_gpu": B, "global_batch": total_batch, "mode": args.mode,
+                "n": n, "m": m, "batch_per_gpu": B, "global_batch": total_batch, "mode": args.mode, "interface_dtype": args.dtype,
                 "admm_iters_per_qp": iters_per_qp, "kernel": solver.kernel_name(),
                 "parallelism": "batch-sharded x%d" % world,
                 "gather": bool(gather_bufs is not None),
