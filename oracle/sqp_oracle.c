@@ -19,6 +19,8 @@
 
 static sqpo_trace_fn g_trace = 0;
 static void *g_trace_user = 0;
+static int g_qp_extended = 0;
+void sqpo_set_qp_extended(int on) { g_qp_extended = on; }
 void sqpo_set_trace(sqpo_trace_fn f, void *user) {
     g_trace = f;
     g_trace_user = user;
@@ -96,6 +98,7 @@ typedef struct {
     double obj, primal_step_norm, dual_step_norm;
     double *p, *p_lambda, *ql, *qu, *tmp_n, *tmp_n2, *tmp_m, *work_nn, *x_step, *c_step, *d;
     qpo_solver_f64 *qp;
+    qpo_solver_f80 *qp80; /* only with sqpo_set_qp_extended(1): the same QP algorithm in x87 extended precision */
     sqpo_settings settings;
     sqpo_info info;
 } sqp_state;
@@ -105,6 +108,25 @@ static double *dalloc(int k) { return (double *)calloc((size_t)(k > 0 ? k : 1), 
 /* run_solve_qp, sqp.cpp:210-242: setup() + solve() on the persistent QP solver member */
 static int run_solve_qp(sqp_state *s, const double *P, const double *q, const double *A, const double *l, const double *u,
                         double *prim, double *dual) {
+    if (s->qp80) {
+        /* yard-stick mode: identical statement order, the QP arithmetic in long double.  Shows which outcomes of the outer
+         * loop hinge on the rounding of the QP iterate (nothing else in the outer loop changes). */
+        const int n = s->n, m = s->m;
+        long double *b = (long double *)malloc(sizeof(long double) * (size_t)(n * n + n + m * n + 2 * m + 1));
+        long double *Pl = b, *ql = Pl + n * n, *Al = ql + n, *ll = Al + m * n, *ul = ll + m;
+        for (int i = 0; i < n * n; i++) Pl[i] = P[i];
+        for (int i = 0; i < n; i++) ql[i] = q[i];
+        for (int i = 0; i < m * n; i++) Al[i] = A[i];
+        for (int i = 0; i < m; i++) { ll[i] = l[i]; ul[i] = u[i]; }
+        qpo_setup_f80(s->qp80, n, m, Pl, ql, Al, ll, ul);
+        qpo_solve_f80(s->qp80, Pl, ql, Al, ll, ul);
+        free(b);
+        s->info.qp_solver_iter += qpo_info_ptr_f80(s->qp80)->iter;
+        if (qpo_info_ptr_f80(s->qp80)->status == QPO_NUMERICAL_ISSUES) return 0;
+        for (int i = 0; i < n; i++) prim[i] = (double)qpo_primal_f80(s->qp80)[i];
+        for (int i = 0; i < m; i++) dual[i] = (double)qpo_dual_f80(s->qp80)[i];
+        return 1;
+    }
     qpo_setup_f64(s->qp, s->n, s->m, P, q, A, l, u);
     qpo_solve_f64(s->qp, P, q, A, l, u);
     s->info.qp_solver_iter += qpo_info_ptr_f64(s->qp)->iter;
@@ -213,6 +235,10 @@ void sqpo_solve(const sqpo_problem *prob, const sqpo_settings *settings, const d
     qpo_settings *qs = qpo_settings_ptr_f64(s->qp);
     qs->warm_start = 1; qs->check_termination = 10; qs->eps_abs = 1e-4; qs->eps_rel = 1e-4; qs->max_iter = 100;
     qs->adaptive_rho = 1; qs->adaptive_rho_interval = 50; qs->alpha = 1.6;
+    if (g_qp_extended) {
+        s->qp80 = qpo_create_f80();
+        *qpo_settings_ptr_f80(s->qp80) = *qs;
+    }
     s->info.qp_solver_iter = 0;
     s->info.status = SQPO_MAX_ITER_EXCEEDED;
 
@@ -256,6 +282,7 @@ void sqpo_solve(const sqpo_problem *prob, const sqpo_settings *settings, const d
     if (lambda_out) memcpy(lambda_out, s->lambda, sizeof(double) * (size_t)m);
     if (info_out) *info_out = s->info;
     qpo_destroy_f64(s->qp);
+    if (s->qp80) qpo_destroy_f80(s->qp80);
     double *ptrs[] = {s->x, s->lambda, s->step_prev, s->grad_L, s->delta_grad_L, s->Hess, s->grad_obj, s->Jac, s->constr, s->l, s->u,
                       s->p, s->p_lambda, s->ql, s->qu, s->tmp_n, s->tmp_n2, s->tmp_m, s->work_nn, s->x_step, s->c_step, s->d};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(ptrs[i]);

@@ -32,6 +32,9 @@ void sqpo_default_settings(sqpo_settings *s);
  * Process-global (test infrastructure, single-threaded use). */
 typedef void (*sqpo_trace_fn)(void *user, int iter, const double *p, const double *p_lambda, double alpha, int qp_iter);
 void sqpo_set_trace(sqpo_trace_fn f, void *user);
+/* 1: the QP subproblems are solved by the x87 extended-precision instance of the QP oracle (a yard-stick for "which outcomes of
+ * the outer loop are decided by the rounding of a QP iterate"); 0 (default): the double instance, as the reference. */
+void sqpo_set_qp_extended(int on);
 void sqpo_solve(const sqpo_problem *prob, const sqpo_settings *settings, const double *x0, const double *lambda0,
                 double *x_out, double *lambda_out, sqpo_info *info_out);
 

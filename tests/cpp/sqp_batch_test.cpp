@@ -190,11 +190,15 @@ static std::vector<Case> reference_cases() {
     add("TestSimpleQP", new SimpleQPasNLP, {0, 0}, {0, 0, 0}, {0.3, 0.7}, true);                // sqp_test.cpp:125-141
     add("TestConstrainedRosenbrock2D", new ConstrainedRosenbrock2D, {0, 0}, {0, 0}, {0.707106781, 0.707106781}, false);
     add("TestRosenbrock2", new Rosenbrock(2), {0, 0}, {0, 0}, {1, 1}, false);                   // autodiff:148-165
-    // n = 3 from x0 = 0 is decided by rounding: the first QP's solution p = (1, 1, 0) sits ON the bound u - c = 1, the
-    // merit weight mu is negative there (sqp.cpp:286, constr_l1 = eps), so the step is accepted iff the ADMM iterate
-    // overshoots the bound by ~1e-6 — the sign of a 1e-4-tolerance residual.  The oracle takes the overshoot branch and
-    // then stalls at (1, 1, 0); without the reference binary the branch it takes cannot be pinned, so this case is
-    // checked for GPU-vs-oracle trajectory parity only.
+    // n = 3 from x0 = 0: the first QP is  min 1/2 p'p - (2, 2, 0)'p,  0 <= p <= 1  (H = I, J = I).  Its ADMM iterate approaches the
+    // active bound FROM ABOVE (x~ = (2 + rho z - y) / (1 + sigma + rho) > 1 while y < y* = 1; an independent numpy restatement gives
+    // the same 1.1855 / 1.0408 / 1.0085 at iterations 10 / 20 / 30) and the solve stops at iteration 60 with p = (1 + 2.1e-6, 1 + 2.1e-6,
+    // 0).  The merit weight mu is negative there (sqp.cpp:286, constr_l1 = eps), the overshoot makes mu * constraint_norm(x + p) ~ -1e11
+    // and the full step is accepted; at (1, 1, 0) the next line search runs out of iterations (alpha = 0.5^19), both step norms fall
+    // under 1e-4 and the loop reports SOLVED at (1, 1, 0).  This is not a rounding matter: the same outer loop with the QPs solved in
+    // x87 extended precision takes the identical path (printed below).  So the algorithm as written does not reach the (1, 1, 1) the
+    // reference's test expects for n = 3; without the reference binary (Eigen absent) that expectation cannot be confirmed or refuted
+    // here, and the case is checked for GPU-vs-oracle trajectory parity only.
     add("TestRosenbrock3", new Rosenbrock(3), {0, 0, 0}, {0, 0, 0}, {1, 1, 1}, false, /*known=*/false);
     add("AutoDiff.TestSimpleNLP", new SimpleNLP, {1.2, 0.1}, {0, 0, 0}, {1, 1}, false);         // autodiff:195-217
     add("AutoDiff.TestSimpleNLP_SOC", new SimpleNLP, {1.2, 0.1}, {0, 0, 0}, {1, 1}, true);      // autodiff:219-241
@@ -211,7 +215,17 @@ static void oracle_cases() {
         printf("oracle %-28s iter %3d qp_iter %5d status %d x", c.name, r.info.iter, r.info.qp_solver_iter, r.info.status);
         for (double v : r.x) printf(" %.9f", v);
         printf("\n");
-        if (!c.known) continue;
+        if (!c.known) {
+            // the same outer loop with the QP subproblems solved in x87 extended precision: shows what the rounding of the first
+            // QP iterate decides (see the comment at TestRosenbrock3)
+            sqpo_set_qp_extended(1);
+            OracleRun e = oracle_solve(*c.prob, s, c.x0.data(), c.y0.data());
+            sqpo_set_qp_extended(0);
+            printf("oracle %-28s (QP in x87 extended precision) iter %3d qp_iter %5d status %d x", c.name, e.info.iter, e.info.qp_solver_iter, e.info.status);
+            for (double v : e.x) printf(" %.9f", v);
+            printf("  -> reference's known answer %s\n", is_approx(e.x.data(), c.solution.data(), c.prob->num_var, 1e-2) ? "REACHED" : "not reached");
+            continue;
+        }
         CHECK(is_approx(r.x.data(), c.solution.data(), c.prob->num_var, 1e-2));
         CHECK(r.info.iter < s.max_iter);
         CHECK(r.info.status == SQPO_SOLVED);
