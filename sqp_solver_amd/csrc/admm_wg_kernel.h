@@ -134,14 +134,15 @@ struct WgLayout {
     // x~ partials of stage 2 ([R u + r][Cp]): a region of their own — stage 2 of a fast wave must not overwrite the stage-1
     // partials a slower wave of the workgroup is still reducing (there is no workgroup barrier between the two stages)
     // (the aliased region below the owners' constants is also made large enough to stage all of W for the W -> W' transposition)
-    static constexpr int O_STX = ev(mx(mx(O_STAGE + STAGE, SETUP), NP * WSTR - NR * Cp));
+    static constexpr int O_AS2 = NP * WSTR;  // build_B: one block of R rows of A behind the staged W
+    static constexpr int O_STX = ev(mx(mx(O_STAGE + STAGE, SETUP), O_AS2 + R * SSTR - NR * Cp));
     // per-element constants of the owners (q, l, u): LDS instead of VGPRs, after everything the set-up may alias
     static constexpr int O_QV = ev(O_STX + NR * Cp);
     static constexpr int O_LOV = O_QV + NP;
     static constexpr int O_UPV = O_LOV + MP;
     static constexpr int O_RINV = O_UPV + MP;  // 1/rho of the owned constraint (changes only at a refactorisation)
     static constexpr int TOTAL = ev(O_RINV + MP);
-    static_assert(NP * WSTR <= O_QV, "W -> W' transposition stages all of W in [0, O_QV)");
+    static_assert(O_AS2 + R * SSTR <= O_QV, "build_B stages all of W and a block of A rows in [0, O_QV)");
     static constexpr int slot(int j) { return 8 * (j / TC) + (j % TC); }
 };
 
@@ -336,63 +337,11 @@ struct WgKernel {
     // W is staged once (transposed) in LDS from the register tile, A goes through LDS one block of R rows at
     // a time — nothing is re-read from global memory.
     static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c SQPH_STICK_ARGS) {
-        T *As = lds + L::O_AS, *Wl = lds + L::O_WL;
-        const int myhalf = c / L::CH, cl = c - myhalf * L::CH;  // my column group inside its half
-
-#pragma unroll
-        for (int s = 0; s < TR; s++) {
-            wsync();
-#pragma unroll
-            for (int k = 0; k < TC; k++) As[r * L::SSTR + 8 * c + k] = at[s][k];
-            T acc[TC];
-#pragma unroll
-            for (int k = 0; k < TC; k++) acc[k] = 0;
-#pragma unroll 1
-            for (int half = 0; half < 2; half++) {
-                wsync();
-                // Wl[jl][slot(i')] = W[i'][CH*TC*half + jl] from the lanes whose columns lie in this half
-                if (myhalf == half) {
-#pragma unroll
-                    for (int u = 0; u < TW; u++) {
-                        const int i = R * u + r;
-                        if (i < L::NP) {
-#pragma unroll
-                            for (int k = 0; k < TC; k++) Wl[(TC * cl + k) * L::WSTR + L::slot(i)] = wt[u][k];
-                        }
-                    }
-                }
-                wsync();
-                // W[TC c + k][j] = 0 for j > TC c + k: column groups beyond my own contribute nothing
-                const int cj0 = L::CH * half;
-                int cj1 = cj0 + L::CH - 1;
-                cj1 = cj1 < c ? cj1 : c;
-                cj1 = cj1 < C - 1 ? cj1 : C - 1;
-#pragma unroll 1
-                for (int cj = cj0; cj <= cj1; cj++) {
-                    T av[8];
-                    wg_read<8>(As + r * L::SSTR + 8 * cj, av);
-#pragma unroll
-                    for (int kj = 0; kj < TC; kj++) {
-                        if (TC * cj + kj >= n) break;
-                        T wv[8];
-                        wg_read<8>(Wl + (TC * (cj - cj0) + kj) * L::WSTR + 8 * c, wv);
-#pragma unroll
-                        for (int k = 0; k < TC; k++) acc[k] = wg_fma(av[kj], wv[k], acc[k]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < TC; k++) at[s][k] = acc[k];
-        }
-        // The tile of W' in the tile layout (rows cyclic over r, columns blocked by c) for the iteration loop,
-        // vt[u][k] = W[TC c + k][R u + r]: a transposition of the W tile through the same staging area, half of W's columns
-        // at a time.  It comes last so that vt is not live in registers next to the accumulators of the loop above (the W
-        // tile is dead after its owner's half has been staged).  Nothing goes through global memory.
-        // First half of the W -> W' transposition: every lane stages its W tile (dead afterwards) in [0, NP * WSTR); the W' tile
-        // is picked up by load_vt_lds() once the set-up block — and with it the W tile's registers — has ended.  (Computing vt
-        // inside this block, next to the live W tile, put 20 tile registers of the iteration loop into scratch.)
-        T *Wf = lds;
-        wsync();
+        // All of W is staged once, transposed, in [0, NP * WSTR): Wf[j][slot(i')] = W[i'][j].  It serves the B = A W' product below
+        // (the W tile's registers are dead from here on) and, afterwards, the W -> W' transposition of load_vt_lds().  The A tile goes
+        // through As one block of R rows at a time; nothing goes through global memory.
+        T *Wf = lds, *As = lds + L::O_AS2;
+        wsync();  // the factorisation's scratch in this region is dead
 #pragma unroll
         for (int u = 0; u < TW; u++) {
             const int i = R * u + r;
@@ -401,6 +350,35 @@ struct WgKernel {
                 for (int k = 0; k < TC; k++) Wf[(TC * c + k) * L::WSTR + L::slot(i)] = wt[u][k];
             }
         }
+#pragma unroll
+        for (int s = 0; s < TR; s++) {
+            wsync();
+#pragma unroll
+            for (int k = 0; k < TC; k++) As[r * L::SSTR + 8 * c + k] = at[s][k];
+            wsync();
+            T acc[TC];
+#pragma unroll
+            for (int k = 0; k < TC; k++) acc[k] = 0;
+            // W[TC c + k][j] = 0 for j > TC c + k: column groups beyond my own contribute nothing
+#pragma unroll 1
+            for (int cj = 0; cj <= c; cj++) {
+                T av[8];
+                wg_read<8>(As + r * L::SSTR + 8 * cj, av);
+#pragma unroll
+                for (int kj = 0; kj < TC; kj++) {
+                    if (TC * cj + kj >= n) break;
+                    T wv[8];
+                    wg_read<8>(Wf + (TC * cj + kj) * L::WSTR + 8 * c, wv);
+#pragma unroll
+                    for (int k = 0; k < TC; k++) acc[k] = wg_fma(av[kj], wv[k], acc[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TC; k++) at[s][k] = acc[k];
+        }
+        // The W' tile (vt[u][k] = W[TC c + k][R u + r]) is picked up from Wf by load_vt_lds() once the set-up block — and with it
+        // the W tile's registers — has ended.  (Computing vt inside this block, next to the live W tile, put 20 tile registers of
+        // the iteration loop into scratch.)
     }
     // second half of the W -> W' transposition: vt[u][k] = W[TC c + k][R u + r] from the staged copy (the tile of W' in the tile
     // layout — rows cyclic over r, columns blocked by c — that the iteration loop runs on).  Nothing goes through global memory.
@@ -416,51 +394,90 @@ struct WgKernel {
         }
         wsync();
     }
-    // residual check only: A x partials (staged for the reduction over c) and A' y partials (over r), with
-    // the A tile streamed column by column from global memory.  The column loop is deliberately NOT
-    // unrolled (x[k] comes from LDS) so this rare block does not raise the kernel's register high-water
-    // mark — occupancy is decided by the peak over the whole kernel, not by the hot loop.
+    // residual check only: A x partials (staged for the reduction over c) and A' y partials (over r), with the A tile streamed from
+    // global memory.  A check is a chain of dependent memory round trips (the register tiles hold B and W', so A and P come from
+    // L2 / HBM), hence: loads are unconditional (indices clamped into the matrix; the padding needs no masking because x and y
+    // are staged with zeros beyond n and m and the padded outputs are never read), and two columns are in flight at a time — as
+    // many as fit next to the live tiles without raising the kernel's register high-water mark (the loop is NOT unrolled further).
+    // m == 0: the caller passes any readable pointer (every index is clamped to 0 then).
     static __device__ __forceinline__ void stage_A_AT_gmem(const TIN *__restrict__ gA, int n, int m, int r, int c,
                                                            const T (&y)[TR], T *lds) {
         T pz[TR];
+        int ii[TR];
 #pragma unroll
-        for (int s = 0; s < TR; s++) pz[s] = 0;
+        for (int s = 0; s < TR; s++) {
+            pz[s] = 0;
+            const int i = R * s + r;
+            ii[s] = i < m ? i : (m > 0 ? m - 1 : 0);
+        }
         T *stx = lds + L::O_STAGE;
         const T *xv = lds + L::O_COLV + c * L::TCp;
-#pragma unroll SQPH_CHECK_UNROLL
-        for (int k = 0; k < TC; k++) {
-            const int j = TC * c + k;
-            const T xk = xv[k];
-            T pb = 0;
+#pragma unroll 1
+        for (int k = 0; k < TC; k += 2) {
+            const int j0 = TC * c + k, j1 = j0 + ((k + 1 < TC) ? 1 : 0);
+            const TIN *p0 = gA + (long)(j0 < n ? j0 : n - 1) * m;
+            const TIN *p1 = gA + (long)(j1 < n ? j1 : n - 1) * m;
+            T a0[TR], a1[TR];
 #pragma unroll
-            for (int s = 0; s < TR; s++) {
-                const int i = R * s + r;
-                const T av = (j < n && i < m) ? (T)gA[(long)j * m + i] : T(0);
-                pz[s] = wg_fma(av, xk, pz[s]);
-                pb = wg_fma(av, y[s], pb);
+            for (int s = 0; s < TR; s++) a0[s] = (T)p0[ii[s]];
+#pragma unroll
+            for (int s = 0; s < TR; s++) a1[s] = (T)p1[ii[s]];
+            {
+                const T xk = xv[k];
+                T pb = 0;
+#pragma unroll
+                for (int s = 0; s < TR; s++) {
+                    pz[s] = wg_fma(a0[s], xk, pz[s]);
+                    pb = wg_fma(a0[s], y[s], pb);
+                }
+                stx[(TC * c + k) * L::Rp + r] = pb;
             }
-            stx[(TC * c + k) * L::Rp + r] = pb;
+            if (k + 1 < TC) {
+                const T xk = xv[k + 1];
+                T pb = 0;
+#pragma unroll
+                for (int s = 0; s < TR; s++) {
+                    pz[s] = wg_fma(a1[s], xk, pz[s]);
+                    pb = wg_fma(a1[s], y[s], pb);
+                }
+                stx[(TC * c + k + 1) * L::Rp + r] = pb;
+            }
         }
         T *sty = lds + L::O_STAGE_Y;
 #pragma unroll
         for (int s = 0; s < TR; s++) sty[(R * s + r) * L::Cp + c] = pz[s];
     }
-    // residual check only: P x partials with the P tile streamed row-block by row-block (not unrolled)
+    // residual check only: P x partials with the P tile streamed two row blocks at a time (same scheme)
     static __device__ __forceinline__ void stage_P_gmem(const TIN *__restrict__ gP, int n, int r, int c, T *lds) {
         T xc[TC];
         get_colv(lds, c, xc);
+        int jo[TC];
+#pragma unroll
+        for (int k = 0; k < TC; k++) {
+            const int j = TC * c + k;
+            jo[k] = (j < n ? j : n - 1) * n;
+        }
         T *sty = lds + L::O_STAGE_Y;
-#pragma unroll SQPH_CHECK_UNROLL
-        for (int u = 0; u < TW; u++) {
-            const int i = R * u + r;
+#pragma unroll 1
+        for (int u = 0; u < TW; u += 2) {
+            const int i0 = R * u + r, i1 = R * (u + ((u + 1 < TW) ? 1 : 0)) + r;
+            const TIN *p0 = gP + (i0 < n ? i0 : n - 1);
+            const TIN *p1 = gP + (i1 < n ? i1 : n - 1);
+            T v0[TC], v1[TC];
+#pragma unroll
+            for (int k = 0; k < TC; k++) v0[k] = (T)p0[jo[k]];
+#pragma unroll
+            for (int k = 0; k < TC; k++) v1[k] = (T)p1[jo[k]];
             T acc = 0;
 #pragma unroll
-            for (int k = 0; k < TC; k++) {
-                const int j = TC * c + k;
-                const T pv = (i < n && j < n) ? (T)gP[(long)j * n + i] : T(0);
-                acc = wg_fma(pv, xc[k], acc);
-            }
+            for (int k = 0; k < TC; k++) acc = wg_fma(v0[k], xc[k], acc);
             sty[(R * u + r) * L::Cp + c] = acc;
+            if (u + 1 < TW) {
+                T acc1 = 0;
+#pragma unroll
+                for (int k = 0; k < TC; k++) acc1 = wg_fma(v1[k], xc[k], acc1);
+                sty[(R * (u + 1) + r) * L::Cp + c] = acc1;
+            }
         }
     }
 
@@ -868,7 +885,7 @@ struct WgKernel {
                         T yr[TR];
                         get_rowv(lds, r, yr);
                         int n_c = n, m_c = m, r_c = r, c_c = c;
-                        const TIN *gA_c = gA;
+                        const TIN *gA_c = m > 0 ? gA : gP;  // m == 0: nothing to read, any readable address will do
                         SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_S(m_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gA_c);
                         stage_A_AT_gmem(gA_c, n_c, m_c, r_c, c_c, yr, lds);  // A x (over c) and A' y (over r)
                     }
@@ -1254,7 +1271,7 @@ struct WgKernel {
                         get_rowv(lds, r, yr);
                         int n_c = n, m_c = m, r_c = r, c_c = c, qp_c = qp;
                         SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_S(m_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_V(qp_c);
-                        stage_A_AT_gmem(a.A + (long)qp_c * a.sA, n_c, m_c, r_c, c_c, yr, lds);
+                        stage_A_AT_gmem(m_c > 0 ? a.A + (long)qp_c * a.sA : a.P + (long)qp_c * a.sP, n_c, m_c, r_c, c_c, yr, lds);
                     }
                     wsync();
                     T Ax[NOM], ATy[NON], Px[NON];
