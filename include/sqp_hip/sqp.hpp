@@ -55,6 +55,33 @@ struct Info {
     Status status = MAX_ITER_EXCEEDED;
 };
 
+// Damped BFGS update ("Procedure 18.2", Nocedal & Wright) of the column-major n x n matrix B with step s and gradient change y:
+// the reference's BFGS_update (include/solvers/bfgs.hpp:14-41), statement for statement.  Bs and r are n-vectors of scratch.
+template <typename Scalar>
+inline void bfgs_update(Scalar *B, int n, const Scalar *s, const Scalar *y, Scalar *Bs, Scalar *r) {
+    Scalar sBs = 0, sy = 0, sr;
+    for (int i = 0; i < n; i++) {
+        Scalar a = 0;
+        for (int j = 0; j < n; j++) a += B[(size_t)j * n + i] * s[j];
+        Bs[i] = a;
+    }
+    for (int i = 0; i < n; i++) {
+        sBs += s[i] * Bs[i];
+        sy += s[i] * y[i];
+    }
+    if (sy < 0.2 * sBs) {
+        const Scalar theta = 0.8 * sBs / (sBs - sy);
+        for (int i = 0; i < n; i++) r[i] = theta * y[i] + (1 - theta) * Bs[i];
+        sr = theta * sy + (1 - theta) * sBs;
+    } else {
+        for (int i = 0; i < n; i++) r[i] = y[i];
+        sr = sy;
+    }
+    if (sr < std::numeric_limits<Scalar>::epsilon()) return;
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) B[(size_t)j * n + i] += -Bs[i] * Bs[j] / sBs + r[i] * r[j] / sr;
+}
+
 // QPBackend: the batched QP-subproblem solver (setup_solve / info / primal_solution / dual_solution over a packed
 // batch).  The product instantiates the default — qp_solver::BatchQPSolver, i.e. libsqp_hip; tests/cpp substitutes a
 // backend that calls the CPU oracle to separate "the host driver is exact" from "a QP rounding flipped a line search".
@@ -257,32 +284,7 @@ class BatchSQP {
         }
         return true;
     }
-    // damped BFGS, include/solvers/bfgs.hpp:14-41
-    void bfgs_update(Inst &I) const {
-        const int n = n_;
-        const std::vector<Scalar> &s = I.step_prev, &y = I.delta_grad_L;
-        Scalar sBs = 0, sy = 0, sr;
-        for (int i = 0; i < n; i++) {
-            Scalar a = 0;
-            for (int j = 0; j < n; j++) a += I.Hess[(size_t)j * n + i] * s[j];
-            I.Bs[i] = a;
-        }
-        for (int i = 0; i < n; i++) {
-            sBs += s[i] * I.Bs[i];
-            sy += s[i] * y[i];
-        }
-        if (sy < 0.2 * sBs) {
-            const Scalar theta = 0.8 * sBs / (sBs - sy);
-            for (int i = 0; i < n; i++) I.r[i] = theta * y[i] + (1 - theta) * I.Bs[i];
-            sr = theta * sy + (1 - theta) * sBs;
-        } else {
-            for (int i = 0; i < n; i++) I.r[i] = y[i];
-            sr = sy;
-        }
-        if (sr < std::numeric_limits<Scalar>::epsilon()) return;
-        for (int j = 0; j < n; j++)
-            for (int i = 0; i < n; i++) I.Hess[(size_t)j * n + i] += -I.Bs[i] * I.Bs[j] / sBs + I.r[i] * I.r[j] / sr;
-    }
+    void bfgs_update(Inst &I) const { sqp::bfgs_update(I.Hess.data(), n_, I.step_prev.data(), I.delta_grad_L.data(), I.Bs.data(), I.r.data()); }
     Scalar constraint_norm(const Inst &I) const {  // src/sqp.cpp:310-318
         Scalar c_l1 = DIV_BY_ZERO_REGUL, a = 0, b = 0;
         for (int i = 0; i < m_; i++) a += (I.l[i] - I.constr[i]) > Scalar(0) ? (I.l[i] - I.constr[i]) : Scalar(0);

@@ -216,6 +216,13 @@ static double inf_norm(const double *v, int k) {
     return r;
 }
 
+/* test access to the BFGS restatement (the reference tests it on its own, tests/bfgs_test.cpp) */
+void sqpo_bfgs_update(double *B, int n, const double *s, const double *y) {
+    double *w = dalloc(2 * n);
+    bfgs_update(B, n, s, y, w, w + n);
+    free(w);
+}
+
 /* SQP::solve(prob, x0, lambda0) -> run_solve, sqp.cpp:26-101 */
 void sqpo_solve(const sqpo_problem *prob, const sqpo_settings *settings, const double *x0, const double *lambda0,
                 double *x_out, double *lambda_out, sqpo_info *info_out) {

@@ -35,6 +35,8 @@ void sqpo_set_trace(sqpo_trace_fn f, void *user);
 /* 1: the QP subproblems are solved by the x87 extended-precision instance of the QP oracle (a yard-stick for "which outcomes of
  * the outer loop are decided by the rounding of a QP iterate"); 0 (default): the double instance, as the reference. */
 void sqpo_set_qp_extended(int on);
+/* BFGS_update, bfgs.hpp:14-41, on a column-major n x n matrix (test access) */
+void sqpo_bfgs_update(double *B, int n, const double *s, const double *y);
 void sqpo_solve(const sqpo_problem *prob, const sqpo_settings *settings, const double *x0, const double *lambda0,
                 double *x_out, double *lambda_out, sqpo_info *info_out);
 

@@ -646,7 +646,30 @@ static void gpu_cases() {
         batch_vs_oracle(w.name, *w.prob, w.N, w.X0, w.L0, w.soc, w.sol.empty() ? nullptr : w.sol.data(), w.min_solved_frac, w.min_strict, w.max_split);
 }
 
+// ---------------------------------------------------------------- the reference's BFGS tests (tests/bfgs_test.cpp:21-66) as data
+static bool posdef2(const double *B) {  // symmetric 2 x 2, column-major: both eigenvalues > 0
+    const double tr = B[0] + B[3], det = B[0] * B[3] - B[1] * B[2];
+    return tr > 0 && det > 0;
+}
+static void bfgs_cases() {
+    const double Hs[2][4] = {{2, 0, 0, 1}, {2, 0, 0, -1}};  // true constant Hessians: posdef, indefinite
+    for (int c = 0; c < 2; c++) {
+        double B[4] = {1, 0, 0, 1}, Bo[4] = {1, 0, 0, 1}, Bs[2], r[2];
+        for (int i = 0; i < 10; i++) {
+            const double step[2] = {std::sin((double)i), std::cos((double)i)};
+            const double dg[2] = {Hs[c][0] * step[0] + Hs[c][2] * step[1], Hs[c][1] * step[0] + Hs[c][3] * step[1]};
+            sqp::bfgs_update(B, 2, step, dg, Bs, r);  // the driver's
+            sqpo_bfgs_update(Bo, 2, step, dg);        // the oracle's
+            CHECK(posdef2(B));                        // EXPECT_TRUE(is_posdef(B)) after every update, both cases
+            for (int k = 0; k < 4; k++) CHECK(B[k] == Bo[k]);  // same statements, same bits
+        }
+        if (c == 0) CHECK(is_approx(B, Hs[0], 4, 1e-3));  // EXPECT_TRUE(B.isApprox(H, 1e-3)), bfgs_test.cpp:41
+        printf("bfgs  %-12s B = [%.6f %.6f; %.6f %.6f]\n", c == 0 ? "Test2D_posdef" : "Test2D_indef", B[0], B[2], B[1], B[3]);
+    }
+}
+
 int main(int argc, char **argv) {
+    bfgs_cases();
     oracle_cases();
     if (argc > 1 && !strcmp(argv[1], "oracle")) {
         printf("oracle cases passed\n");

@@ -36,6 +36,8 @@ def test_sqp_oracle_reproduces_reference_known_answers():
     p = subprocess.run([exe, "oracle"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "oracle cases passed" in p.stdout
+    # the reference's BFGS tests (tests/bfgs_test.cpp): the driver's and the oracle's damped update, bit-identical
+    assert "bfgs  Test2D_posdef" in p.stdout and "bfgs  Test2D_indef" in p.stdout
 
 
 def test_batch_sqp_host_driver_is_bit_exact_with_the_oracle_qp_backend():
