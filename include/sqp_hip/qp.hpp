@@ -431,7 +431,18 @@ template <int N_, int M_, typename Scalar_ = double>
 struct QP {
     using Scalar = Scalar_;
     enum { n = N_, m = M_ };
-#ifdef SQP_HIP_HAVE_EIGEN
+#if defined(SQP_HIP_HAVE_EIGEN) && defined(QP_SOLVER_USE_SPARSE)
+    // the sparse variant of the legacy class, unsupported/qp_solver.hpp:17-32: P and A are Eigen::SparseMatrix; the column
+    // counts only size the reference's KKT matrix and are not needed here.  P is densified (n x n) and A handed over in CSR
+    // (sqph_*_csr) by QPSolver below.
+    Eigen::SparseMatrix<Scalar> P;
+    Eigen::Matrix<int, N_, 1> P_col_nnz;
+    Eigen::Matrix<Scalar, N_, 1> q;
+    Eigen::SparseMatrix<Scalar> A;
+    Eigen::Matrix<int, N_, 1> A_col_nnz;
+    Eigen::Matrix<Scalar, M_, 1> l, u;
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#elif defined(SQP_HIP_HAVE_EIGEN)
     Eigen::Matrix<Scalar, N_, N_> P;  // members as in unsupported/qp_solver.hpp:35-48
     Eigen::Matrix<Scalar, N_, 1> q;
     Eigen::Matrix<Scalar, M_, N_> A;
@@ -456,7 +467,9 @@ template <typename S> inline S *ptr(S *v) { return v; }
 }  // namespace detail
 
 // LinearSolver / UpLo are accepted for source compatibility and ignored: the device always factors the Schur complement.
-#ifdef SQP_HIP_HAVE_EIGEN
+#if defined(SQP_HIP_HAVE_EIGEN) && defined(QP_SOLVER_USE_SPARSE)
+template <typename QPType, template <typename, int, typename...> class LinearSolver = Eigen::SimplicialLDLT, int LinearSolver_UpLo = Eigen::Lower>
+#elif defined(SQP_HIP_HAVE_EIGEN)
 template <typename QPType, template <typename, int, typename...> class LinearSolver = Eigen::LDLT, int LinearSolver_UpLo = Eigen::Lower>
 #else
 template <typename QPType>
@@ -495,11 +508,11 @@ class QPSolver {
         for (int i = 0; i < n; i++) x[i] = 0;
         for (int i = 0; i < m; i++) z[i] = y[i] = 0;
     }
-    void setup(const qp_t &qp) { run(&supported::BatchQPSolver<Scalar>::setup, qp, false); }
-    void update_qp(const qp_t &qp) { run(&supported::BatchQPSolver<Scalar>::update_qp, qp, true); }
+    void setup(const qp_t &qp) { run(OP_SETUP, qp, false); }
+    void update_qp(const qp_t &qp) { run(OP_UPDATE, qp, true); }
     void solve(const qp_t &qp) {
         if (_info.status == UNINITIALIZED) return;  // unsupported/qp_solver.hpp:246-249
-        run(&supported::BatchQPSolver<Scalar>::solve, qp, true);
+        run(OP_SOLVE, qp, true);
     }
 #ifdef SQP_HIP_HAVE_EIGEN
     const var_t &primal_solution() const { return x; }
@@ -518,8 +531,42 @@ class QPSolver {
     info_t &info() { return _info; }
 
    private:
-    template <typename F>
-    void run(F fn, const qp_t &qp, bool send_state) {
+    enum op_t { OP_SETUP, OP_UPDATE, OP_SOLVE };
+#if defined(SQP_HIP_HAVE_EIGEN) && defined(QP_SOLVER_USE_SPARSE)
+    // Eigen's compressed column-major A -> CSR (rows in order, columns ascending inside a row), P -> dense column-major
+    void dispatch(op_t op, const qp_t &qp) {
+        typedef Eigen::SparseMatrix<Scalar> SpMat;
+        std::vector<Scalar> Pd((size_t)n * n, Scalar(0));
+        for (int k = 0; k < (int)qp.P.outerSize(); k++)
+            for (typename SpMat::InnerIterator it(qp.P, k); it; ++it) Pd[(size_t)it.col() * n + it.row()] = it.value();
+        std::vector<int> rowptr((size_t)m + 1, 0);
+        for (int k = 0; k < (int)qp.A.outerSize(); k++)
+            for (typename SpMat::InnerIterator it(qp.A, k); it; ++it) rowptr[(size_t)it.row() + 1]++;
+        for (int i = 0; i < m; i++) rowptr[(size_t)i + 1] += rowptr[(size_t)i];
+        const int nnz = rowptr[(size_t)m];
+        std::vector<int> colind((size_t)(nnz > 0 ? nnz : 1)), cur(rowptr.begin(), rowptr.end() - 1);
+        std::vector<Scalar> val((size_t)(nnz > 0 ? nnz : 1));
+        for (int k = 0; k < (int)qp.A.outerSize(); k++)
+            for (typename SpMat::InnerIterator it(qp.A, k); it; ++it) {
+                const int e = cur[(size_t)it.row()]++;
+                colind[(size_t)e] = (int)it.col();
+                val[(size_t)e] = it.value();
+            }
+        const auto b = impl_.packed_csr(1, Pd.data(), detail::ptr(qp.q), rowptr.data(), colind.data(), val.data(), nnz > 0 ? nnz : 1,
+                                        detail::ptr(qp.l), detail::ptr(qp.u));
+        if (op == OP_SETUP) impl_.setup_csr(b);
+        else if (op == OP_UPDATE) impl_.update_qp_csr(b);
+        else impl_.solve_csr(b);
+    }
+#else
+    void dispatch(op_t op, const qp_t &qp) {
+        const auto b = impl_.packed(1, detail::ptr(qp.P), detail::ptr(qp.q), detail::ptr(qp.A), detail::ptr(qp.l), detail::ptr(qp.u));
+        if (op == OP_SETUP) impl_.setup(b);
+        else if (op == OP_UPDATE) impl_.update_qp(b);
+        else impl_.solve(b);
+    }
+#endif
+    void run(op_t op, const qp_t &qp, bool send_state) {
         impl_.settings() = _settings;
         if (send_state) {  // x, z, y are public members in the reference: what the caller left there is the solver's state
             bool d = false;
@@ -527,7 +574,7 @@ class QPSolver {
             for (int i = 0; i < m && !d; i++) d = !(z[i] == seen_[n + i]) || !(y[i] == seen_[n + m + i]);
             if (d) impl_.set_state(1, detail::ptr(x), m > 0 ? detail::ptr(z) : nullptr, m > 0 ? detail::ptr(y) : nullptr);
         }
-        (impl_.*fn)(impl_.packed(1, detail::ptr(qp.P), detail::ptr(qp.q), detail::ptr(qp.A), detail::ptr(qp.l), detail::ptr(qp.u)));
+        dispatch(op, qp);
         for (int i = 0; i < n; i++) seen_[i] = x[i] = impl_.primal_solution(0)[i];
         for (int i = 0; i < m; i++) seen_[n + i] = z[i] = impl_.z(0)[i];
         for (int i = 0; i < m; i++) seen_[n + m + i] = y[i] = impl_.dual_solution(0)[i];

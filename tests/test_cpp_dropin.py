@@ -4,7 +4,8 @@ reference's include paths.
 
 * tests/cpp/qp_dropin_test.cpp, qp_dropin_legacy_test.cpp: this repository's own callers written in the reference's style
   (`#include "solvers/qp.hpp"`, `qp.P = &P;`, Eigen vectors from primal_solution(), QP<2,3> with Eigen members).
-* the reference's OWN test files (tests/qp_solver_test.cpp, tests/unsupported/qp_solver_test.cpp + test_main.cpp), compiled
+* the reference's OWN test files (tests/qp_solver_test.cpp, tests/unsupported/qp_solver_test.cpp,
+  tests/qp_solver_sparse_test.cpp + test_main.cpp), compiled
   UNCHANGED from where they lie under /root/reference against the facade + the stand-ins (Eigen, GoogleTest).  They can only
   be compiled where /root/reference exists (this container); the binaries land in tests/cpp/_ref/ (git-ignored, they travel
   to the GPU box like the built .so) and the GPU test runs them when they are there.  Nothing of the reference is copied.
@@ -25,6 +26,8 @@ OWN = ["qp_dropin_test", "qp_dropin_legacy_test"]
 REF = {  # binary -> reference sources (relative to /root/reference)
     "ref_qp_solver_test": ["tests/qp_solver_test.cpp", "tests/test_main.cpp"],
     "ref_legacy_qp_solver_test": ["tests/unsupported/qp_solver_test.cpp", "tests/test_main.cpp"],
+    # the legacy class's sparse variant (QP_SOLVER_USE_SPARSE: Eigen::SparseMatrix members, CSR on the device)
+    "ref_sparse_qp_solver_test": ["tests/qp_solver_sparse_test.cpp", "tests/test_main.cpp"],
 }
 
 
