@@ -20,7 +20,17 @@
 
 #include "qp.hpp"
 
+// The types below live in sqp::raw.  By default that namespace is inline (sqp::NonLinearProblem, sqp::BatchSQP, ...); the drop-in
+// header for the reference's SQP class (compat/solvers/sqp.hpp) defines SQP_HIP_SQP_DROPIN, which makes it a plain namespace so
+// that sqp::NonLinearProblem / sqp_settings_t / Info / SQP can carry the reference's Eigen-typed definitions.
+#ifdef SQP_HIP_SQP_DROPIN
+#define SQP_HIP_INLINE_RAW
+#else
+#define SQP_HIP_INLINE_RAW inline
+#endif
+
 namespace sqp {
+SQP_HIP_INLINE_RAW namespace raw {
 
 template <typename Scalar_ = double>
 struct NonLinearProblem {
@@ -195,6 +205,7 @@ class BatchSQP {
                 for (int a = 0; a < n; a++) I.x[a] += alpha * I.p[a];
                 for (int a = 0; a < m; a++) I.lambda[a] += alpha * I.p_lambda[a];
                 for (int a = 0; a < n; a++) I.step_prev[a] = alpha * I.p[a];
+                if (step_) step_(step_user_, live[k], iter, I.x.data(), I.lambda.data());
                 const Scalar primal_step_norm = alpha * inf_norm(I.p), dual_step_norm = alpha * inf_norm(I.p_lambda);
                 if (primal_step_norm <= settings_.eps_prim && dual_step_norm <= settings_.eps_dual &&
                     max_constraint_violation(I, prob) <= settings_.eps_prim) {
@@ -210,6 +221,11 @@ class BatchSQP {
             inst_[i].info.iter = settings_.max_iter + 1;
         }
     }
+
+    // Called for every live instance right after its step has been taken (x, lambda updated) — where the reference calls
+    // settings.iteration_callback (src/sqp.cpp:88-90).
+    typedef void (*step_fn)(void *user, int instance, int iter, const Scalar *x, const Scalar *lambda);
+    void set_step_callback(step_fn f, void *user) { step_ = f; step_user_ = user; }
 
     // Per-instance trajectory record, called once per outer iteration after the line search (the reference has no such
     // hook; used by the parity tests to locate the first outer iteration at which two runs separate).
@@ -284,7 +300,7 @@ class BatchSQP {
         }
         return true;
     }
-    void bfgs_update(Inst &I) const { sqp::bfgs_update(I.Hess.data(), n_, I.step_prev.data(), I.delta_grad_L.data(), I.Bs.data(), I.r.data()); }
+    void bfgs_update(Inst &I) const { raw::bfgs_update(I.Hess.data(), n_, I.step_prev.data(), I.delta_grad_L.data(), I.Bs.data(), I.r.data()); }
     Scalar constraint_norm(const Inst &I) const {  // src/sqp.cpp:310-318
         Scalar c_l1 = DIV_BY_ZERO_REGUL, a = 0, b = 0;
         for (int i = 0; i < m_; i++) a += (I.l[i] - I.constr[i]) > Scalar(0) ? (I.l[i] - I.constr[i]) : Scalar(0);
@@ -342,9 +358,12 @@ class BatchSQP {
     Settings settings_;
     QPBackend qp_;
     trace_fn trace_ = nullptr;
+    step_fn step_ = nullptr;
+    void *step_user_ = nullptr;
     void *trace_user_ = nullptr;
     std::vector<Inst> inst_;
     std::vector<Scalar> P_, q_, A_, l_, u_;
 };
 
+}  // namespace raw
 }  // namespace sqp
