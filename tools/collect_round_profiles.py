@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""After tools/round_profiles.sh ran on the GPU box: copy the summaries into profiles/, record the PMC traffic of each workload
+under the current kernel-source hash, and move the bench lines.   usage: tools/collect_round_profiles.py r02 prof|bench"""
+import json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, phase = sys.argv[1], sys.argv[2]
+if phase == "bench":
+    shutil.copy(os.path.join(ROOT, "gpurun_out", tag + "_bench_lines.jsonl"), os.path.join(ROOT, "profiles", tag + "_bench_lines.jsonl"))
+    print("bench lines copied")
+    sys.exit(0)
+KERNELS = {"c3": "wg2_16x8_7x7_w2", "c3_default": "wg2_16x8_7x7_w2", "c3_sqp": "wg2_16x8_7x7_w2", "c2": "g32_5x5_w2", "c5": "csr_t7", "lane": "lane_2x3_exact"}
+W = {  # name -> (n, m, batch, mode)
+    "c3": (50, 100, 8192, "fixed"), "c3_default": (50, 100, 8192, "default"), "c3_sqp": (50, 100, 8192, "sqp"),
+    "c2": (20, 40, 4096, "fixed"), "c5": (200, 400, 8192, "fixed"), "lane": (2, 3, 65536, "fixed"),
+}
+for name, (n, m, batch, mode) in W.items():
+    src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, name))
+    shutil.copy(os.path.join(src, "summary.txt"), os.path.join(ROOT, "profiles", "%s_%s_summary.txt" % (tag, name)))
+    for f in os.listdir(os.path.join(src, "trace")) if os.path.isdir(os.path.join(src, "trace")) else []:
+        pass
+    stats = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(src, "trace")) for f in fs if f.endswith("kernel_stats.csv")]
+    if stats:
+        shutil.copy(stats[0], os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, name)))
+    kernel = KERNELS[name]
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "record_traffic.py"), os.path.join(src, "summary.txt"), kernel, str(n), str(m), str(batch), mode])
+print("ok")
