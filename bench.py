@@ -67,6 +67,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    # stdout carries exactly ONE line, the JSON record: libraries that write banners there (RCCL prints its version block on
+    # stdout when the first communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("SQPH_BENCH_DIST1") == "1")
@@ -251,7 +256,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, solver, P[:k], q[:k], A_cm, l[:k], u[:k], st, ndt)
             else:
                 out["cpu_baseline"] = cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         if gather_bufs is not None and rank == 0:
             # sanity: the gathered record of rank 0's own shard equals its resident state
