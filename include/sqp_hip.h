@@ -154,7 +154,9 @@ void sqph_default_settings(sqph_settings *s);
 int sqph_create(sqph_solver **out, int device, int n, int m, int batch_capacity, int dtype, int flags);
 void sqph_destroy(sqph_solver *s);
 
-/* Stream the kernels/copies are enqueued on (a hipStream_t; NULL = the null stream). */
+/* Stream the kernels/copies are enqueued on (a hipStream_t; NULL = the null stream).  With SQPH_DEVICE problem data a call only
+ * enqueues work there (one kernel launch; no allocation or synchronisation after the first call of a shape), so it can be captured
+ * into a hipGraph and replayed on updated inputs (tests/test_gpu_parity.py::test_hip_graph_capture_of_the_fused_call). */
 int sqph_set_stream(sqph_solver *s, void *hip_stream);
 
 int sqph_set_settings(sqph_solver *s, const sqph_settings *settings);

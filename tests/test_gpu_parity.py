@@ -447,3 +447,37 @@ def test_stress_parity_sparse_shape():
         _stress_log(rec)
         assert rec["ex"] < tol and rec["ey"] < tol, rec
         assert (info.rho_updates == io["rho_updates"]).all() and (info.iter == io["iter"]).all()
+
+
+def test_hip_graph_capture_of_the_fused_call():
+    """Device-memspace calls only enqueue work on the handle's stream (no allocation, no synchronisation after the first call of a
+    shape), so a fused setup+solve can be captured into a hipGraph and replayed on updated inputs — the launch-bound MPC pattern."""
+    import torch
+
+    from sqp_solver_amd.problems import random_qp_batch_torch
+
+    n, m, B = 50, 100, 128
+    P, q, A, l, u = random_qp_batch_torch(B, n, m, seed=3, device="cuda:0")
+    s = QPSolverBatch(n, m, B, device=0)
+    s.settings.max_iter = 60
+    s.settings.check_termination = 0
+    st = torch.cuda.Stream()
+    s.set_stream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        s.setup_solve(P, q, A, l, u, colmajor=True)  # first call of the shape: allocations happen here
+        st.synchronize()
+        x0 = s.solution()[0].copy()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            s.setup_solve(P, q, A, l, u, colmajor=True)
+        for scale in (1.5, -0.5):
+            q.mul_(scale)  # new linear term in the same buffers
+            g.replay()
+            st.synchronize()
+            xg, yg = (a.copy() for a in s.solution()[:2])
+            s.setup_solve(P, q, A, l, u, colmajor=True)
+            st.synchronize()
+            xd, yd = (a.copy() for a in s.solution()[:2])
+            assert np.array_equal(xg, xd) and np.array_equal(yg, yd)
+            assert not np.array_equal(xg, x0)
+    assert s.kernel_name() == "wg2_16x8_7x7_w2"
