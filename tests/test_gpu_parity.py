@@ -458,7 +458,7 @@ def test_hip_graph_capture_of_the_fused_call():
 
     n, m, B = 50, 100, 128
     P, q, A, l, u = random_qp_batch_torch(B, n, m, seed=3, device="cuda:0")
-    s = QPSolverBatch(n, m, B, device=0)
+    s = make_gpu(n, m, B)
     s.settings.max_iter = 60
     s.settings.check_termination = 0
     st = torch.cuda.Stream()
