@@ -22,6 +22,15 @@
  *   static constr_type_init(l,u,type)  src/qp.cpp:283-294          sqph_constr_type_init (host utility)
  *   legacy sparse QP<n,m> (Eigen::SparseMatrix A), setup/update_qp/solve
  *                                 include/unsupported/qp_solver.hpp:17-32,215-330   sqph_*_csr (sqph_csr_batch: dense P, CSR A)
+ *   non-const x / y / z accessors (warm starts)  qp.hpp:160-164    sqph_set_state
+ *   the SOC re-solve: same P, A, new bounds      src/sqp.cpp:244-276 (TODO :273)   sqph_setup_solve_reuse
+ *   settings.verbose / print_status              src/qp.cpp:72-76,113-117,373-383  sqph_set_trace_qp / sqph_get_trace
+ *   one solver object per problem, spread over threads (and devices) by the caller
+ *                                 qp.hpp:217-247                   sqph_device_count / sqph_shard_bounds / sqph_own_stream /
+ *                                                                  sqph_gather_create, _post, _fetch, _device_ptrs, _destroy
+ *
+ * The reference's callers are served source-compatibly by include/sqp_hip/compat/ (solvers/qp.hpp, unsupported/qp_solver.hpp,
+ * solvers/sqp.hpp, solvers/bfgs.hpp): its own test files compile unchanged against that tree.
  *
  * Conventions
  *   - plain pointers and sizes only; no C++/torch types.  dtype selects Scalar.
