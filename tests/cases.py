@@ -391,6 +391,91 @@ def soc_factor_reuse(make, n=8, m=12, batch=6, **kw):
             assert relerr(x, xo) < TOL_F64 and relerr1(y, yo) < TOL_F64
 
 
+def api_sequence_fuzz(make, n, m, batch, seed, steps=12, adaptive_ok=True, **kw):
+    """A random sequence of the stateful calls (setup / update_qp / solve / setup_solve / setup_solve_reuse / set_state) with
+    settings flipped in between — check_termination 0 <-> 7 and verbose on/off move the dispatch between kernel families, so a
+    solve() regularly finds a factor another family built (or none: fused calls keep none by default).  After every call that
+    solves, the batch is compared with one oracle instance per QP driven through the same sequence."""
+    rng = np.random.default_rng(seed)
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=seed)
+    s = make(n, m, batch, keep_factor=bool(rng.integers(2)), **kw)
+    orc = [oracle.QPSolver() for _ in range(batch)]
+    st = s.settings
+    st.max_iter, st.check_termination = 30, 0
+    cur = dict(P=P, q=q, l=l, u=u)
+    have_setup = False
+    log = []
+    kernels = set()
+
+    def push_settings():
+        for o in orc:
+            os_ = o.settings
+            for f in ("max_iter", "check_termination", "warm_start", "adaptive_rho", "adaptive_rho_interval", "alpha", "rho"):
+                setattr(os_, f, getattr(st, f))
+
+    def perturbed():
+        return cur["q"] + 0.1 * rng.standard_normal(q.shape), cur["l"] - 0.05 * rng.random(l.shape), cur["u"] + 0.05 * rng.random(u.shape)
+
+    def compare(tag):
+        x, y, z, info = s.solution()
+        if hasattr(s, "kernel_name"):
+            kernels.add(s.kernel_name())
+        for b, o in enumerate(orc):
+            assert info.status[b] == o.info.status and info.iter[b] == o.info.iter and info.rho_updates[b] == o.info.rho_updates, (log, tag, b)
+            xo, yo, zo = o.primal_solution(), o.dual_solution(), o.z()
+            assert relerr(x[b][None], xo[None]) < TOL_F64 and relerr1(y[b][None], yo[None]) < TOL_F64 and relerr1(z[b][None], zo[None]) < TOL_F64, (log, tag, b)
+
+    ops = ["setup", "update", "solve", "solve", "setup_solve", "reuse", "set_state", "flip_check", "flip_verbose", "flip_warm", "flip_adaptive", "flip_iters"]
+    for k in range(steps):
+        op = "setup_solve" if k == 0 else ops[int(rng.integers(len(ops)))]
+        if op in ("update", "solve", "reuse", "set_state") and not have_setup:
+            op = "setup"
+        log.append(op)
+        push_settings()
+        if op == "setup":
+            s.setup(cur["P"], cur["q"], A, cur["l"], cur["u"])
+            for b, o in enumerate(orc):
+                o.setup(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+            have_setup = True
+        elif op == "update":  # new P (still SPD) and q, same A
+            G = 0.05 * rng.standard_normal(P.shape)
+            cur["P"] = cur["P"] + G @ np.transpose(G, (0, 2, 1))
+            cur["q"] = perturbed()[0]
+            s.update_qp(cur["P"], cur["q"], A, cur["l"], cur["u"])
+            for b, o in enumerate(orc):
+                o.update_qp(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+        elif op == "solve":
+            cur["q"], cur["l"], cur["u"] = perturbed()
+            s.solve(cur["P"], cur["q"], A, cur["l"], cur["u"])
+            for b, o in enumerate(orc):
+                o.solve(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+            compare(k)
+        elif op in ("setup_solve", "reuse"):
+            cur["q"], cur["l"], cur["u"] = perturbed()
+            (s.setup_solve if op == "setup_solve" else s.setup_solve_reuse)(cur["P"], cur["q"], A, cur["l"], cur["u"])
+            for b, o in enumerate(orc):
+                o.setup(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+                o.solve(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+            have_setup = True
+            compare(k)
+        elif op == "set_state":
+            x0, z0, y0 = rng.standard_normal((batch, n)), rng.standard_normal((batch, m)), rng.standard_normal((batch, m))
+            s.set_state(x0, z0, y0)
+            for b, o in enumerate(orc):
+                o.set_state(x0[b], z0[b], y0[b])
+        elif op == "flip_check":
+            st.check_termination = 0 if st.check_termination else 7
+        elif op == "flip_verbose":
+            st.verbose = 0 if st.verbose else 1  # device side only: routes to the recording kernels
+        elif op == "flip_warm":
+            st.warm_start = 0 if st.warm_start else 1
+        elif op == "flip_adaptive" and adaptive_ok:
+            st.adaptive_rho, st.adaptive_rho_interval = (0, 0) if st.adaptive_rho else (1, 9)
+        elif op == "flip_iters":
+            st.max_iter = 45 if st.max_iter == 30 else 30
+    return log, kernels
+
+
 def set_state_warm_start(make, n=6, m=9, batch=3, **kw):
     P, q, A, l, u = random_qp_batch(batch, n, m, seed=9)
     rng = np.random.default_rng(0)

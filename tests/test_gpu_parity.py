@@ -481,3 +481,16 @@ def test_hip_graph_capture_of_the_fused_call():
             assert np.array_equal(xg, xd) and np.array_equal(yg, yd)
             assert not np.array_equal(xg, x0)
     assert s.kernel_name() == "wg2_16x8_7x7_w2"
+
+
+@pytest.mark.parametrize("n,m,batch,adaptive_ok", [(2, 3, 5, False), (8, 12, 4, True), (20, 40, 3, True), (50, 100, 2, True)])
+def test_api_sequence_fuzz(n, m, batch, adaptive_ok):
+    """random call sequences with dispatch-changing settings in between, against per-QP oracle instances"""
+    seen = set()
+    for seed in range(1, 9):
+        log, kernels = cases.api_sequence_fuzz(make_gpu, n, m, batch, seed=100 * n + seed, adaptive_ok=adaptive_ok)
+        seen |= kernels
+    print(n, m, sorted(seen))
+    # the sequences did cross kernel families (verbose -> recording kernels, check_termination -> g32 / wg); the one-QP-per-lane
+    # kernel records traces itself and serves every setting
+    assert len(seen) >= (1 if n <= 4 else 2), seen
