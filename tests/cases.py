@@ -402,7 +402,7 @@ def api_sequence_fuzz(make, n, m, batch, seed, steps=12, adaptive_ok=True, **kw)
     orc = [oracle.QPSolver() for _ in range(batch)]
     st = s.settings
     st.max_iter, st.check_termination = 30, 0
-    cur = dict(P=P, q=q, l=l, u=u)
+    cur = dict(P=P, q=q, l=l, u=u, A=A)
     have_setup = False
     log = []
     kernels = set()
@@ -433,29 +433,30 @@ def api_sequence_fuzz(make, n, m, batch, seed, steps=12, adaptive_ok=True, **kw)
         log.append(op)
         push_settings()
         if op == "setup":
-            s.setup(cur["P"], cur["q"], A, cur["l"], cur["u"])
+            s.setup(cur["P"], cur["q"], cur["A"], cur["l"], cur["u"])
             for b, o in enumerate(orc):
-                o.setup(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+                o.setup(cur["P"][b], cur["q"][b], cur["A"][b], cur["l"][b], cur["u"][b])
             have_setup = True
-        elif op == "update":  # new P (still SPD) and q, same A
+        elif op == "update":  # new P (still SPD), q and values of A (same sparsity), qp.cpp:46-62
             G = 0.05 * rng.standard_normal(P.shape)
             cur["P"] = cur["P"] + G @ np.transpose(G, (0, 2, 1))
+            cur["A"] = cur["A"] * (1.0 + 0.05 * rng.standard_normal(A.shape))
             cur["q"] = perturbed()[0]
-            s.update_qp(cur["P"], cur["q"], A, cur["l"], cur["u"])
+            s.update_qp(cur["P"], cur["q"], cur["A"], cur["l"], cur["u"])
             for b, o in enumerate(orc):
-                o.update_qp(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+                o.update_qp(cur["P"][b], cur["q"][b], cur["A"][b], cur["l"][b], cur["u"][b])
         elif op == "solve":
             cur["q"], cur["l"], cur["u"] = perturbed()
-            s.solve(cur["P"], cur["q"], A, cur["l"], cur["u"])
+            s.solve(cur["P"], cur["q"], cur["A"], cur["l"], cur["u"])
             for b, o in enumerate(orc):
-                o.solve(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+                o.solve(cur["P"][b], cur["q"][b], cur["A"][b], cur["l"][b], cur["u"][b])
             compare(k)
         elif op in ("setup_solve", "reuse"):
             cur["q"], cur["l"], cur["u"] = perturbed()
-            (s.setup_solve if op == "setup_solve" else s.setup_solve_reuse)(cur["P"], cur["q"], A, cur["l"], cur["u"])
+            (s.setup_solve if op == "setup_solve" else s.setup_solve_reuse)(cur["P"], cur["q"], cur["A"], cur["l"], cur["u"])
             for b, o in enumerate(orc):
-                o.setup(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
-                o.solve(cur["P"][b], cur["q"][b], A[b], cur["l"][b], cur["u"][b])
+                o.setup(cur["P"][b], cur["q"][b], cur["A"][b], cur["l"][b], cur["u"][b])
+                o.solve(cur["P"][b], cur["q"][b], cur["A"][b], cur["l"][b], cur["u"][b])
             have_setup = True
             compare(k)
         elif op == "set_state":

@@ -494,3 +494,47 @@ def test_api_sequence_fuzz(n, m, batch, adaptive_ok):
     # the sequences did cross kernel families (verbose -> recording kernels, check_termination -> g32 / wg); the one-QP-per-lane
     # kernel records traces itself and serves every setting
     assert len(seen) >= (1 if n <= 4 else 2), seen
+
+
+class _CsrFacade:
+    """the dense-signature calls of cases.api_sequence_fuzz on the CSR entry points (A converted once per call)"""
+
+    def __init__(self, s):
+        self._s = s
+        self.settings = s.settings
+
+    def _csr(self, fn, P, q, A, l, u):
+        rp, ci, v = cases.dense_to_csr(A)
+        fn(P, q, rp, ci, v, l, u)
+
+    def setup(self, *a): self._csr(self._s.setup_csr, *a)
+    def update_qp(self, *a): self._csr(self._s.update_qp_csr, *a)
+    def solve(self, *a): self._csr(self._s.solve_csr, *a)
+    def setup_solve(self, *a): self._csr(self._s.setup_solve_csr, *a)
+    def setup_solve_reuse(self, *a): self._csr(self._s.setup_solve_csr, *a)  # no CSR variant of the reuse call: a plain fused call
+    def set_state(self, *a): self._s.set_state(*a)
+    def solution(self): return self._s.solution()
+    def kernel_name(self): return self._s.kernel_name()
+
+
+@pytest.mark.parametrize("n,m,batch", [(2, 3, 4), (20, 40, 3), (70, 150, 2)])
+def test_api_sequence_fuzz_csr(n, m, batch):
+    """the same random call sequences through the sparse entry points (native sparse kernel where the shape calls for it,
+    expand + dense kernels otherwise)"""
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    seen = set()
+    for seed in range(1, 5):
+        def make(n_, m_, b_, **kw):
+            return _CsrFacade(make_gpu(n_, m_, b_, **kw))
+
+        # a sparse A: the generator of the dense cases gives the other arrays, A is thinned out
+        P, q, rp, ci, v, l, u, A = random_csr_qp_batch(batch, n, m, density=0.3 if n < 50 else 0.06, seed=seed)
+        orig = cases.random_qp_batch
+        cases.random_qp_batch = lambda b_, n_, m_, seed=0, **kw: (P, q, A, l, u)
+        try:
+            log, kernels = cases.api_sequence_fuzz(make, n, m, batch, seed=7 * n + seed)
+        finally:
+            cases.random_qp_batch = orig
+        seen |= kernels
+    print(n, m, sorted(seen))
