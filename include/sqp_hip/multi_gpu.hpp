@@ -30,20 +30,17 @@ class MultiGpuBatchQPSolver {
         : n_(n), m_(m), batch_(batch), root_(root) {
         int G = num_devices > 0 ? num_devices : sqph_device_count();
         if (G <= 0) throw std::runtime_error("MultiGpuBatchQPSolver: no HIP device visible (this library has no CPU path)");
-        if (G > batch) G = (int)batch;
-        for (int g = 0; g < G; g++) {
-            long long lo, hi;
-            sqph_shard_bounds(batch, G, g, &lo, &hi);
-            lo_.push_back(lo);
-            hi_.push_back(hi);
-            parts_.emplace_back(new Single(n, m, (int)(hi - lo), g, flags));
-            detail::check(sqph_own_stream(parts_.back()->handle()), parts_.back()->handle(), "sqph_own_stream");
-        }
-        detail::check(sqph_gather_create(&gather_, root, n, m, batch), nullptr, "sqph_gather_create");
-        x_.resize((size_t)batch * n);
-        y_.resize((size_t)batch * (m > 0 ? m : 1));
-        raw_.resize((size_t)batch);
-        info_.resize((size_t)batch);
+        std::vector<int> devices;
+        for (int g = 0; g < G; g++) devices.push_back(g);
+        init(devices, flags);
+    }
+    // Explicit placement: shard g of the contiguous split lives on devices[g].  A device may be listed more than once — several
+    // shards per GPU, each with its own handle and stream (their host-to-device copies and kernels overlap; it is also how the
+    // sharding and gather logic is exercised on a one-GPU machine).
+    MultiGpuBatchQPSolver(int n, int m, long long batch, const std::vector<int> &devices, int flags = 0, int root = 0)
+        : n_(n), m_(m), batch_(batch), root_(root) {
+        if (devices.empty()) throw std::runtime_error("MultiGpuBatchQPSolver: empty device list");
+        init(devices, flags);
     }
     ~MultiGpuBatchQPSolver() {
         sqph_gather_destroy(gather_);
@@ -84,6 +81,23 @@ class MultiGpuBatchQPSolver {
     void gathered_device(void **x, void **y, sqph_info **info) { detail::check(sqph_gather_device_ptrs(gather_, x, y, info), nullptr, "sqph_gather_device_ptrs"); }
 
    private:
+    void init(std::vector<int> devices, int flags) {
+        if ((long long)devices.size() > batch_) devices.resize((size_t)batch_);
+        const int G = (int)devices.size();
+        for (int g = 0; g < G; g++) {
+            long long lo, hi;
+            sqph_shard_bounds(batch_, G, g, &lo, &hi);
+            lo_.push_back(lo);
+            hi_.push_back(hi);
+            parts_.emplace_back(new Single(n_, m_, (int)(hi - lo), devices[(size_t)g], flags));
+            detail::check(sqph_own_stream(parts_.back()->handle()), parts_.back()->handle(), "sqph_own_stream");
+        }
+        detail::check(sqph_gather_create(&gather_, root_, n_, m_, batch_), nullptr, "sqph_gather_create");
+        x_.resize((size_t)batch_ * n_);
+        y_.resize((size_t)batch_ * (m_ > 0 ? m_ : 1));
+        raw_.resize((size_t)batch_);
+        info_.resize((size_t)batch_);
+    }
     void post(int g) {
         detail::check(sqph_gather_post(gather_, parts_[g]->handle(), lo_[g], (int)(hi_[g] - lo_[g])), parts_[g]->handle(), "sqph_gather_post");
     }

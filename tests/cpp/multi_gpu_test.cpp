@@ -68,8 +68,22 @@ static void sharded_vs_single(int n, int m, int B) {
     single.settings().check_termination = 0;
     single.setup_solve(single.packed(B, P.data(), q.data(), A.data(), l.data(), u.data()));
     const int ndev = sqph_device_count();
+    // every device count available, then shard counts beyond it placed round-robin (several shards per GPU: the G > 1 split,
+    // per-shard streams and the gather offsets run even where one GPU is all there is)
+    std::vector<std::vector<int>> placements;
     for (int G = 1; G <= ndev; G++) {
-        MultiGpuBatchQPSolver<double> multi(n, m, B, G);
+        std::vector<int> d;
+        for (int g = 0; g < G; g++) d.push_back(g);
+        placements.push_back(d);
+    }
+    for (int G : {2, 3, 5, 8}) {
+        std::vector<int> d;
+        for (int g = 0; g < G; g++) d.push_back(g % ndev);
+        placements.push_back(d);
+    }
+    for (const auto &devices : placements) {
+        MultiGpuBatchQPSolver<double> multi(n, m, B, devices);
+        const int G = (int)devices.size();
         CHECK(multi.num_devices() == (G < B ? G : B));
         multi.settings() = single.settings();
         multi.setup_solve(multi.packed(P.data(), q.data(), A.data(), l.data(), u.data()));
@@ -82,7 +96,13 @@ static void sharded_vs_single(int n, int m, int B) {
         sqph_info *di = nullptr;
         multi.gathered_device(&dx, &dy, &di);
         CHECK(dx && dy && di);
-        printf("multi-GPU n=%d m=%d batch=%d over %d device(s): gathered records bit-identical to the single-device solve\n", n, m, B, multi.num_devices());
+        // a second call on the same object (solve() on the resident factors of every shard) gathers again
+        multi.solve(multi.packed(P.data(), q.data(), A.data(), l.data(), u.data()));
+        single.solve(single.packed(B, P.data(), q.data(), A.data(), l.data(), u.data()));
+        for (int b = 0; b < B; b++) CHECK(!std::memcmp(multi.primal_solution(b), single.primal_solution(b), sizeof(double) * n));
+        single.setup_solve(single.packed(B, P.data(), q.data(), A.data(), l.data(), u.data()));
+        printf("multi-GPU n=%d m=%d batch=%d over %d shard(s) on %d device(s): gathered records bit-identical to the single-device solve\n", n, m, B,
+               multi.num_devices(), ndev < G ? ndev : G);
     }
 }
 
