@@ -106,7 +106,38 @@ static void sharded_vs_single(int n, int m, int B) {
     }
 }
 
+// host-memspace round trip of a C3-shaped batch (PCIe-inclusive): one handle against several shards on the same GPU, whose
+// host-to-device copies (one host thread each) overlap each other and the kernels of the shards already on the device
+#include <chrono>
+static void pcie_shards(int n, int m, int B) {
+    std::vector<double> P((size_t)B * n * n, 0.0), q((size_t)B * n), A((size_t)B * m * n), l((size_t)B * m), u((size_t)B * m);
+    Lcg g{99};
+    for (int b = 0; b < B; b++) {
+        for (int i = 0; i < n; i++) P[(size_t)b * n * n + (size_t)i * n + i] = 1.0 + g.uni();
+        for (int j = 0; j < n; j++) q[(size_t)b * n + j] = g.uni() - 0.5;
+        for (int e = 0; e < m * n; e++) A[(size_t)b * m * n + e] = g.uni() - 0.5;
+        for (int i = 0; i < m; i++) { l[(size_t)b * m + i] = -g.uni(); u[(size_t)b * m + i] = g.uni(); }
+    }
+    for (int G : {1, 2, 4, 8}) {
+        std::vector<int> d((size_t)G, 0);
+        MultiGpuBatchQPSolver<double> multi(n, m, B, d);
+        multi.settings().max_iter = 200;
+        multi.settings().check_termination = 0;
+        auto b = multi.packed(P.data(), q.data(), A.data(), l.data(), u.data());
+        for (int w = 0; w < 2; w++) { multi.setup_solve(b); (void)multi.primal_solution(0); }
+        const int K = 5;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < K; k++) { multi.setup_solve(b); (void)multi.primal_solution(0); }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / K;
+        printf("pcie n=%d m=%d batch=%d host-memspace round trip, %d shard(s) on one GPU: %.2f ms = %.3g QP/s\n", n, m, B, G, ms, B / (ms * 1e-3));
+    }
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "pcie")) {
+        pcie_shards(50, 100, 8192);
+        return 0;
+    }
     split_arithmetic();
     if (argc > 1 && !strcmp(argv[1], "split")) {
         printf("split arithmetic passed\n");
