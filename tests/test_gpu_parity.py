@@ -538,3 +538,13 @@ def test_api_sequence_fuzz_csr(n, m, batch):
             cases.random_qp_batch = orig
         seen |= kernels
     print(n, m, sorted(seen))
+
+
+@pytest.mark.parametrize("n,m", [(4, 4), (8, 12), (12, 24), (16, 24), (24, 40), (32, 64), (56, 112), (64, 128), (112, 208), (113, 209)])
+def test_api_sequence_fuzz_at_kernel_shape_limits(n, m):
+    """the largest (n, m) each compiled kernel shape takes (and one beyond the last: the fallback), through the random call sequences"""
+    seen = set()
+    for seed in (1, 2):
+        log, kernels = cases.api_sequence_fuzz(make_gpu, n, m, 2, seed=1000 + 10 * n + seed, steps=8, adaptive_ok=n > 4)
+        seen |= kernels
+    print(n, m, sorted(seen))
