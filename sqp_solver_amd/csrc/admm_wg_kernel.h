@@ -118,10 +118,11 @@ struct WgLayout {
     static constexpr int STAGE_Y = mx(NR, MP) * Cp;
     // set-up scratch, aliasing the staging areas:  rho[MP] | rowbuf[NP+2] | sj[NP] | As[R][SSTR] | Wl[NP][SSTR]
     // As = one block of R rows of A, Wl = W transposed (Wl[j][slot(i')] = W[i'][j]); column groups are
-    // padded to 8 (slot(j) = 8*(j/TC) + j%TC) so a lane's TC consecutive columns are one aligned 64-B read.
+    // padded to SLOT = 8 (4 when TC <= 4) entries (slot(j) = SLOT*(j/TC) + j%TC) so a lane's TC consecutive columns are one aligned read.
     // (the set-up scratch starts at offset 0: no vector is live in LDS while a factor is being built)
-    static constexpr int SSTR = 8 * C + 2;  // As row stride (padded: the R rows are written by different lanes)
-    static constexpr int WSTR = 8 * C;      // Wl row stride
+    static constexpr int SLOT = TC <= 4 ? 4 : 8;
+    static constexpr int SSTR = SLOT * C + 2;  // As row stride (padded: the R rows are written by different lanes)
+    static constexpr int WSTR = SLOT * C;      // Wl row stride
     static constexpr int O_RHO = 0;
     static constexpr int O_ROWBUF = O_RHO + MP;
     static constexpr int O_SJ = O_ROWBUF + NP + 2;
@@ -143,7 +144,7 @@ struct WgLayout {
     static constexpr int O_RINV = O_UPV + MP;  // 1/rho of the owned constraint (changes only at a refactorisation)
     static constexpr int TOTAL = ev(O_RINV + MP);
     static_assert(O_AS2 + R * SSTR <= O_QV, "build_B stages all of W and a block of A rows in [0, O_QV)");
-    static constexpr int slot(int j) { return 8 * (j / TC) + (j % TC); }
+    static constexpr int slot(int j) { return SLOT * (j / TC) + (j % TC); }
 };
 
 template <typename TIN, int NW, int R, int C, int TR, int TC, int TW>
@@ -354,7 +355,7 @@ struct WgKernel {
         for (int s = 0; s < TR; s++) {
             wsync();
 #pragma unroll
-            for (int k = 0; k < TC; k++) As[r * L::SSTR + 8 * c + k] = at[s][k];
+            for (int k = 0; k < TC; k++) As[r * L::SSTR + L::SLOT * c + k] = at[s][k];
             wsync();
             T acc[TC];
 #pragma unroll
@@ -362,13 +363,13 @@ struct WgKernel {
             // W[TC c + k][j] = 0 for j > TC c + k: column groups beyond my own contribute nothing
 #pragma unroll 1
             for (int cj = 0; cj <= c; cj++) {
-                T av[8];
-                wg_read<8>(As + r * L::SSTR + 8 * cj, av);
+                T av[L::SLOT];
+                wg_read<L::SLOT>(As + r * L::SSTR + L::SLOT * cj, av);
 #pragma unroll
                 for (int kj = 0; kj < TC; kj++) {
                     if (TC * cj + kj >= n) break;
-                    T wv[8];
-                    wg_read<8>(Wf + (TC * cj + kj) * L::WSTR + 8 * c, wv);
+                    T wv[L::SLOT];
+                    wg_read<L::SLOT>(Wf + (TC * cj + kj) * L::WSTR + L::SLOT * c, wv);
 #pragma unroll
                     for (int k = 0; k < TC; k++) acc[k] = wg_fma(av[kj], wv[k], acc[k]);
                 }
@@ -387,8 +388,8 @@ struct WgKernel {
 #pragma unroll
         for (int u = 0; u < TW; u++) {
             const int jp = R * u + r;
-            T tmp[8];
-            wg_read<8>(lds + (jp < L::NP ? jp : 0) * L::WSTR + 8 * c, tmp);
+            T tmp[L::SLOT];
+            wg_read<L::SLOT>(lds + (jp < L::NP ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
 #pragma unroll
             for (int k = 0; k < TC; k++) vt[u][k] = (jp < n && TC * c + k < n) ? tmp[k] : T(0);
         }
@@ -514,7 +515,7 @@ struct WgKernel {
         for (int s = 0; s < TR; s++) {
             wsync();
 #pragma unroll
-            for (int k = 0; k < TC; k++) As[r * L::SSTR + 8 * c + k] = at[s][k];
+            for (int k = 0; k < TC; k++) As[r * L::SSTR + L::SLOT * c + k] = at[s][k];
             wsync();
 #pragma unroll 2
             for (int il = 0; il < R; il++) {
@@ -522,8 +523,8 @@ struct WgKernel {
                 if (i >= m) break;
                 const T ri = rho_l[i];
                 const T *row = As + il * L::SSTR;
-                T a2[8], a1[TW];
-                wg_read<8>(row + 8 * c, a2);
+                T a2[L::SLOT], a1[TW];
+                wg_read<L::SLOT>(row + L::SLOT * c, a2);
 #pragma unroll
                 for (int u = 0; u < TW; u++) a1[u] = row[sl[u]] * ri;
 #pragma unroll
