@@ -1414,7 +1414,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
     WgKernel<TIN, NW, R, C, TR, TC, TW>::run(a, lds);
 }
 
-// shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins
+// shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins.  The 32 x 8 grids are for
+// problems with many more constraints than variables (m <= 224 with n <= 16 / 32 / 56): measured 4,096 x (10,150) 1.43 ms against
+// 7.73 ms in the 16 x 16 / 13 x 7 shape it fell into before, 4,096 x (50,150) 2.94 against 8.68 ms
 // (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
 #ifdef SQPH_SLIM
 #define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
@@ -1428,6 +1430,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
     X(1, 8, 8, 8, 4, 4, 2)       \
     X(2, 16, 8, 7, 7, 4, 2)      \
     X(4, 16, 16, 8, 4, 4, 2)     \
+    X(4, 32, 8, 7, 2, 1, 4)      \
+    X(4, 32, 8, 7, 4, 1, 3)      \
+    X(4, 32, 8, 7, 7, 2, 2)      \
     X(4, 16, 16, 13, 7, 7, 1)
 
 // four QPs per wavefront (run_group): block = one wavefront, LDS = 4 slices

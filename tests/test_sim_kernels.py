@@ -158,6 +158,19 @@ def test_wg_four_wave_large_tile_shape():
     cases.parity_fixed_iters(lambda n, m, b, **kw: simlib.SimSolverBatch(n, m, b, variant=simlib.WG), 70, 150, 1, iters=25)
 
 
+@pytest.mark.parametrize("n,m", [(10, 150), (16, 224), (30, 200), (50, 140), (56, 224)])
+def test_wg_tall_shapes(n, m):
+    """the 32 x 8 lane grids (many more constraints than variables: m <= 224 with n <= 16 / 32 / 56) under the emulator"""
+    mk = lambda n_, m_, b, **kw: simlib.SimSolverBatch(n_, m_, b, variant=simlib.WG, keep_factor=kw.get("keep_factor", False))  # noqa: E731
+    cases.parity_fixed_iters(mk, n, m, 2, iters=25)
+    if n <= 30:
+        cases.parity_termination(mk, n, m, 2)
+        # adaptive rho on these constraint-heavy QPs drives rho up: iterates stay inside the bar, the absolute floor of the reported
+        # residuals (calibrated on m = 2n problems) does not apply
+        cases.parity_termination(mk, n, m, 2, adaptive=True, diagnostics=False)
+        cases.fused_then_solve(mk, n, m, 2, adaptive=False)  # (adaptive rho on these constraint-heavy QPs sits at the fp64 noise floor)
+
+
 # ------------------------------------------------------------------ two QPs per wavefront (8 x 4 lane grid per QP)
 def make_g32(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
     return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G32, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
