@@ -88,6 +88,15 @@ class SQP {
 
     explicit SQP(int device = 0) : device_(device) {
         info_.iter = 0; info_.qp_solver_iter = 0; info_.status = MAX_ITER_EXCEEDED;
+        // TODO(mi) of the reference: "Performance strongly depends on QP solver settings" — its constructor's values, src/sqp.cpp:15-23
+        qp_settings_.warm_start = true;
+        qp_settings_.check_termination = 10;
+        qp_settings_.eps_abs = 1e-4;
+        qp_settings_.eps_rel = 1e-4;
+        qp_settings_.max_iter = 100;
+        qp_settings_.adaptive_rho = true;
+        qp_settings_.adaptive_rho_interval = 50;
+        qp_settings_.alpha = 1.6;
     }
     ~SQP() = default;
 
@@ -110,8 +119,9 @@ class SQP {
     inline Settings &settings() { return settings_; }
     inline const Info &info() const { return info_; }
     inline Info &info() { return info_; }
-    // the QP settings the reference's constructor sets on its qp_solver_ member (src/sqp.cpp:15-23); valid after the first solve()
-    qp_solver::QPSolverSettings<Scalar> &qp_settings() { return driver().qp_settings(); }
+    // the settings of the QP subproblem solver (the reference exposes them as qp_solver_.settings() of its public member); they
+    // take effect at the next solve()
+    qp_solver::QPSolverSettings<Scalar> &qp_settings() { return qp_settings_; }
 
     // Solver state variables (public in the reference: "// private:" is commented out, sqp.hpp:104; the iteration callback reads them)
     Vector x_;
@@ -128,6 +138,7 @@ class SQP {
         ds.tau = settings_.tau; ds.eta = settings_.eta; ds.rho = settings_.rho; ds.eps_prim = settings_.eps_prim;
         ds.eps_dual = settings_.eps_dual; ds.max_iter = settings_.max_iter; ds.line_search_max_iter = settings_.line_search_max_iter;
         ds.second_order_correction = settings_.second_order_correction;
+        drv_->qp_settings() = qp_settings_;
         Adaptor ad(prob);
         std::vector<raw::NonLinearProblem<Scalar> *> probs(1, &ad);
         info_.qp_solver_iter = 0;
@@ -181,14 +192,11 @@ class SQP {
         self->info_.iter = iter;
         self->settings_.iteration_callback(*self);
     }
-    raw::BatchSQP<Scalar> &driver() {
-        if (!drv_) throw std::runtime_error("sqp::SQP: qp_settings() before the first solve()");
-        return *drv_;
-    }
     int device_;
     int n_ = -1, m_ = -1;
     std::unique_ptr<raw::BatchSQP<Scalar>> drv_;
     Settings settings_;
+    qp_solver::QPSolverSettings<Scalar> qp_settings_;
     Info info_;
 };
 
