@@ -158,9 +158,10 @@ def test_wg_four_wave_large_tile_shape():
     cases.parity_fixed_iters(lambda n, m, b, **kw: simlib.SimSolverBatch(n, m, b, variant=simlib.WG), 70, 150, 1, iters=25)
 
 
-@pytest.mark.parametrize("n,m", [(10, 150), (16, 224), (30, 200), (50, 140), (56, 224)])
+@pytest.mark.parametrize("n,m", [(10, 150), (16, 224), (30, 200), (50, 140), (56, 224), (20, 400), (32, 448), (50, 300)])
 def test_wg_tall_shapes(n, m):
-    """the 32 x 8 lane grids (many more constraints than variables: m <= 224 with n <= 16 / 32 / 56) under the emulator"""
+    """the 32 x 8 and 64 x 8 lane grids (many more constraints than variables: m <= 224 with n <= 16 / 32 / 56, m <= 448 with
+    n <= 32 / 56) under the emulator"""
     mk = lambda n_, m_, b, **kw: simlib.SimSolverBatch(n_, m_, b, variant=simlib.WG, keep_factor=kw.get("keep_factor", False))  # noqa: E731
     cases.parity_fixed_iters(mk, n, m, 2, iters=25)
     if n <= 30:
