@@ -659,14 +659,17 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         a.mode = mode_in;
         a.mode = for_family('g');
         const int big = s->n > s->m ? s->n : s->m;
-        const int nt = big <= 128 ? 64 : 256;
+        static const int nt_env = getenv("SQPH_GENERIC_NT") ? atoi(getenv("SQPH_GENERIC_NT")) : 0;  // experiments only
+        // 4 waves were 8 waves per CU at these sizes (LDS): too few loads in flight to stream the matrices — measured 1.2-2.9x with 8 / 16
+        int nt = nt_env > 0 ? nt_env : (big <= 128 ? 64 : ((long long)s->n * s->m >= 20000 ? 1024 : 512));
+        while (nt > 256 && generic_lds_elems<T>(s->n, s->m, nt) * sizeof(T) > 160 * 1024) nt /= 2;  // the per-thread scratch must leave room for the vectors
         const size_t lds = generic_lds_elems<T>(s->n, s->m, nt) * sizeof(T);
         if (lds > 160 * 1024) SQPH_FAIL(s, SQPH_ERR_UNSUPPORTED, "n=%d m=%d needs %zu B of LDS (>160 KiB)", s->n, s->m, lds);
         if (lds > 64 * 1024)
             SQPH_HIP(s, hipFuncSetAttribute((const void *)admm_generic_kernel<T, TIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((admm_generic_kernel<T, TIN>), dim3(qp->batch), dim3(nt), lds, s->stream, a);
         SQPH_HIP(s, hipGetLastError());
-        s->kernel_name = nt == 64 ? "generic_w1" : "generic_w4";
+        s->kernel_name = nt == 64 ? "generic_w1" : nt == 256 ? "generic_w4" : nt == 512 ? "generic_w8" : "generic_w16";
         launched_by('g', a.mode);
     }
     if (s->timing) {

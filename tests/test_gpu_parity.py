@@ -46,7 +46,8 @@ def test_reference_cases(case, make):
 
 
 @pytest.mark.parametrize("make", MAKERS, ids=IDS)
-@pytest.mark.parametrize("n,m,batch,iters", [(2, 3, 7, 200), (20, 40, 128, 200), (50, 100, 64, 200), (13, 57, 16, 100), (56, 104, 8, 50), (64, 30, 8, 50)])
+@pytest.mark.parametrize("n,m,batch,iters", [(2, 3, 7, 200), (20, 40, 128, 200), (50, 100, 64, 200), (13, 57, 16, 100), (56, 104, 8, 50), (64, 30, 8, 50),
+                                             (60, 250, 3, 40), (120, 250, 3, 40)])  # the last two: the generic kernel with 8 / 16 waves per QP
 def test_parity_fixed_iters(n, m, batch, iters, make):
     cases.parity_fixed_iters(make, n, m, batch, iters=iters)
 
