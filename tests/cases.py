@@ -423,7 +423,9 @@ def api_sequence_fuzz(make, n, m, batch, seed, steps=12, adaptive_ok=True, **kw)
         for b, o in enumerate(orc):
             assert info.status[b] == o.info.status and info.iter[b] == o.info.iter and info.rho_updates[b] == o.info.rho_updates, (log, tag, b)
             xo, yo, zo = o.primal_solution(), o.dual_solution(), o.z()
-            assert relerr(x[b][None], xo[None]) < TOL_F64 and relerr1(y[b][None], yo[None]) < TOL_F64 and relerr1(z[b][None], zo[None]) < TOL_F64, (log, tag, b)
+            assert relerr(x[b][None], xo[None]) < TOL_F64, (log, tag, b)
+            if m > 0:
+                assert relerr1(y[b][None], yo[None]) < TOL_F64 and relerr1(z[b][None], zo[None]) < TOL_F64, (log, tag, b)
 
     ops = ["setup", "update", "solve", "solve", "setup_solve", "reuse", "set_state", "flip_check", "flip_verbose", "flip_warm", "flip_adaptive", "flip_iters"]
     for k in range(steps):
