@@ -1417,7 +1417,8 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
 // shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins.  The 32 x 8 grids are for
 // problems with many more constraints than variables (m <= 224 with n <= 16 / 32 / 56): measured 4,096 x (10,150) 1.43 ms against
 // 7.73 ms in the 16 x 16 / 13 x 7 shape it fell into before, 4,096 x (50,150) 2.94 against 8.68 ms; the 64 x 8 grids (8 waves) carry
-// m <= 448 with n <= 32 / 56: 2,048 x (50,400) 3.98 ms against 45.5 ms in the generic kernel
+// m <= 448 with n <= 32 / 56: 2,048 x (50,400) 3.98 ms against 45.5 ms in the generic kernel; the 16 x 16 grids with 2 / 4 / 8 tile rows
+// serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x)
 // (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
 #ifdef SQPH_SLIM
 #define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
@@ -1434,6 +1435,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_kernel(KArgs<double, TIN
     X(4, 32, 8, 7, 2, 1, 4)      \
     X(4, 32, 8, 7, 4, 1, 3)      \
     X(4, 32, 8, 7, 7, 2, 2)      \
+    X(4, 16, 16, 2, 7, 7, 2)     \
+    X(4, 16, 16, 4, 7, 7, 2)     \
+    X(4, 16, 16, 8, 7, 7, 2)     \
     X(4, 16, 16, 13, 7, 7, 1)    \
     X(8, 64, 8, 7, 4, 1, 2)      \
     X(8, 64, 8, 7, 7, 1, 2)

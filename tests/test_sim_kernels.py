@@ -158,6 +158,15 @@ def test_wg_four_wave_large_tile_shape():
     cases.parity_fixed_iters(lambda n, m, b, **kw: simlib.SimSolverBatch(n, m, b, variant=simlib.WG), 70, 150, 1, iters=25)
 
 
+@pytest.mark.parametrize("n,m", [(100, 20), (112, 32), (90, 60), (80, 120)])
+def test_wg_wide_shapes(n, m):
+    """56 < n <= 112 with few constraints: the 16 x 16 grids with 2 / 4 / 8 tile rows"""
+    mk = lambda n_, m_, b, **kw: simlib.SimSolverBatch(n_, m_, b, variant=simlib.WG, keep_factor=kw.get("keep_factor", False))  # noqa: E731
+    cases.parity_fixed_iters(mk, n, m, 1, iters=20)
+    if n <= 100:
+        cases.fused_then_solve(mk, n, m, 1, adaptive=False)
+
+
 @pytest.mark.parametrize("n,m", [(10, 150), (16, 224), (30, 200), (50, 140), (56, 224), (20, 400), (32, 448), (50, 300)])
 def test_wg_tall_shapes(n, m):
     """the 32 x 8 and 64 x 8 lane grids (many more constraints than variables: m <= 224 with n <= 16 / 32 / 56, m <= 448 with
