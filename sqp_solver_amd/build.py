@@ -31,10 +31,26 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB, os.path.join(CSRC, "capi.hip")]
+    # one object per translation unit (compiled concurrently), then one link
+    units = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    cflags = [f for f in FLAGS if f != "-shared"]
+    objs, procs = [], []
+    for u in units:
+        obj = os.path.join(LIBDIR, u[:-4] + ".o")
+        cmd = [HIPCC] + cflags + ["-c", "-o", obj, os.path.join(CSRC, u)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    for o in objs:
+        os.remove(o)
     return LIB
 
 

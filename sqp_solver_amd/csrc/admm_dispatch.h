@@ -63,12 +63,21 @@ inline int g32_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const
     return 0;
 }
 
+// the same shapes without the residual-check block, for calls that never check (wg_nocheck.hip: a translation unit of its own)
+template <typename TIN>
+int wg_nocheck_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name, int skip);
+extern template int wg_nocheck_try_launch<double>(const KArgs<double, double> &, hipStream_t, const char **, int);
+extern template int wg_nocheck_try_launch<float>(const KArgs<double, float> &, hipStream_t, const char **, int);
+
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>
 inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
     // SQPH_WG_SKIP=k (experiments only): skip the first k shapes that would fit
     static const int skip_env = getenv("SQPH_WG_SKIP") ? atoi(getenv("SQPH_WG_SKIP")) : 0;
+    static const bool always_checks = getenv("SQPH_WG_ALWAYS_CHECKS") != nullptr;  // experiments only
     int skip = skip_env;
+    if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0) && !always_checks)
+        return wg_nocheck_try_launch<TIN>(a, stream, name, skip);
 #define SQPH_WG_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                                            \
     if (a.m <= R_ * TR_ && a.n <= C_ * TC_ && skip-- <= 0) {                                                                    \
         hipLaunchKernelGGL((admm_wg_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \

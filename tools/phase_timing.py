@@ -6,7 +6,7 @@ from sqp_solver_amd import build as b
 if not os.environ.get("SQPH_LIB"):  # SQPH_LIB=<prebuilt -DSQPH_PHASE_TIMING library> (tools/slim_build.sh) skips the compile
     b.FLAGS.append("-DSQPH_PHASE_TIMING")
     b.LIB = b.LIB.replace("libsqp_hip.so", "libsqp_hip_timing.so")
-    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-o", b.LIB, os.path.join(b.CSRC, "capi.hip")])
+    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-o", b.LIB, os.path.join(b.CSRC, "capi.hip"), os.path.join(b.CSRC, "wg_nocheck.hip")])
 from sqp_solver_amd import QPSolverBatch
 from sqp_solver_amd.problems import random_qp_batch
 n, m, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

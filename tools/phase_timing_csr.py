@@ -8,7 +8,7 @@ if not os.environ.get("SQPH_LIB"):  # SQPH_LIB = a prebuilt -DSQPH_PHASE_TIMING 
     for f in os.environ.get("SQPH_EXTRA_FLAGS", "").split():
         b.FLAGS.append(f)
     b.LIB = b.LIB.replace("libsqp_hip.so", "libsqp_hip_timing.so")
-    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-o", b.LIB, os.path.join(b.CSRC, "capi.hip")])
+    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-o", b.LIB, os.path.join(b.CSRC, "capi.hip"), os.path.join(b.CSRC, "wg_nocheck.hip")])
 from sqp_solver_amd import QPSolverBatch
 from sqp_solver_amd.problems import random_csr_qp_batch
 n, m, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
