@@ -816,168 +816,180 @@ struct WgKernel {
 #else
 #define SQPH_TICK(k)
 #endif
-            for (; iter <= a.max_iter; iter++) {
-                __syncthreads();
-                SQPH_TICK(0)
-                {   // stage 1 partials:  B' w + W u, both reduced over r
-                    T w[TR], ur[TW];
-                    get_rowv(lds, r, w);
-                    get_wrow(lds, r, ur);
-                    stage1(bt, vt, w, ur, lds, r, c);
-                }
-                SQPH_TICK(1)
-                // y1 = W u + B' w: the R producers of a column group's TC outputs and their consumers in stage 2 are the
-                // same R lanes of one wavefront, so the reduction is wave-local — lane r < TC of group c sums output
-                // TC c + r and publishes it for its group; no workgroup barrier between the two stages
-                wave_sync();
-                SQPH_TICK(2)
-                if (r < TC) {
-                    const int j = TC * c + r;
-                    put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0));
-                }
-                SQPH_TICK(3)
-                wave_sync();
-                SQPH_TICK(4)
-                {   // stage 2 partials:  z~ = B y1  and  x~ = W' y1, both reduced over c
-                    T y1c[TC];
-                    get_colv2(lds, c, y1c);
-                    stage2(bt, vt, y1c, lds, r, c);
-                }
-                SQPH_TICK(5)
-                // the owner's constants do not depend on the partial sums: fetched before the barrier, their LDS latency
-                // hides behind it
-                T c_rinv = T(1), c_lo = T(0), c_up = T(0), c_q = T(0);
-                if (t < L::MP) {
-                    c_rinv = rinvv[t];
-                    c_lo = lov[t];
-                    c_up = upv[t];
-                }
-                if (t < L::NP) c_q = qv[t];
-                __syncthreads();
-                SQPH_TICK(6)
-                // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
-                // SIMDs are issue-bound at two waves each (a branch-free variant measured 14 % slower)
-                if (nown) x = alpha * reduce_xt(lds, t) + oma * x;
-                if (mown) {
-                    const T zt = reduce_over_c(lds, t);
-                    const T zr = alpha * zt + oma * z;
-                    T zn = zr + c_rinv * y;
-                    const T lo = c_lo, up = c_up;
-                    zn = zn < lo ? lo : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
-                    zn = zn > up ? up : zn;
-                    y = y + rho * (zr - zn);
-                    z = zn;
-                }
-
-                // iter % check_termination == 0  /  iter % adaptive_rho_interval == 0 as countdowns (an integer
-                // modulo by a run-time value costs ~20 SALU instructions on the critical path of every iteration)
-                bool check = false, adapt = false;
+            // Segments: the iterations up to the next residual check run in a tight loop that contains no check code (the allocator then
+            // keeps its spill code out of it); the check follows, between two segments.
+            while (iter <= a.max_iter) {
+                int seg = a.max_iter - iter + 1;
                 if constexpr (CHECKS) {
-                    if (--next_check == 0) {
+                    if (next_check > 0 && next_check < seg) seg = next_check;
+                    if (next_adapt > 0 && next_adapt < seg) seg = next_adapt;
+                }
+                for (int seg_i = 0; seg_i < seg; seg_i++) {
+                    __syncthreads();
+                    SQPH_TICK(0)
+                    {   // stage 1 partials:  B' w + W u, both reduced over r
+                        T w[TR], ur[TW];
+                        get_rowv(lds, r, w);
+                        get_wrow(lds, r, ur);
+                        stage1(bt, vt, w, ur, lds, r, c);
+                    }
+                    SQPH_TICK(1)
+                    // y1 = W u + B' w: the R producers of a column group's TC outputs and their consumers in stage 2 are the
+                    // same R lanes of one wavefront, so the reduction is wave-local — lane r < TC of group c sums output
+                    // TC c + r and publishes it for its group; no workgroup barrier between the two stages
+                    wave_sync();
+                    SQPH_TICK(2)
+                    if (r < TC) {
+                        const int j = TC * c + r;
+                        put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0));
+                    }
+                    SQPH_TICK(3)
+                    wave_sync();
+                    SQPH_TICK(4)
+                    {   // stage 2 partials:  z~ = B y1  and  x~ = W' y1, both reduced over c
+                        T y1c[TC];
+                        get_colv2(lds, c, y1c);
+                        stage2(bt, vt, y1c, lds, r, c);
+                    }
+                    SQPH_TICK(5)
+                    // the owner's constants do not depend on the partial sums: fetched before the barrier, their LDS latency
+                    // hides behind it
+                    T c_rinv = T(1), c_lo = T(0), c_up = T(0), c_q = T(0);
+                    if (t < L::MP) {
+                        c_rinv = rinvv[t];
+                        c_lo = lov[t];
+                        c_up = upv[t];
+                    }
+                    if (t < L::NP) c_q = qv[t];
+                    __syncthreads();
+                    SQPH_TICK(6)
+                    // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
+                    // SIMDs are issue-bound at two waves each (a branch-free variant measured 14 % slower)
+                    if (nown) x = alpha * reduce_xt(lds, t) + oma * x;
+                    if (mown) {
+                        const T zt = reduce_over_c(lds, t);
+                        const T zr = alpha * zt + oma * z;
+                        T zn = zr + c_rinv * y;
+                        const T lo = c_lo, up = c_up;
+                        zn = zn < lo ? lo : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
+                        zn = zn > up ? up : zn;
+                        y = y + rho * (zr - zn);
+                        z = zn;
+                    }
+
+                    // operands of the next iteration (the barrier at the loop top orders them before the gathers)
+                    if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - c_rinv * y) : T(0));
+                    if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - c_q : T(0));
+                    SQPH_TICK(7)
+                }
+                iter += seg;
+                if constexpr (CHECKS) {
+                    bool check = false, adapt = false;
+                    if (next_check > 0 && (next_check -= seg) == 0) {
                         check = true;
                         next_check = a.check_termination;
                     }
-                    if (--next_adapt == 0) {
+                    if (next_adapt > 0 && (next_adapt -= seg) == 0) {
                         adapt = true;
                         next_adapt = a.adaptive_rho_interval;
                     }
+                    if (check || adapt) {
+                        // update_state + residuals, qp.cpp:316-331, 353-361.  A and P are streamed from global
+                        // memory here (the register tiles hold B and W); this block runs every check_termination
+                        // iterations only.
+                        __syncthreads();
+                        if (t < L::NP) put_colv(lds, t, nown ? x : T(0));
+                        if (t < L::MP) put_rowv(lds, r, c, mown ? y : T(0));
+                        __syncthreads();
+                        {
+                            T yr[TR];
+                            get_rowv(lds, r, yr);
+                            int n_c = n, m_c = m, r_c = r, c_c = c;
+                            const TIN *gA_c = m > 0 ? gA : gP;  // m == 0: nothing to read, any readable address will do
+                            SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_S(m_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gA_c);
+                            stage_A_AT_gmem(gA_c, n_c, m_c, r_c, c_c, yr, lds);  // A x (over c) and A' y (over r)
+                        }
+                        __syncthreads();
+                        const T Ax = mown ? reduce_over_c(lds, t) : T(0);
+                        const T ATy = nown ? reduce_over_r(lds, t) : T(0);
+                        __syncthreads();
+                        {
+                            int n_c = n, r_c = r, c_c = c;
+                            const TIN *gP_c = gP;
+                            SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gP_c);
+                            stage_P_gmem(gP_c, n_c, r_c, c_c, lds);  // full P (both triangles), as qp.cpp:324
+                        }
+                        __syncthreads();
+                        const T Px = nown ? reduce_over_c(lds, t) : T(0);
+                        __syncthreads();
+                        T v[7] = {0, 0, 0, 0, 0, 0, 0};
+                        if (mown) {
+                            v[0] = tabs(Ax);
+                            v[1] = tabs(z);
+                            v[2] = tabs(Ax - z);
+                        }
+                        if (nown) {
+                            const T q = qv[t];
+                            v[3] = tabs(Px);
+                            v[4] = tabs(ATy);
+                            v[5] = tabs(q);
+                            v[6] = tabs(Px + q + ATy);
+                        }
+                        {   // workgroup-wide NaN-propagating max: butterfly inside each wave, NW values through LDS
+                            T *red = lds + L::O_RED;
+    #pragma unroll
+                            for (int e = 0; e < 7; e++) v[e] = wave_nanmax(v[e]);
+                            if constexpr (NW > 1) {
+                                if ((t & 63) == 0) {
+    #pragma unroll
+                                    for (int e = 0; e < 7; e++) red[e * NW + (t >> 6)] = v[e];
+                                }
+                                __syncthreads();
+    #pragma unroll
+                                for (int e = 0; e < 7; e++) {
+                                    T mval = red[e * NW];
+    #pragma unroll
+                                    for (int wv_ = 1; wv_ < NW; wv_++) mval = nanmax(mval, red[e * NW + wv_]);
+                                    v[e] = mval;
+                                }
+                                __syncthreads();
+                            }
+                        }
+                        const T nrm_prim = nanmax(v[0], v[1]);
+                        const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
+                        info.res_prim = (double)v[2];
+                        info.res_dual = (double)v[6];
+                        if (check) {
+                            if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                                info.status = SQPH_SOLVED;
+                                iter--;  // the iteration the test passed at (the segment loop has already counted past it)
+                                break;
+                            }
+                        }
+                        if (adapt) {
+                            const T eps = a.regul;
+                            const T rp_norm = v[2] / (nrm_prim + eps);
+                            const T rd_norm = v[6] / (nrm_dual + eps);
+                            T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
+                            new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
+                            new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
+                            info.rho_estimate = (double)new_rho;
+                            if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
+                                rho_s = new_rho;
+                                if (mown) {
+                                    rho = rho_for_type<T>(sct[t], rho_s, a.rho_min, a.rho_eq_factor);  // type re-read from the state array (rare)
+                                    rinvv[t] = T(1) / rho;
+                                }
+                                info.rho_updates += 1;
+                                need_factor = true;
+                                iter--;
+                                break;  // leave the iteration loop WITHOUT advancing iter; the factor block does it
+                            }
+                        }
+                        // the check borrowed the row-gather vector for y: publish w again for the next segment
+                        if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
+                    }
                 }
-                if (CHECKS && (check || adapt)) {
-                    // update_state + residuals, qp.cpp:316-331, 353-361.  A and P are streamed from global
-                    // memory here (the register tiles hold B and W); this block runs every check_termination
-                    // iterations only.
-                    __syncthreads();
-                    if (t < L::NP) put_colv(lds, t, nown ? x : T(0));
-                    if (t < L::MP) put_rowv(lds, r, c, mown ? y : T(0));
-                    __syncthreads();
-                    {
-                        T yr[TR];
-                        get_rowv(lds, r, yr);
-                        int n_c = n, m_c = m, r_c = r, c_c = c;
-                        const TIN *gA_c = m > 0 ? gA : gP;  // m == 0: nothing to read, any readable address will do
-                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_S(m_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gA_c);
-                        stage_A_AT_gmem(gA_c, n_c, m_c, r_c, c_c, yr, lds);  // A x (over c) and A' y (over r)
-                    }
-                    __syncthreads();
-                    const T Ax = mown ? reduce_over_c(lds, t) : T(0);
-                    const T ATy = nown ? reduce_over_r(lds, t) : T(0);
-                    __syncthreads();
-                    {
-                        int n_c = n, r_c = r, c_c = c;
-                        const TIN *gP_c = gP;
-                        SQPH_OPAQUE_S(n_c); SQPH_OPAQUE_V(r_c); SQPH_OPAQUE_V(c_c); SQPH_OPAQUE_S(gP_c);
-                        stage_P_gmem(gP_c, n_c, r_c, c_c, lds);  // full P (both triangles), as qp.cpp:324
-                    }
-                    __syncthreads();
-                    const T Px = nown ? reduce_over_c(lds, t) : T(0);
-                    __syncthreads();
-                    T v[7] = {0, 0, 0, 0, 0, 0, 0};
-                    if (mown) {
-                        v[0] = tabs(Ax);
-                        v[1] = tabs(z);
-                        v[2] = tabs(Ax - z);
-                    }
-                    if (nown) {
-                        const T q = qv[t];
-                        v[3] = tabs(Px);
-                        v[4] = tabs(ATy);
-                        v[5] = tabs(q);
-                        v[6] = tabs(Px + q + ATy);
-                    }
-                    {   // workgroup-wide NaN-propagating max: butterfly inside each wave, NW values through LDS
-                        T *red = lds + L::O_RED;
-#pragma unroll
-                        for (int e = 0; e < 7; e++) v[e] = wave_nanmax(v[e]);
-                        if constexpr (NW > 1) {
-                            if ((t & 63) == 0) {
-#pragma unroll
-                                for (int e = 0; e < 7; e++) red[e * NW + (t >> 6)] = v[e];
-                            }
-                            __syncthreads();
-#pragma unroll
-                            for (int e = 0; e < 7; e++) {
-                                T mval = red[e * NW];
-#pragma unroll
-                                for (int wv_ = 1; wv_ < NW; wv_++) mval = nanmax(mval, red[e * NW + wv_]);
-                                v[e] = mval;
-                            }
-                            __syncthreads();
-                        }
-                    }
-                    const T nrm_prim = nanmax(v[0], v[1]);
-                    const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
-                    info.res_prim = (double)v[2];
-                    info.res_dual = (double)v[6];
-                    if (check) {
-                        if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
-                            info.status = SQPH_SOLVED;
-                            break;
-                        }
-                    }
-                    if (adapt) {
-                        const T eps = a.regul;
-                        const T rp_norm = v[2] / (nrm_prim + eps);
-                        const T rd_norm = v[6] / (nrm_dual + eps);
-                        T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
-                        new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
-                        new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
-                        info.rho_estimate = (double)new_rho;
-                        if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
-                            rho_s = new_rho;
-                            if (mown) {
-                                rho = rho_for_type<T>(sct[t], rho_s, a.rho_min, a.rho_eq_factor);  // type re-read from the state array (rare)
-                                rinvv[t] = T(1) / rho;
-                            }
-                            info.rho_updates += 1;
-                            need_factor = true;
-                            break;  // leave the iteration loop WITHOUT advancing iter; the factor block does it
-                        }
-                    }
-                }
-                // operands of the next iteration (the barrier at the loop top orders them before the gathers)
-                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - c_rinv * y) : T(0));
-                if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - c_q : T(0));
-                SQPH_TICK(7)
             }
 #ifdef SQPH_PHASE_TIMING
             if (t < 8) x = (T)tacc[t];           // debug build only: wave 0's phase ticks instead of x[0..8)
