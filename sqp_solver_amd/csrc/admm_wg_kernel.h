@@ -922,45 +922,44 @@ struct WgKernel {
                         __syncthreads();
                         const T Px = nown ? reduce_over_c(lds, t) : T(0);
                         __syncthreads();
-                        T v[7] = {0, 0, 0, 0, 0, 0, 0};
+                        // the seven norms of qp.cpp:316-331 as four reductions: max(|Ax|, |z|) and max(|Px|, |A'y|, |q|) are only used
+                        // combined, so each lane combines its own terms first (a NaN-propagating max is order-free)
+                        T v[4] = {0, 0, 0, 0};  // nrm_prim | res_prim | nrm_dual | res_dual
                         if (mown) {
-                            v[0] = tabs(Ax);
-                            v[1] = tabs(z);
-                            v[2] = tabs(Ax - z);
+                            v[0] = nanmax(tabs(Ax), tabs(z));
+                            v[1] = tabs(Ax - z);
                         }
                         if (nown) {
                             const T q = qv[t];
-                            v[3] = tabs(Px);
-                            v[4] = tabs(ATy);
-                            v[5] = tabs(q);
-                            v[6] = tabs(Px + q + ATy);
+                            v[2] = nanmax(tabs(Px), nanmax(tabs(ATy), tabs(q)));
+                            v[3] = tabs(Px + q + ATy);
                         }
                         {   // workgroup-wide NaN-propagating max: butterfly inside each wave, NW values through LDS
                             T *red = lds + L::O_RED;
-    #pragma unroll
-                            for (int e = 0; e < 7; e++) v[e] = wave_nanmax(v[e]);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = wave_nanmax(v[e]);
                             if constexpr (NW > 1) {
                                 if ((t & 63) == 0) {
-    #pragma unroll
-                                    for (int e = 0; e < 7; e++) red[e * NW + (t >> 6)] = v[e];
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) red[e * NW + (t >> 6)] = v[e];
                                 }
                                 __syncthreads();
-    #pragma unroll
-                                for (int e = 0; e < 7; e++) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
                                     T mval = red[e * NW];
-    #pragma unroll
+#pragma unroll
                                     for (int wv_ = 1; wv_ < NW; wv_++) mval = nanmax(mval, red[e * NW + wv_]);
                                     v[e] = mval;
                                 }
                                 __syncthreads();
                             }
                         }
-                        const T nrm_prim = nanmax(v[0], v[1]);
-                        const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
-                        info.res_prim = (double)v[2];
-                        info.res_dual = (double)v[6];
+                        const T nrm_prim = v[0];
+                        const T nrm_dual = v[2];
+                        info.res_prim = (double)v[1];
+                        info.res_dual = (double)v[3];
                         if (check) {
-                            if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                            if (v[1] <= a.eps_abs + a.eps_rel * nrm_prim && v[3] <= a.eps_abs + a.eps_rel * nrm_dual) {
                                 info.status = SQPH_SOLVED;
                                 iter--;  // the iteration the test passed at (the segment loop has already counted past it)
                                 break;
@@ -968,8 +967,8 @@ struct WgKernel {
                         }
                         if (adapt) {
                             const T eps = a.regul;
-                            const T rp_norm = v[2] / (nrm_prim + eps);
-                            const T rd_norm = v[6] / (nrm_dual + eps);
+                            const T rp_norm = v[1] / (nrm_prim + eps);
+                            const T rd_norm = v[3] / (nrm_dual + eps);
                             T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
                             new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
                             new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
