@@ -616,6 +616,15 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         a.mode = for_family('c');
         p.a = a;
         p.ca = CsrArgs<TIN>{csr->rowptr, csr->colind, (const TIN *)csr->val, csr->s_rowptr, csr->s_colind, csr->s_val, csr->nnz_cap};
+        // calls that never look at the residuals take the instantiation without the check block (csr_nocheck.hip)
+        if (st.check_termination <= 0 && !(st.adaptive_rho && st.adaptive_rho_interval > 0)) {
+            const int rc = csr_nocheck_launch<TIN>(csr->TT, s->m, csr->nnz_cap, qp->batch, s->stream, p);
+            if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "sparse kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+            if (rc > 0) {
+                s->kernel_name = csr->TT == 7 ? "csr_t7" : csr->TT == 4 ? "csr_t4" : "csr";
+                launched = true;
+            }
+        }
 #define SQPH_CSR_CASE(TT_)                                                                                                          \
     if (!launched && csr->TT == TT_) {                                                                                              \
         const CsrLayout<TT_> L = CsrLayout<TT_>::make(s->m, csr->nnz_cap);                                                          \
