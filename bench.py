@@ -228,6 +228,8 @@ def main():
                     else "the SQP driver's QP settings (src/sqp.cpp:15-23: eps 1e-4, check 10, max_iter 100, adaptive rho / 50, alpha 1.6)"),
                 "n": n, "m": m, "batch_per_gpu": B, "global_batch": total_batch, "mode": args.mode, "interface_dtype": args.dtype,
                 "admm_iters_per_qp": iters_per_qp, "kernel": solver.kernel_name(),
+                # calls that never check (fixed mode) run the kernel instantiation without the residual-check block
+                "kernel_variant": "no-check" if (args.mode == "fixed" and solver.kernel_name().startswith(("wg", "csr"))) else "checking",
                 "parallelism": "batch-sharded x%d" % world,
                 "gather": bool(gather_bufs is not None),
             },
