@@ -12,8 +12,10 @@ namespace sqph {
 // one QP per lane for tiny shapes (admm_lane_kernel.h): >0 launched, 0 not covered, <0 error
 template <typename TIN, typename TA = double>
 inline int lane_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
-    static const bool off = getenv("SQPH_NO_LANE") != nullptr;  // experiments only
+#ifdef SQPH_EXPERIMENTS  // environment knobs exist in experiment builds only (tools/slim_build.sh), never in the shipped library
+    static const bool off = getenv("SQPH_NO_LANE") != nullptr;
     if (off) return 0;
+#endif
 #define SQPH_LANE_CASE(N_, M_, E_)                                                                                    \
     if (SQPH_LANE_MATCH(a, N_, M_, E_)) {                                                                             \
         hipLaunchKernelGGL((admm_lane_kernel<TA, TIN, N_, M_, E_>), dim3((a.batch + 63) / 64), dim3(64), 0, stream, a);   \
@@ -29,8 +31,10 @@ inline int lane_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, cons
 // four-QPs-per-wavefront kernels for small shapes (admm_wg_kernel.h, run_group): >0 launched, 0 not covered, <0 error
 template <typename TIN>
 inline int g16_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
-    static const bool off = getenv("SQPH_NO_G16") != nullptr;  // experiments only
+#ifdef SQPH_EXPERIMENTS
+    static const bool off = getenv("SQPH_NO_G16") != nullptr;
     if (off) return 0;
+#endif
 #define SQPH_G16_CASE(TR_, TC_, W_)                                                                                            \
     if (a.m <= 4 * TR_ && a.n <= 4 * TC_) {                                                                                    \
         hipLaunchKernelGGL((admm_g16_kernel<TIN, TR_, TC_, W_>), dim3((a.batch + 3) / 4), dim3(64), 0, stream, a);             \
@@ -45,8 +49,10 @@ inline int g16_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const
 // two QPs per wavefront (32 lanes each): >0 launched, 0 not covered, <0 error
 template <typename TIN>
 inline int g32_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
-    static const bool off = getenv("SQPH_NO_G32") != nullptr;  // experiments only
+#ifdef SQPH_EXPERIMENTS
+    static const bool off = getenv("SQPH_NO_G32") != nullptr;
     if (off) return 0;
+#endif
     // Two QPs share a wavefront until the slower one is done.  With termination checks the iteration counts of the
     // reference's default settings are heavy-tailed (most QPs stop at 75-200, some run to max_iter) and the 1.24x this
     // kernel gains at equal counts is lost (measured at n = 20, m = 40: 1.51 vs 1.21 ms); the four-per-wave kernel's 3x
@@ -72,9 +78,14 @@ extern template int wg_nocheck_try_launch<float>(const KArgs<double, float> &, h
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>
 inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
-    // SQPH_WG_SKIP=k (experiments only): skip the first k shapes that would fit
+#ifdef SQPH_EXPERIMENTS
+    // SQPH_WG_SKIP=k: skip the first k shapes that would fit; SQPH_WG_ALWAYS_CHECKS: never take the no-check instantiation
     static const int skip_env = getenv("SQPH_WG_SKIP") ? atoi(getenv("SQPH_WG_SKIP")) : 0;
-    static const bool always_checks = getenv("SQPH_WG_ALWAYS_CHECKS") != nullptr;  // experiments only
+    static const bool always_checks = getenv("SQPH_WG_ALWAYS_CHECKS") != nullptr;
+#else
+    constexpr int skip_env = 0;
+    constexpr bool always_checks = false;
+#endif
     int skip = skip_env;
     if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0) && !always_checks)
         return wg_nocheck_try_launch<TIN>(a, stream, name, skip);

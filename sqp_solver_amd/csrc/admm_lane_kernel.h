@@ -174,7 +174,9 @@ struct LaneKernel {
 #pragma unroll
             for (int j = 0; j < NMAX; j++) Pl[i][j] = i >= j ? P[i][j] : P[j][i];
 
-        bool rho_unchanged = (mode & MODE_SAME_MATRICES) != 0;  // the resident factor was built with exactly this rho vector
+        // the resident factor was built with exactly this rho vector — and is a valid factor: after a set-up that ended in
+        // NUMERICAL_ISSUES (or on an UNINITIALIZED instance) the reference's re-solve runs setup() again (sqp.cpp:274 -> 221-229)
+        bool rho_unchanged = (mode & MODE_SAME_MATRICES) != 0 && info.status != SQPH_NUMERICAL_ISSUES && info.status != SQPH_UNINITIALIZED;
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
             rho_s = a_rho0;
 #pragma unroll

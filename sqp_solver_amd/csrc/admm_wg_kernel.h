@@ -666,6 +666,25 @@ struct WgKernel {
         if (!(mode & (MODE_SETUP | MODE_UPDATE)) &&
             (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
             return;  // qp.cpp:68-71 (block-uniform)
+#if defined(SQPH_EXPERIMENTS) && !defined(SQPH_SIM)
+        // experiment: de-phase co-resident workgroups.  xp[0] = delay in s_memtime ticks, xp[1] = selector (0: blockIdx bit xp[2];
+        // 1: wave slot parity of this wave; 2: delay proportional to blockIdx bits [xp[2], xp[2]+2)), xp[3] = only blocks below
+        unsigned long long xt0 = __builtin_amdgcn_s_memtime();
+        {
+            const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            if (a.xp[0] > 0 && (a.xp[3] <= 0 || qp < a.xp[3])) {
+                unsigned long long d = 0;
+                if (a.xp[1] == 0) d = ((qp >> a.xp[2]) & 1) ? a.xp[0] : 0;
+                else if (a.xp[1] == 1) d = (hwid & 1) ? a.xp[0] : 0;
+                else d = (unsigned long long)((qp >> a.xp[2]) & 3) * a.xp[0];
+                while (__builtin_amdgcn_s_memtime() - xt0 < d) __builtin_amdgcn_s_sleep(32);
+            }
+            if (a.xdbg && (t & 63) == 0) {
+                a.xdbg[8 * qp + 4 * (t >> 6) + 0] = hwid | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+                a.xdbg[8 * qp + 4 * (t >> 6) + 1] = xt0;
+            }
+        }
+#endif
 
         // lane t owns x[t], q[t] (t < n) and z[t], y[t], l[t], u[t], rho[t] (t < m)
         const bool nown = t < n, mown = t < m;
@@ -723,7 +742,8 @@ struct WgKernel {
         T vt[TW][TC];  // the tile of W' the iteration runs on (the W tile itself lives only inside the set-up block)
         T at[TR][TC];  // the A tile; turned into B = A W' in place once the factor is known
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
-        if ((mode & MODE_SAME_MATRICES) && (mode & (MODE_SETUP | MODE_UPDATE)) && !(mode & MODE_REFACTOR)) {
+        if ((mode & MODE_SAME_MATRICES) && (mode & (MODE_SETUP | MODE_UPDATE)) && !(mode & MODE_REFACTOR) &&
+            info.status != SQPH_NUMERICAL_ISSUES && info.status != SQPH_UNINITIALIZED) {  // a failed set-up left no valid factor: refactor
             // sqph_setup_solve_reuse: same P and A as the resident factor; it is also the factor setup() would build if no lane's
             // rho differs from the vector it was built with (workgroup-wide OR through one LDS word of the idle staging area)
             T *flag = lds + L::O_STAGE;
@@ -1016,6 +1036,9 @@ struct WgKernel {
             a.info[qp] = info;
             a.rho[qp] = rho_s;
         }
+#if defined(SQPH_EXPERIMENTS) && !defined(SQPH_SIM)
+        if (a.xdbg && (t & 63) == 0) a.xdbg[8 * qp + 4 * (t >> 6) + 2] = __builtin_amdgcn_s_memtime();
+#endif
     }
 
     // ------------------------------------------------------------------ NW == 0: four QPs per wavefront

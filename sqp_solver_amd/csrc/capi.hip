@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -62,10 +63,14 @@ constexpr size_t ZERO_COPY_BYTES = 256u << 10;  // beyond this the kernels' re-r
 // Small host-memspace calls (the SQP driver's per-iteration subproblem batches) are latency-bound: the kernels read the
 // problem data straight from a pinned, device-mapped host buffer and the results are packed straight into another one
 // (no H2D / D2H copy commands), and the host waits by polling the stream for a bounded time before it falls back to the
-// blocking wait (whose wake-up latency is tens of microseconds).  SQPH_NO_ZEROCOPY=1 restores the copy path (A/B).
+// blocking wait (whose wake-up latency is tens of microseconds).  Experiment builds: SQPH_NO_ZEROCOPY=1 restores the copy path (A/B).
 bool zero_copy_enabled() {
+#ifdef SQPH_EXPERIMENTS
     static const bool off = getenv("SQPH_NO_ZEROCOPY") != nullptr;
     return !off;
+#else
+    return true;
+#endif
 }
 hipError_t wait_stream_low_latency(hipStream_t st) {
     for (int spin = 0; spin < 20000; spin++) {
@@ -448,7 +453,7 @@ int sqph_get_solution(sqph_solver *s, int batch, int memspace, void *x, void *y,
                 s->hout = s->dout = s->hout_dev = nullptr;
                 s->hout_cap = 0;
                 const size_t cap = words * 8 < 65536 ? 65536 : words * 8;
-                SQPH_HIP(s, hipHostMalloc(&s->hout, cap, hipHostMallocMapped));
+                SQPH_HIP(s, hipHostMalloc(&s->hout, cap, hipHostMallocMapped | hipHostMallocCoherent));
                 SQPH_HIP(s, hipMalloc(&s->dout, cap));
                 if (hipHostGetDevicePointer(&s->hout_dev, s->hout, 0) != hipSuccess) s->hout_dev = nullptr;
                 s->hout_cap = cap;
@@ -582,6 +587,27 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     a.max_iter = st.max_iter; a.check_termination = st.check_termination; a.warm_start = st.warm_start;
     a.adaptive_rho = st.adaptive_rho; a.adaptive_rho_interval = st.adaptive_rho_interval;
 
+#ifdef SQPH_EXPERIMENTS
+    {   // experiment builds only: knobs SQPH_XP0..7, and (SQPH_XDBG=<file>) 8 words per workgroup dumped after the launch
+        for (int k = 0; k < 8; k++) {
+            char nm[16];
+            snprintf(nm, sizeof(nm), "SQPH_XP%d", k);
+            a.xp[k] = getenv(nm) ? atoi(getenv(nm)) : 0;
+        }
+        a.xdbg = nullptr;
+        if (getenv("SQPH_XDBG")) {
+            static unsigned long long *dbg = nullptr;
+            static size_t dbg_cap = 0;
+            if ((size_t)qp->batch > dbg_cap) {
+                if (dbg) (void)hipFree(dbg);
+                SQPH_HIP(s, hipMalloc((void **)&dbg, (size_t)qp->batch * 8 * sizeof(unsigned long long)));
+                dbg_cap = qp->batch;
+            }
+            SQPH_HIP(s, hipMemsetAsync(dbg, 0, (size_t)qp->batch * 8 * sizeof(unsigned long long), s->stream));
+            a.xdbg = dbg;
+        }
+    }
+#endif
     const bool verbose = st.verbose != 0 && (mode & MODE_SOLVE);
     if (verbose) {
         const int cap = (st.check_termination > 0 ? st.max_iter / st.check_termination : 0) + 2;
@@ -668,7 +694,11 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         a.mode = mode_in;
         a.mode = for_family('g');
         const int big = s->n > s->m ? s->n : s->m;
-        static const int nt_env = getenv("SQPH_GENERIC_NT") ? atoi(getenv("SQPH_GENERIC_NT")) : 0;  // experiments only
+#ifdef SQPH_EXPERIMENTS
+        static const int nt_env = getenv("SQPH_GENERIC_NT") ? atoi(getenv("SQPH_GENERIC_NT")) : 0;
+#else
+        constexpr int nt_env = 0;
+#endif
         // 4 waves were 8 waves per CU at these sizes (LDS): too few loads in flight to stream the matrices — measured 1.2-2.9x with 8 / 16
         int nt = nt_env > 0 ? nt_env : (big <= 128 ? 64 : ((long long)s->n * s->m >= 20000 ? 1024 : 512));
         while (nt > 256 && generic_lds_elems<T>(s->n, s->m, nt) * sizeof(T) > 160 * 1024) nt /= 2;  // the per-thread scratch must leave room for the vectors
@@ -685,6 +715,17 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         SQPH_HIP(s, hipEventRecord(s->evs[s->ev_used].second, s->stream));
         s->ev_used++;
     }
+#ifdef SQPH_EXPERIMENTS
+    if (a.xdbg) {
+        SQPH_HIP(s, hipStreamSynchronize(s->stream));
+        std::vector<unsigned long long> h((size_t)qp->batch * 8);
+        SQPH_HIP(s, hipMemcpy(h.data(), a.xdbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(getenv("SQPH_XDBG"), "wb")) {
+            fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+            fclose(f);
+        }
+    }
+#endif
     return SQPH_OK;
 }
 
@@ -724,7 +765,7 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
                 s->hpin = s->dpin = s->hpin_dev = nullptr;
                 s->hpin_cap = 0;
                 const size_t cap = total < 65536 ? 65536 : total;
-                SQPH_HIP(s, hipHostMalloc(&s->hpin, cap, hipHostMallocMapped));
+                SQPH_HIP(s, hipHostMalloc(&s->hpin, cap, hipHostMallocMapped | hipHostMallocCoherent));
                 SQPH_HIP(s, hipMalloc(&s->dpin, cap));
                 if (hipHostGetDevicePointer(&s->hpin_dev, s->hpin, 0) != hipSuccess) s->hpin_dev = nullptr;
                 s->hpin_cap = cap;
@@ -929,8 +970,9 @@ struct sqph_gather {
     long long total = 0;
     double *x = nullptr, *y = nullptr;
     sqph_info *info = nullptr;
-    std::vector<hipEvent_t> pending;   // one per posted copy, recorded on the producer's stream
-    std::vector<int> pending_dev;
+    std::mutex mu;                     // shards post from their own host threads (MultiGpuBatchQPSolver::run_host)
+    std::vector<hipEvent_t> pending;   // one per posted copy, recorded on the producer's stream  (guarded by mu)
+    std::vector<int> pending_dev;      //                                                          (guarded by mu)
     std::string err;
 };
 
@@ -992,26 +1034,34 @@ int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int cou
     hipEvent_t ev;
     SQPH_HIP(src, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     SQPH_HIP(src, hipEventRecord(ev, src->stream));
-    g->pending.push_back(ev);
-    g->pending_dev.push_back(src->device);
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->pending.push_back(ev);
+        g->pending_dev.push_back(src->device);
+    }
     return SQPH_OK;
 }
 
 static int gather_wait(sqph_gather *g) {
-    for (size_t i = 0; i < g->pending.size(); i++) {
-        DeviceGuard dg(g->pending_dev[i]);
-        hipError_t e = hipEventSynchronize(g->pending[i]);
-        (void)hipEventDestroy(g->pending[i]);
+    // take the posted events out under the lock, wait for them outside it (a concurrent post lands in the next wait)
+    std::vector<hipEvent_t> evs;
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        evs.swap(g->pending);
+        devs.swap(g->pending_dev);
+    }
+    int rc = SQPH_OK;
+    for (size_t i = 0; i < evs.size(); i++) {
+        DeviceGuard dg(devs[i]);
+        const hipError_t e = rc == SQPH_OK ? hipEventSynchronize(evs[i]) : hipSuccess;
+        (void)hipEventDestroy(evs[i]);  // every event is released, also behind a failed one
         if (e != hipSuccess) {
             g_err = std::string("sqph_gather: ") + hipGetErrorString(e);
-            g->pending.clear();
-            g->pending_dev.clear();
-            return SQPH_ERR_HIP;
+            rc = SQPH_ERR_HIP;
         }
     }
-    g->pending.clear();
-    g->pending_dev.clear();
-    return SQPH_OK;
+    return rc;
 }
 
 int sqph_gather_device_ptrs(sqph_gather *g, void **x, void **y, sqph_info **info) {

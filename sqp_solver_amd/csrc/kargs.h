@@ -50,6 +50,12 @@ struct KArgs {
     // Null = off.  Only the generic and the one-QP-per-lane kernels record; the host routes verbose calls to them.
     double *trace;
     int trace_qp, trace_cap;
+#ifdef SQPH_EXPERIMENTS
+    // experiment builds only (tools/slim_build.sh -DSQPH_EXPERIMENTS): knobs from the environment (SQPH_XP0..7) and a
+    // per-workgroup debug record buffer; never part of the shipped library
+    int xp[8];
+    unsigned long long *xdbg;
+#endif
 };
 
 }  // namespace sqph

@@ -39,7 +39,11 @@ class ResultGather:
     ONE gather per batch (direct peer-to-root over xGMI with the "nccl" backend).  The collective is asynchronous and
     double-buffered: the gather of batch k runs on the communication stream while batch k+1 is being solved; a staging
     buffer is reused only after its previous gather has completed (stream dependency, no host wait).  `flush()` joins
-    everything outstanding (call it before the final synchronisation / before reading `stacked()`)."""
+    everything outstanding (call it before the final synchronisation / before reading `stacked()`).
+
+    Shards need not be equal (shard_bounds gives the first `total % world` ranks one QP more): the row counts are exchanged
+    once at construction, every rank's staging buffer is padded to the largest shard's record size (a gather moves equal
+    sized buffers), and `stacked()` decodes rank r's buffer with rank r's own row count."""
 
     def __init__(self, solver=None, world=1, rank=0, device=None, tensors=None, dst=0, depth=2):
         import torch
@@ -49,10 +53,21 @@ class ResultGather:
         self.world, self.rank, self.dst, self.depth = world, rank, dst, depth
         self.local = list(tensors) if tensors is not None else list(device_views(solver, device))
         self.local = [t if t.is_contiguous() else t.contiguous() for t in self.local]
-        self.nbytes = [t.numel() * t.element_size() for t in self.local]
-        total = sum(self.nbytes)
+        rows = self.local[0].shape[0]
+        assert all(t.shape[0] == rows for t in self.local), "every array carries one record per QP"
+        # bytes of one QP's record in each array (the arrays may be empty on a rank whose shard is empty)
+        self.row_bytes = [int(np.prod(t.shape[1:], dtype=np.int64)) * t.element_size() for t in self.local]
+        self.nbytes = [rows * rb for rb in self.row_bytes]
         dev = self.local[0].device
-        self.stage = [torch.empty(total, dtype=torch.uint8, device=dev) for _ in range(depth)]
+        counts = torch.tensor([rows], dtype=torch.int64, device=dev)
+        if world > 1:
+            allc = [torch.zeros_like(counts) for _ in range(world)]
+            dist.all_gather(allc, counts)
+            self.rows = [int(c.item()) for c in allc]
+        else:
+            self.rows = [rows]
+        total = max(self.rows) * sum(self.row_bytes)
+        self.stage = [torch.zeros(total, dtype=torch.uint8, device=dev) for _ in range(depth)]
         self.out = None
         if rank == dst:
             self.out = [[torch.empty(total, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(depth)]
@@ -70,7 +85,8 @@ class ResultGather:
             self.work[slot].wait()  # the staging buffer is free again once its previous gather is done
         off = 0
         for t, nb in zip(self.local, self.nbytes):
-            self.stage[slot][off:off + nb].copy_(t.view(torch.uint8).reshape(-1))
+            if nb:
+                self.stage[slot][off:off + nb].copy_(t.view(torch.uint8).reshape(-1))
             off += nb
         self.work[slot] = self.dist.gather(self.stage[slot], self.out[slot] if self.rank == self.dst else None, dst=self.dst,
                                            async_op=True)
@@ -85,16 +101,18 @@ class ResultGather:
 
     def stacked(self):
         """On dst: each array of the most recent gather concatenated over ranks in rank order (== the unsharded batch
-        order); joins outstanding gathers first."""
+        order, padding removed); joins outstanding gathers first."""
         import torch
 
         self.flush()
         if self.out is None or self.last is None:
             return None
         res = []
-        off = 0
-        for t, nb in zip(self.local, self.nbytes):
-            parts = [o[off:off + nb].view(t.dtype).reshape(t.shape) for o in self.out[self.last]]
+        for k, t in enumerate(self.local):
+            parts = []
+            for r, o in enumerate(self.out[self.last]):
+                off = self.rows[r] * sum(self.row_bytes[:k])  # rank r packed its arrays back to back with ITS row count
+                nb = self.rows[r] * self.row_bytes[k]
+                parts.append(o[off:off + nb].view(t.dtype).reshape((self.rows[r],) + tuple(t.shape[1:])))
             res.append(torch.cat(parts, dim=0))
-            off += nb
         return res

@@ -391,6 +391,30 @@ def soc_factor_reuse(make, n=8, m=12, batch=6, **kw):
             assert relerr(x, xo) < TOL_F64 and relerr1(y, yo) < TOL_F64
 
 
+def soc_reuse_after_failed_setup(make, n=8, m=12, batch=4, **kw):
+    """setup_solve_reuse() on an instance whose set-up ended in NUMERICAL_ISSUES must run the factorisation again (the reference's
+    SOC re-solve calls setup(), src/sqp.cpp:274 -> 221-229) instead of iterating on the invalid resident factor: the QP stays
+    NUMERICAL_ISSUES with its iterates untouched, the other QPs of the batch are unaffected."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=23)
+    P = P.copy()
+    P[0] = -100.0 * np.eye(n)  # S = P + sigma I + A'RA indefinite => NUMERICAL_ISSUES for QP 0
+    q2, l2, u2 = q + 0.3, l - 0.2, u + 0.05
+    s = make(n, m, batch, keep_factor=True, **kw)
+    s.settings.max_iter, s.settings.check_termination = 40, 0
+    s.setup_solve(P, q, A, l, u)
+    x1, y1, z1, info1 = s.solution()
+    assert info1.status[0] == 3 and (info1.status[1:] != 3).all()
+    s.setup_solve_reuse(P, q2, A, l2, u2)
+    x, y, z, info = s.solution()
+    s2 = make(n, m, batch, **kw)
+    s2.settings.max_iter, s2.settings.check_termination = 40, 0
+    s2.setup_solve(P, q2, A, l2, u2)
+    x2, y2, z2, info2 = s2.solution()
+    assert info.status[0] == 3 and (info.status == info2.status).all() and (info.iter[1:] == info2.iter[1:]).all()
+    assert np.array_equal(x, x2) and np.array_equal(y, y2) and np.array_equal(z, z2)
+    assert not x[0].any() and not y[0].any()
+
+
 def api_sequence_fuzz(make, n, m, batch, seed, steps=12, adaptive_ok=True, **kw):
     """A random sequence of the stateful calls (setup / update_qp / solve / setup_solve / setup_solve_reuse / set_state) with
     settings flipped in between — check_termination 0 <-> 7 and verbose on/off move the dispatch between kernel families, so a

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline", "cpu_baseline"]
@@ -30,7 +32,7 @@ def test_recorded_lines_follow_the_contract():
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["parity_status_equal"] and c["parity_iter_equal"]
         if d["dtype"] == "f64":
-            assert c["parity_max_rel_err_x"] < 1e-6 and (c["parity_max_rel_err_y"] < 1e-6 or d["config"]["n"] <= 4)
+            assert c["parity_max_rel_err_x"] < 1e-6 and c["parity_max_rel_err_y"] < 1e-6
         total = d["config"]["global_batch"]
         assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
@@ -43,3 +45,38 @@ def test_bench_refuses_without_a_device():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                        timeout=300)
     assert p.returncode != 0 and "no CPU path" in (p.stderr + p.stdout)
+
+
+def test_bench_gpus_n_without_devices_fails_loudly():
+    """`bench.py --gpus N` with fewer than N devices must not print an N-labelled (or silently 1-GPU) line (VERDICT r2 missing #2)"""
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "device(s) visible" in (p.stderr + p.stdout) and '"n_gpus"' not in p.stdout
+    # a launcher-provided world that disagrees with --gpus is refused as well
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_spawned_path_runs_the_rccl_gather():
+    """bench.py starts its own ranks: `--spawn` takes the N>1 code path (torch.distributed.run, process group on the nccl = RCCL
+    backend, ResultGather) on the one device of the box; the gathered records equal the resident state (asserted inside bench.py)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--batch-per-gpu", "1024"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["gather"] is True and d["config"]["global_batch"] == 1024
+    # strong-scaling split with a batch that does not divide evenly is fine on one rank too (padding path: rows == [1023])
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--global-batch", "1023"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["gather"] is True and d["config"]["global_batch"] == 1023 and d["scaling"] == "strong"

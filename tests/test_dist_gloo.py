@@ -17,18 +17,17 @@ from sqp_solver_amd.dist import shard_bounds, ResultGather
 from sqp_solver_amd.problems import random_qp_batch
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-n, m, total = 6, 9, 10
+n, m, total = 6, 9, 7
 P, q, A, l, u = random_qp_batch(total, n, m, seed=77)
 lo, hi = shard_bounds(total, world, rank)
 s = simlib.SimSolverBatch(n, m, hi - lo, variant=simlib.WG)
 s.settings.max_iter = 40; s.settings.check_termination = 0
 s.setup_solve(P[lo:hi], q[lo:hi], A[lo:hi], l[lo:hi], u[lo:hi])
 x, y, z, info = s.solution()
-# equal-sized records are what gather needs: pad the last shard like a capacity-sized device buffer
-cap = -(-total // world)
-pad = lambda a: torch.from_numpy(np.concatenate([a, np.zeros((cap - a.shape[0],) + a.shape[1:], a.dtype)]))
-tx, ty, ti = pad(x), pad(y), pad(info.iter.astype(np.int32).reshape(-1, 1))
+# unequal shards (total = 7 over 2 ranks: 4 + 3): ResultGather pads the staging buffers itself
+tx, ty, ti = torch.from_numpy(x.copy()), torch.from_numpy(y.copy()), torch.from_numpy(info.iter.astype(np.int32).reshape(-1, 1))
 g = ResultGather(world=world, rank=rank, tensors=[tx, ty, ti])
+assert g.rows == [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
 # three batches through the two staging buffers (the third reuses the first one after its gather has completed);
 # the arrays change in between, as the solver state does from batch to batch
 keep = tx.clone()
@@ -37,8 +36,8 @@ tx.mul_(3.0); g.gather()
 tx.copy_(keep); g.gather()
 if rank == 0:
     xs, ys, its = [t.numpy() for t in g.stacked()]
-    rows = np.concatenate([np.arange(*shard_bounds(total, world, r)) - shard_bounds(total, world, r)[0] + r * cap for r in range(world)])
-    np.savez(sys.argv[2], x=xs[rows], y=ys[rows], iter=its[rows, 0])
+    assert xs.shape[0] == total
+    np.savez(sys.argv[2], x=xs, y=ys, iter=its[:, 0])
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -57,7 +56,7 @@ def test_two_rank_shard_and_gather(tmp_path):
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
          "--master-port", "29533", script, ROOT, out], env=env, timeout=600)
     g = np.load(out)
-    n, m, total = 6, 9, 10
+    n, m, total = 6, 9, 7
     P, q, A, l, u = random_qp_batch(total, n, m, seed=77)
     s = simlib.SimSolverBatch(n, m, total, variant=simlib.WG)
     s.settings.max_iter = 40

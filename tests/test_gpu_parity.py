@@ -87,6 +87,12 @@ def test_setup_solve_reuse(n, m):
     cases.soc_factor_reuse(make_gpu, n=n, m=m, batch=5)
 
 
+@pytest.mark.parametrize("n,m", [(2, 3), (4, 6), (8, 12), (50, 100)])
+def test_setup_solve_reuse_after_failed_setup(n, m):
+    """the SOC fast path refactors a QP whose set-up ended in NUMERICAL_ISSUES (reference: sqp.cpp:274 -> 221-229)"""
+    cases.soc_reuse_after_failed_setup(make_gpu, n=n, m=m, batch=5)
+
+
 def test_four_wave_shapes():
     """m <= 208, n <= 112: four wavefronts per QP (13 x 7 + 7 x 7 doubles of tiles per lane, one wave per SIMD)"""
     s = make_gpu(100, 200, 2)

@@ -275,6 +275,12 @@ def test_setup_solve_reuse(make, n, m):
     cases.soc_factor_reuse(make, n=n, m=m, batch=3)
 
 
+@pytest.mark.parametrize("make,n,m", [(make_lane, 2, 3), (make_lane, 4, 6), (make_wg, 8, 12), (make_wg, 50, 100)], ids=["lane2x3", "lane4x6", "wg1", "wg2"])
+def test_setup_solve_reuse_after_failed_setup(make, n, m):
+    """the SOC fast path must not iterate on the factor of a set-up that ended in NUMERICAL_ISSUES"""
+    cases.soc_reuse_after_failed_setup(make, n=n, m=m, batch=3)
+
+
 def test_lane_golden_fixtures():
     """the config-4 golden fixtures (tests/golden/c4_*.npz) through the one-QP-per-lane kernel under the emulator"""
     import golden_io
