@@ -231,10 +231,25 @@ def parity_fixed_iters(make, n, m, batch, iters=200, seed=11, dtype=np.float64, 
     return ex, ey, ez
 
 
-def parity_termination(make, n, m, batch, seed=5, adaptive=False, sqp_settings=False, diagnostics=True, **kw):
+# One record per parity_termination() call: how many QPs took either escape hatch.  The GPU session writes
+# them to gpurun_out/parity_counts.json and prints the totals in the pytest summary (tests/conftest.py).
+HATCH_COUNTS = []
+
+
+def parity_termination(make, n, m, batch, seed=5, adaptive=False, sqp_settings=False, diagnostics=True, max_hatch_frac=None, **kw):
     """Default-termination solves: status / iteration count / residuals / solutions against the oracle.
-    diagnostics=False skips the comparison of the reported residual norms and rho estimate (tiny QPs under adaptive rho: a
-    residual at rounding level — 0 in one summation order, 1e-16 in another — makes them incomparable)."""
+    diagnostics=False skips the comparison of the reported residual norms and rho estimate; diagnostics="stable" compares them on
+    the QPs whose reference diagnostics are themselves reproducible (tiny QPs under adaptive rho: a residual at rounding level —
+    0 in one summation order, 1e-16 in another — makes them incomparable on the others; those are counted).
+    Escape hatches, both COUNTED in HATCH_COUNTS and bounded by max_hatch_frac of the batch (default 2 % from n = 20 up, where
+    none has been observed; 10 % on the tiny shapes): `excused` = QPs whose status / iterations / rho updates may differ because
+    the reference path itself is unstable on them; `widened` = QPs on the 10x-noise-floor bar instead of 1e-6."""
+    if max_hatch_frac is None:
+        max_hatch_frac = 0.02 if n >= 20 else 0.10
+    rec = {"n": n, "m": m, "batch": batch, "seed": seed, "adaptive": bool(adaptive), "sqp_settings": bool(sqp_settings),
+           "kw": {k: str(v) for k, v in kw.items()}, "excused": 0, "widened": 0, "diag_compared": 0, "diag_unstable": 0}
+    HATCH_COUNTS.append(rec)
+    hatch_cap = max(1, int(batch * max_hatch_frac))
     P, q, A, l, u = random_qp_batch(batch, n, m, seed=seed)
     s = make(n, m, batch, **kw)
     st = s.settings
@@ -267,7 +282,8 @@ def parity_termination(make, n, m, batch, seed=5, adaptive=False, sqp_settings=F
             _, _, _, ip = oracle.solve_batch(Pp, pert(q[bad]), pert(A[bad]), pert(l[bad]), pert(u[bad]), oracle_settings(st))
             unstable |= (ip["status"] != io["status"][bad]) | (ip["iter"] != io["iter"][bad]) | (ip["rho_updates"] != io["rho_updates"][bad])
         assert unstable.all(), (bad[~unstable], info.iter[bad], io["iter"][bad])
-        assert len(bad) <= max(1, batch // 10), bad
+        rec["excused"] = int(len(bad))
+        assert len(bad) <= hatch_cap, (len(bad), hatch_cap, bad)
         keep = same
         x, y, xo, yo, zo, q, A, P = x[keep], y[keep], xo[keep], yo[keep], zo[keep], q[keep], A[keep], P[keep]
         info, io = info[keep], io[keep]
@@ -292,12 +308,37 @@ def parity_termination(make, n, m, batch, seed=5, adaptive=False, sqp_settings=F
             nx, ny = np.maximum(nx, per(xp, xo, 1e-300)), np.maximum(ny, per(yp, yo, 1.0))
         ex, ey = per(x, xo, 1e-300), per(y, yo, 1.0)
         assert (ex <= np.maximum(TOL_F64, 10 * nx)).all() and (ey <= np.maximum(TOL_F64, 10 * ny)).all(), (ex.max(), ey.max(), nx.max(), ny.max())
-        assert ((ex > TOL_F64) | (ey > TOL_F64)).sum() <= max(1, len(ex) // 10)
+        rec["widened"] = int(((ex > TOL_F64) | (ey > TOL_F64)).sum())
+        assert rec["widened"] <= hatch_cap, (rec["widened"], hatch_cap)
         tight = (ex <= TOL_F64) & (ey <= TOL_F64) & bool(diagnostics)
     # reported residual norms (diagnostics): rtol 1e-6, with an absolute floor of 1e-9 of the vectors they are
     # differences of (Ax, z / Px, A'y, q: entries agree with the oracle's to <= 4e-9 relative, observed) — 1,000x tighter
     # than the iterate bar.  (Measured against the x87 yard-stick the Schur form is the more accurate of the two, see
     # stress_parity.)
+    lk, uk = (l[keep], u[keep]) if not same.all() else (l, u)
+    if isinstance(diagnostics, str):
+        # diagnostics == "stable": compare on the QPs whose REFERENCE diagnostics are reproducible — the oracle's x87 instance and
+        # four one-ulp input perturbations leave status, iterations and rho updates alone and move res_prim / res_dual / rho_estimate
+        # by no more than a tenth of the bars below
+        assert diagnostics == "stable"
+        ld = np.longdouble
+        runs = [oracle.solve_batch(P.astype(ld), q.astype(ld), A.astype(ld), lk.astype(ld), uk.astype(ld), oracle_settings(st), dtype=ld)[3]]
+        rng = np.random.default_rng(3)
+        for _ in range(4):
+            pert = lambda a: a * (1.0 + np.where(rng.integers(0, 2, a.shape) > 0, 1.0, -1.0) * 2.0 ** -52)  # noqa: E731
+            Pp = pert(P)
+            Pp = np.tril(Pp) + np.transpose(np.tril(Pp, -1), (0, 2, 1))
+            runs.append(oracle.solve_batch(Pp, pert(q), pert(A), pert(lk), pert(uk), oracle_settings(st))[3])
+        stable = np.ones(len(x), bool)
+        for ir in runs:
+            stable &= (ir["status"] == io["status"]) & (ir["iter"] == io["iter"]) & (ir["rho_updates"] == io["rho_updates"])
+            for key in ("res_prim", "res_dual", "rho_estimate"):
+                a0, a1 = np.asarray(io[key], np.float64), np.asarray(ir[key], np.float64)
+                stable &= np.abs(a1 - a0) <= 0.1 * (RES_RTOL * np.abs(a0) + RES_ATOL)
+        rec["diag_unstable"] = int((~stable).sum())
+        tight = tight & stable
+        assert tight.sum() >= len(x) // 4, (int(tight.sum()), len(x))  # the comparison below must not be vacuous
+    rec["diag_compared"] = int(tight.sum())
     Ax = np.einsum("bij,bj->bi", A, xo)
     nrm = lambda a: np.max(np.abs(a), axis=1)  # noqa: E731
     n_prim = np.maximum(nrm(Ax), nrm(zo))

@@ -31,3 +31,39 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def _hatch_summary():
+    try:
+        import cases
+    except Exception:
+        return None
+    recs = list(cases.HATCH_COUNTS)
+    if not recs:
+        return None
+    return {"calls": len(recs), "qps": int(sum(r["batch"] for r in recs)), "excused": int(sum(r["excused"] for r in recs)),
+            "widened": int(sum(r["widened"] for r in recs)), "diag_unstable": int(sum(r["diag_unstable"] for r in recs)),
+            "records": recs}
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Parity escape hatches taken in this session (tests/cases.py::parity_termination), so that a green run says how green."""
+    s = _hatch_summary()
+    if s is None:
+        return
+    terminalreporter.write_line(
+        "parity hatches: %d parity_termination calls, %d QPs: %d excused (reference path unstable), %d on the widened bar, "
+        "%d with unstable reference diagnostics" % (s["calls"], s["qps"], s["excused"], s["widened"], s["diag_unstable"]))
+    for r in s["records"]:
+        if r["excused"] or r["widened"]:
+            terminalreporter.write_line("  n=%d m=%d batch=%d adaptive=%s sqp=%s %s: excused %d widened %d" % (
+                r["n"], r["m"], r["batch"], r["adaptive"], r["sqp_settings"], r["kw"], r["excused"], r["widened"]))
+    if _has_gpu():
+        try:
+            import json
+
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            json.dump(s, open(os.path.join(d, "parity_counts.json"), "w"), indent=1)
+        except Exception:
+            pass

@@ -34,10 +34,18 @@ REF = {  # binary -> reference sources (relative to /root/reference)
     "ref_sqp_test_autodiff": ["tests/sqp_test_autodiff.cpp", "tests/test_main.cpp"],
     "ref_bfgs_test": ["tests/bfgs_test.cpp", "tests/test_main.cpp"],
 }
+# The reference's OWN outer loop (src/sqp.cpp, with its own include/solvers/sqp.hpp and bfgs.hpp), compiled unchanged, on top of the
+# facade's QPSolver: the literal north_star boundary — SQP::solve() on the host, the GPU QP solver beneath.  `solvers/qp.hpp` must
+# resolve to the facade while `solvers/sqp.hpp` / `bfgs.hpp` resolve to the reference's files: a generated include directory of
+# one-line redirects (tests/cpp/_ref/inc, git-ignored).
+REFSRC = {
+    "refsrc_sqp_test": ["src/sqp.cpp", "tests/sqp_test.cpp", "tests/test_main.cpp"],
+    "refsrc_sqp_test_autodiff": ["src/sqp.cpp", "tests/sqp_test_autodiff.cpp", "tests/test_main.cpp"],
+}
 HOST_ONLY = ["ref_bfgs_test"]  # no QP solve inside: runs without a device
 # The one case of the reference's files that does not pass: the n = 3 half of SQPAutoDiff.TestRosenbrock.  The algorithm as
 # written stalls at (1, 1, 0) there — the CPU oracle (double and x87 QP arithmetic) takes the identical path; DESIGN.md section 7.
-KNOWN_FAILURES = {"ref_sqp_test_autodiff": ["SQPAutoDiff.TestRosenbrock"]}
+KNOWN_FAILURES = {"ref_sqp_test_autodiff": ["SQPAutoDiff.TestRosenbrock"], "refsrc_sqp_test_autodiff": ["SQPAutoDiff.TestRosenbrock"]}
 
 
 def _link_args(depth):
@@ -65,6 +73,29 @@ def build_reference_tests():
     for name, srcs in REF.items():
         exe = os.path.join(REFDIR, name + ".bin")
         cmd = ["g++", "-std=c++14", "-O1"] + INC + ["-I" + os.path.join(CPP, "gtest_stub"), "-o", exe]
+        cmd += [os.path.join(REFERENCE, s) for s in srcs] + _link_args(3)
+        subprocess.check_call(cmd)
+        out.append(exe)
+    return out
+
+
+def build_reference_sqp_source():
+    """src/sqp.cpp of the reference + its own tests, over compat/solvers/qp.hpp (only where /root/reference exists)."""
+    if not os.path.isdir(REFERENCE):
+        return [os.path.join(REFDIR, k + ".bin") for k in REFSRC if os.path.exists(os.path.join(REFDIR, k + ".bin"))]
+    inc = os.path.join(REFDIR, "inc", "solvers")
+    os.makedirs(inc, exist_ok=True)
+    redirects = {"qp.hpp": os.path.join(ROOT, "include", "sqp_hip", "compat", "solvers", "qp.hpp"),
+                 "sqp.hpp": os.path.join(REFERENCE, "include", "solvers", "sqp.hpp"),
+                 "bfgs.hpp": os.path.join(REFERENCE, "include", "solvers", "bfgs.hpp")}
+    for name, target in redirects.items():
+        with open(os.path.join(inc, name), "w") as f:
+            f.write("#pragma once\n#include \"%s\"\n" % target)
+    out = []
+    for name, srcs in REFSRC.items():
+        exe = os.path.join(REFDIR, name + ".bin")
+        cmd = ["g++", "-std=c++14", "-O1", "-I" + os.path.join(REFDIR, "inc"), "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(CPP, "eigen_stub"), "-I" + os.path.join(CPP, "gtest_stub"), "-o", exe]
         cmd += [os.path.join(REFERENCE, s) for s in srcs] + _link_args(3)
         subprocess.check_call(cmd)
         out.append(exe)
@@ -120,6 +151,34 @@ def test_reference_gtest_files_pass_against_the_facade():
         failed = sorted(l.split("]")[1].strip() for l in p.stdout.splitlines() if l.startswith("[  FAILED  ]"))
         assert failed == sorted(KNOWN_FAILURES.get(name, [])), p.stdout + p.stderr
         assert "tests ran" in p.stdout
-        if name in KNOWN_FAILURES:
-            # ... and it fails the way the oracle says it must: the n = 3 run ends at (1, 1, ~0)
-            assert "primal solution 1 1 1.9" in p.stdout, p.stdout
+
+
+def _solution_lines(exe):
+    env = dict(os.environ, SQP_HIP_STUB_FULL_PRECISION="1")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    sols = [l for l in p.stdout.splitlines() if l.startswith(("primal solution", "dual solution"))]
+    verdicts = [l for l in p.stdout.splitlines() if l.startswith(("[       OK ]", "[  FAILED  ]"))]
+    return p, sols, verdicts
+
+
+@pytest.mark.gpu
+def test_reference_sqp_source_over_the_facade_equals_the_dropin_class_bit_for_bit():
+    """The reference's src/sqp.cpp (unchanged, its own sqp.hpp / bfgs.hpp) driving the facade's QPSolver — the literal north_star
+    boundary — against compat/solvers/sqp.hpp (the batched driver with one instance) on the reference's own SQP tests: same QP
+    kernels, same host arithmetic order, so every printed primal / dual solution must agree to the last digit and the same tests
+    must pass.  Any difference is a bug in one of the two outer loops."""
+    build_reference_tests()
+    exes = build_reference_sqp_source()
+    if not exes:
+        pytest.skip("tests/cpp/_ref/refsrc_*.bin not built (needs /root/reference at build time)")
+    for exe in exes:
+        name = os.path.basename(exe)[:-4]
+        twin = os.path.join(REFDIR, name.replace("refsrc_", "ref_") + ".bin")
+        pa, sa, va = _solution_lines(exe)
+        pb, sb, vb = _solution_lines(twin)
+        print(pa.stdout)
+        assert "tests ran" in pa.stdout and len(sa) >= 6, pa.stdout + pa.stderr
+        assert sa == sb, "\n".join("%s | %s" % ab for ab in zip(sa, sb))
+        assert va == vb
+        failed = sorted(l.split("]")[1].strip() for l in va if l.startswith("[  FAILED  ]"))
+        assert failed == sorted(KNOWN_FAILURES.get(name, [])), pa.stdout

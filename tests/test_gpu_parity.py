@@ -367,8 +367,9 @@ def test_lane_kernel_paths():
     cases.parity_fixed_iters(make_gpu, 2, 3, 64, iters=100, alpha=1.6)
     cases.parity_fixed_iters(make_gpu, 4, 6, 64, iters=100, dtype=np.float32)
     for kw in (dict(), dict(adaptive=True), dict(sqp_settings=True)):
-        cases.parity_termination(make_gpu, 4, 6, 200, diagnostics=not kw, **kw)
-        cases.parity_termination(make_gpu, 2, 3, 200, diagnostics=not kw, **kw)
+        # residual norms / rho estimate are compared on the QPs whose reference diagnostics are themselves reproducible
+        cases.parity_termination(make_gpu, 4, 6, 200, diagnostics=True if not kw else "stable", **kw)
+        cases.parity_termination(make_gpu, 2, 3, 200, diagnostics=True if not kw else "stable", **kw)
     cases.warm_start_and_resolve(make_gpu, n=4, m=6)
     cases.set_state_warm_start(make_gpu, n=3, m=5)
     cases.shared_matrices(make_gpu, n=4, m=6)
