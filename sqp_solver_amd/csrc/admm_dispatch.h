@@ -6,7 +6,6 @@
 
 #include "admm_lane_kernel.h"
 #include "admm_wg_kernel.h"
-#include "admm_wgr_kernel.h"
 
 namespace sqph {
 
@@ -75,29 +74,6 @@ template <typename TIN>
 int wg_nocheck_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name, int skip);
 extern template int wg_nocheck_try_launch<double>(const KArgs<double, double> &, hipStream_t, const char **, int);
 extern template int wg_nocheck_try_launch<float>(const KArgs<double, float> &, hipStream_t, const char **, int);
-
-// row-split workgroup kernels (admm_wgr_kernel.h: one barrier per iteration, stacked tile rows), tried ahead of the column-split ones
-template <typename TIN>
-int wgr_nocheck_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name);
-extern template int wgr_nocheck_try_launch<double>(const KArgs<double, double> &, hipStream_t, const char **);
-extern template int wgr_nocheck_try_launch<float>(const KArgs<double, float> &, hipStream_t, const char **);
-template <typename TIN>
-inline int wgr_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
-#ifdef SQPH_EXPERIMENTS
-    static const bool off = getenv("SQPH_NO_WGR") != nullptr;
-    if (off) return 0;
-#endif
-    if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0)) return wgr_nocheck_try_launch<TIN>(a, stream, name);
-#define SQPH_WGR_CASE(NW_, R_, C_, TR_, TC_, TW_, TS_, W_)                                                                            \
-    if (SQPH_WGR_FITS(a, R_, C_, TR_, TC_, TW_, TS_)) {                                                                              \
-        hipLaunchKernelGGL((admm_wgr_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, TS_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
-        *name = "wgr" #NW_ "_" #R_ "x" #C_ "_" #TS_ "x" #TC_ "_w" #W_;                                                                \
-        return hipGetLastError() == hipSuccess ? 1 : -1;                                                                              \
-    }
-    SQPH_WGR_SHAPES(SQPH_WGR_CASE)
-#undef SQPH_WGR_CASE
-    return 0;
-}
 
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>

@@ -129,6 +129,8 @@ struct WgLayout {
     static constexpr int O_AS = ev(O_SJ + NP);
     static constexpr int O_WL = O_AS + R * SSTR;
     static constexpr int CH = (C + 1) / 2;  // W is staged half of its columns (CH column groups) at a time
+    // P staged in LDS behind As while S = A'RA is accumulated (LDS-DMA issued ahead of the A tile's loads, see stage_P_async)
+    static constexpr int O_PST = ev(O_AS + R * SSTR);
     static constexpr int SETUP = O_WL + CH * TC * WSTR;
     static constexpr int O_RED = O_STAGE + MP + 2 * NP + 16;  // workgroup max scratch (residual checks)
     static constexpr int STAGE = mx(STAGE_X + STAGE_Y, MP + 2 * NP + 16 + 8 * NW);
@@ -144,6 +146,8 @@ struct WgLayout {
     static constexpr int O_RINV = O_UPV + MP;  // 1/rho of the owned constraint (changes only at a refactorisation)
     static constexpr int TOTAL = ev(O_RINV + MP);
     static_assert(O_AS2 + R * SSTR <= O_QV, "build_B stages all of W and a block of A rows in [0, O_QV)");
+    // the workgroup kernels whose scratch has room for an n x n block of doubles take P through LDS
+    static constexpr bool P_STAGED = NW > 0 && O_PST + NP * NP <= O_QV;
     static constexpr int slot(int j) { return SLOT * (j / TC) + (j % TC); }
 };
 
@@ -482,11 +486,43 @@ struct WgKernel {
         }
     }
 
+    // P -> LDS, asynchronously (gfx950 LDS-DMA, global_load_lds_dwordx4: 64 lanes x 16 bytes land contiguously at a wave-uniform LDS
+    // base, no VGPRs in between).  Issued ahead of the A tile's loads, so the two HBM streams of a set-up overlap, and every lane's
+    // read is coalesced — the factor's own access P[min(i,j) n + max(i,j)] (lower triangle only, qp.cpp:159-189) is a stride-n
+    // gather for half of the tile (measured: ~20 k of the set-up's 191 k cycles waiting for it).  Returns false (nothing issued)
+    // when the block is not 16-byte aligned; the factor then reads P from global memory as before.
+    static __device__ __forceinline__ bool stage_P_async(const TIN *__restrict__ gP, int n, T *lds, int t) {
+#ifdef SQPH_NO_P_STAGE  // A/B experiment builds only
+        return false;
+#endif
+        if constexpr (!L::P_STAGED) {
+            return false;
+        } else {
+            const unsigned bytes = (unsigned)(n * n) * (unsigned)sizeof(TIN);
+            if ((reinterpret_cast<unsigned long long>(gP) & 15ull) != 0) return false;
+            char *dst = reinterpret_cast<char *>(lds + L::O_PST);
+#ifdef SQPH_SIM
+            for (unsigned e = (unsigned)t; e < (unsigned)(n * n); e += (unsigned)NT) reinterpret_cast<TIN *>(dst)[e] = gP[e];
+#else
+            const char *src = reinterpret_cast<const char *>(gP);
+            const unsigned full = bytes & ~15u;
+            for (unsigned off = (unsigned)(t >> 6) * 1024u + (unsigned)(t & 63) * 16u; off < full; off += (unsigned)NT * 16u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(dst + (off - (unsigned)(t & 63) * 16u)), 16, 0, 0);
+            if ((bytes & 15u) && t == 0) {  // n odd with 8-byte elements (or n n not a multiple of 4 floats): the tail by a plain load
+                for (unsigned e = full / (unsigned)sizeof(TIN); e < (unsigned)(n * n); e++) reinterpret_cast<TIN *>(dst)[e] = gP[e];
+            }
+#endif
+            return true;
+        }
+    }
+
     // ------------------------------------------------------------------ factor (see admm_generic.h factor_schur)
     // Scratch inside the staging area: rho[MP] | rowbuf[NP + 1] | sj[NP]   (doubles)
     // `at` is the A register tile (rows R s + r, columns TC c + k); it is only read here.
+    // p_staged: P lies in LDS at O_PST (stage_P_async was issued before the call; block-uniform)
     static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const T (&at)[TR][TC], int n, int m, T sigma,
-                                                  T *lds, int t, int r, int c, T (&wt)[TW][TC] SQPH_STICK_ARGS) {
+                                                  T *lds, int t, int r, int c, T (&wt)[TW][TC], bool p_staged SQPH_STICK_ARGS) {
         T *rho_l = lds + L::O_RHO;
         T *rowbuf = lds + L::O_ROWBUF;
         T *sjv = lds + L::O_SJ;
@@ -533,12 +569,16 @@ struct WgKernel {
                     for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
             }
         }
+#ifndef SQPH_SIM
+        if (L::P_STAGED && p_staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the P block has landed in LDS
+#endif
         wsync();
         for (int e = t; e < L::NP + 2; e += NT) {
             rowbuf[e] = 0;
             if (e < L::NP) sjv[e] = T(1);
         }
         wsync();
+        const TIN *Pst = reinterpret_cast<const TIN *>(lds + L::O_PST);
 #pragma unroll
         for (int u = 0; u < TW; u++) {
             const int i = R * u + r;
@@ -548,7 +588,7 @@ struct WgKernel {
                 const bool ok = i < n && j < n;
                 const int lo = i > j ? i : j, hi = i > j ? j : i;
                 // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>)
-                const T p = ok ? (T)gP[(long)hi * n + lo] : T(0);
+                const T p = ok ? ((L::P_STAGED && p_staged) ? (T)Pst[hi * n + lo] : (T)gP[(long)hi * n + lo]) : T(0);
                 wt[u][k] = ok ? (wt[u][k] + p + (i == j ? sigma : T(0))) : T(0);
                 if (ok && i == j) sjv[j] = wt[u][k];  // the diagonal, for the Jacobi scaling
             }
@@ -778,9 +818,10 @@ struct WgKernel {
                 SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(m_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_V(t_f);
                 SQPH_OPAQUE_S(gA_f); SQPH_OPAQUE_S(gP_f);
                 SQPH_STICK(7)
+                const bool p_staged = stage_P_async(gP_f, n_f, lds, t_f);  // P -> LDS in flight next to the loads of A
                 load_A_tile(gA_f, n_f, m_f, r_f, c_f, at);  // the only read of A from global memory per factorisation
                 SQPH_STICK(0)
-                const bool ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt SQPH_STICK_PASS);
+                const bool ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt, p_staged SQPH_STICK_PASS);
                 SQPH_STICK(4)
                 // the factor is kept for later solve() calls unless the host asked for a fused setup+solve without it
                 if (!(mode & MODE_NO_FACTOR_STORE)) store_sq_tile(gW, n_f, r_f, c_f, wt);
@@ -1184,7 +1225,7 @@ struct WgKernel {
                     int n_f = n, m_f = m, r_f = r, c_f = c, t_f = t, qp_f = qp;
                     SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(m_f); SQPH_OPAQUE_V(r_f); SQPH_OPAQUE_V(c_f); SQPH_OPAQUE_V(t_f); SQPH_OPAQUE_V(qp_f);
                     load_A_tile(a.A + (long)qp_f * a.sA, n_f, m_f, r_f, c_f, at);
-                    ok = factor(a.P + (long)qp_f * a.sP, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt);
+                    ok = factor(a.P + (long)qp_f * a.sP, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt, false);
                     if (!(mode & MODE_NO_FACTOR_STORE)) store_sq_tile(a.Sinv + (long)qp_f * 2 * n_f * n_f, n_f, r_f, c_f, wt);
                 }
                 wsync();

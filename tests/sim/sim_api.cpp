@@ -8,7 +8,6 @@
 #include "../../sqp_solver_amd/csrc/admm_generic.h"
 #include "../../sqp_solver_amd/csrc/admm_lane_kernel.h"
 #include "../../sqp_solver_amd/csrc/admm_wg_kernel.h"
-#include "../../sqp_solver_amd/csrc/admm_wgr_kernel.h"
 #include "../../sqp_solver_amd/csrc/admm_csr_kernel.h"
 
 extern "C" {
@@ -59,15 +58,13 @@ int run_generic(const SimArgs &s, int nt) {
 
 extern "C" {
 
-// variant: 0 = generic (nt threads per QP); 2 = workgroup-tiled; 4 / 5 = four / two QPs per wavefront; 6 = one QP per lane;
-// 8 = workgroup-tiled, row-split (admm_wgr_kernel.h)
+// variant: 0 = generic (nt threads per QP); 2 = workgroup-tiled; 4 / 5 = four / two QPs per wavefront; 6 = one QP per lane
 int sim_run(const SimArgs *s, int variant, int dtype, int nt) {
     if (variant == 0) return dtype == SQPH_F32 ? run_generic<float>(*s, nt) : run_generic<double>(*s, nt);
     if (variant == 5) return dtype == SQPH_F32 ? sqph::sim_run_g32<float>(convert<float>(*s)) : sqph::sim_run_g32<double>(convert<double>(*s));
     if (variant == 4) return dtype == SQPH_F32 ? sqph::sim_run_g16<float>(convert<float>(*s)) : sqph::sim_run_g16<double>(convert<double>(*s));
     if (variant == 7) return dtype == SQPH_F32 ? sqph::sim_run_lane<float, float>(convert<float>(*s)) : -1;
     if (variant == 6) return dtype == SQPH_F32 ? sqph::sim_run_lane<float>(convert<float>(*s)) : sqph::sim_run_lane<double>(convert<double>(*s));
-    if (variant == 8) return dtype == SQPH_F32 ? sqph::sim_run_wgr<float>(convert<float>(*s)) : sqph::sim_run_wgr<double>(convert<double>(*s));
     if (variant == 2) return dtype == SQPH_F32 ? sqph::sim_run_wg<float>(convert<float>(*s)) : sqph::sim_run_wg<double>(convert<double>(*s));
     return -1;
 }

@@ -12,7 +12,7 @@ SIMDIR = os.path.join(HERE, "sim")
 LIB = os.path.join(SIMDIR, "libsqph_sim.so")
 
 MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET, MODE_NO_FACTOR_STORE, MODE_REFACTOR, MODE_SAME_MATRICES = 1, 2, 4, 8, 16, 32, 64
-GENERIC, WG, CSR, G16, G32, LANE, LANE_F32, WGR = 0, 2, 3, 4, 5, 6, 7, 8
+GENERIC, WG, CSR, G16, G32, LANE, LANE_F32 = 0, 2, 3, 4, 5, 6, 7
 
 
 class SimArgs(ctypes.Structure):

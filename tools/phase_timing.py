@@ -21,8 +21,6 @@ s.setup_solve(*args)
 s.setup_solve(*args)
 x, y, z, info = s.solution()
 names = ["bar1", "stage1", "bar2", "reduce_y1", "bar3", "stage2", "bar4", "update"]
-if s.kernel_name().startswith("wgr"):
-    names = ["stage1", "barrier", "reduce_y1", "stage2", "owners", "-", "-", "-"]
 for nm, arr in (("wave0", x[:, :8]), ("wave1", y[:, 64:72])):
     if arr.shape[1] < 8: continue
     t = arr.mean(axis=0) / 200.0
