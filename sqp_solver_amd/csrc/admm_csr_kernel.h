@@ -261,26 +261,43 @@ struct CsrKernel {
             }
         }
         __syncthreads();
-        // fill: slot order inside a column is arbitrary here ...
+        // fill: slot order inside a column is arbitrary here (it depends on the order the atomics were served) ...
+        unsigned *tmp = reinterpret_cast<unsigned *>(lds + L.o_stage);  // the partial-sum staging area is idle during the set-up
+        const bool ranked = (size_t)nnz * sizeof(unsigned) <= (size_t)L.o_tcol * sizeof(T);
+        unsigned *fill = ranked ? tmp : csc;
         for (int i = t; i < m; i += NT) {
             for (int e = rowptr[i]; e < rowptr[i + 1]; e++) {
                 const int j = col[e];
                 const int slot = lds_atomic_inc(&ccur[j]);
-                csc[slot] = ((unsigned)i << 16) | (unsigned)e;
+                fill[slot] = ((unsigned)i << 16) | (unsigned)e;
             }
         }
         __syncthreads();
-        // ... and made canonical by sorting every column on (row, position)
-        for (int j = t; j < n; j += NT) {
-            const int e0 = colptr[j], e1 = colptr[j + 1];
-            for (int e = e0 + 1; e < e1; e++) {
-                const unsigned key = csc[e];
-                int f = e - 1;
-                while (f >= e0 && csc[f] > key) {
-                    csc[f + 1] = csc[f];
-                    f--;
+        // ... and made canonical (ordered by row inside every column: deterministic sums) ...
+        if (ranked) {
+            // ... by ranking: the keys of a column are distinct, so the final slot of an entry is the number of smaller keys in its
+            // column — one lane per ENTRY, all 1024 lanes busy (round 2 sorted every column by insertion with one lane per COLUMN:
+            // 200 lanes, ~200 dependent LDS operations each; the set-up's load phase was 127 k cycles)
+            for (int s0 = t; s0 < nnz; s0 += NT) {
+                const unsigned key = tmp[s0];
+                const int j = col[key & 0xffffu];
+                const int e0 = colptr[j], e1 = colptr[j + 1];
+                int rank = 0;
+                for (int f = e0; f < e1; f++) rank += tmp[f] < key ? 1 : 0;
+                csc[e0 + rank] = key;
+            }
+        } else {
+            for (int j = t; j < n; j += NT) {
+                const int e0 = colptr[j], e1 = colptr[j + 1];
+                for (int e = e0 + 1; e < e1; e++) {
+                    const unsigned key = csc[e];
+                    int f = e - 1;
+                    while (f >= e0 && csc[f] > key) {
+                        csc[f + 1] = csc[f];
+                        f--;
+                    }
+                    csc[f + 1] = key;
                 }
-                csc[f + 1] = key;
             }
         }
         __syncthreads();
@@ -343,6 +360,54 @@ struct CsrKernel {
         __syncthreads();
     }
 
+    // pivots k = 32 AK + rk, rk = 0..31 (see eliminate): g[j] = W-part of row k (j < k) | d + 1 (j = k) | column k of the trailing
+    // matrix (j > k); every entry (i,j), i > k, j <= i, gets  e -= (g[i]/d) * g[j].  One barrier per pivot (g is double-buffered).
+    template <int AK>
+    static __device__ __forceinline__ void pivot_rows(int n, T *g, T *dsv, int NPl, int r, int c, bool &good, T (&w)[NE]) {
+        if constexpr (AK < TT) {
+#pragma unroll 1
+            for (int rk = 0; rk < 32; rk++) {
+                const int k = 32 * AK + rk;
+                if (k >= n) break;
+                T *gk = g + (k & 1) * (NPl + 1);
+                if (c == rk) {  // my column group holds column k: entries (a, AK), rows i = r + 32a > k
+                    if (r > rk) gk[r + 32 * AK] = w[idx(AK, AK)];
+#pragma unroll
+                    for (int a = AK + 1; a < TT; a++) gk[r + 32 * a] = w[idx(a, AK)];
+                }
+                if (r == rk) {  // my row group holds row k: entries (AK, b), columns j = c + 32b < k, and the pivot
+#pragma unroll
+                    for (int b = 0; b < AK; b++) gk[c + 32 * b] = w[idx(AK, b)];
+                    if (c < rk) gk[c + 32 * AK] = w[idx(AK, AK)];
+                    if (c == rk) {
+                        gk[k] = w[idx(AK, AK)] + T(1);
+                        gk[NPl] = w[idx(AK, AK)];
+                        dsv[k] = w[idx(AK, AK)];
+                    }
+                }
+                __syncthreads();
+                const T d = gk[NPl];
+                // a bad pivot is only recorded (block-uniform: every lane reads the same word); leaving the loop from here
+                // costs the whole tile its registers (the extra exit made the allocator spill 120 VGPRs)
+                if (!(d > T(0)) || !(d * T(0) == T(0))) good = false;
+                const T dinv = T(1) / d;
+                T gc[TT];
+#pragma unroll
+                for (int b = 0; b < TT; b++) gc[b] = gk[c + 32 * b];
+                // rows of tile row AK with i <= k get l_i = 0 (branch-free: a conditional update keeps old and new tile rows alive
+                // side by side and spilled the tile); the tile rows above AK are finished, the ones below are all beyond k
+#pragma unroll
+                for (int a = AK; a < TT; a++) {
+                    const T gi = gk[r + 32 * a];
+                    const T li = (a > AK || r > rk) ? -(gi * dinv) : T(0);
+#pragma unroll
+                    for (int b = 0; b <= a; b++) w[idx(a, b)] = wg_fma(li, gc[b], w[idx(a, b)]);
+                }
+            }
+            pivot_rows<AK + 1>(n, g, dsv, NPl, r, c, good, w);
+        }
+    }
+
     // In-register factorisation of the tile: Jacobi scaling, forward elimination of [S | I] in place (admm_generic.h:
     // factor_schur), final scaling to W = D^-1/2 L^-1 D_J^-1/2.  One broadcast vector g per pivot k:
     //   g[j] = W-part of row k (j < k) | d + 1 (j = k) | column k of the trailing matrix (j > k)
@@ -392,59 +457,13 @@ struct CsrKernel {
                 for (int b = 0; b <= a; b++) w[idx(a, b)] = w[idx(a, b)] * sr[a] * sc[b];
         }
         bool good = true;
-        for (int k = 0; k < n; k++) {
-            const int ak = k >> 5, rk = k & 31;
-            T *gk = g + (k & 1) * (NPl + 1);
-            // publish g for pivot k
-            if (c == rk) {  // my column group holds column k: entries (a, ak), rows i = r + 32a > k
-#pragma unroll
-                for (int b = 0; b < TT; b++) {
-                    if (b == ak) {
-#pragma unroll
-                        for (int a = b; a < TT; a++) {
-                            const int i = r + 32 * a;
-                            if (i > k) gk[i] = w[idx(a, b)];
-                        }
-                    }
-                }
-            }
-            if (r == rk) {  // my row group holds row k: entries (ak, b), columns j = c + 32b < k, and the pivot
-#pragma unroll
-                for (int a = 0; a < TT; a++) {
-                    if (a == ak) {
-#pragma unroll
-                        for (int b = 0; b <= a; b++) {
-                            const int j = c + 32 * b;
-                            if (j < k) gk[j] = w[idx(a, b)];
-                            if (j == k) {
-                                gk[j] = w[idx(a, b)] + T(1);
-                                gk[NPl] = w[idx(a, b)];
-                                dsv[k] = w[idx(a, b)];
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            const T d = gk[NPl];
-            // a bad pivot is only recorded (block-uniform: every lane reads the same word); leaving the loop from here
-            // costs the whole tile its registers (the extra exit made the allocator spill 120 VGPRs)
-            if (!(d > T(0)) || !(d * T(0) == T(0))) good = false;
-            const T dinv = T(1) / d;
-            T gc[TT];
-#pragma unroll
-            for (int b = 0; b < TT; b++) gc[b] = gk[c + 32 * b];
-            // branch-free on purpose: rows i <= k get l_i = 0 (a conditional update keeps old and new tile rows alive
-            // side by side and spilled the tile)
-#pragma unroll
-            for (int a = 0; a < TT; a++) {
-                const int i = r + 32 * a;
-                const T li = (i > k) ? -(gk[i] * dinv) : T(0);
-#pragma unroll
-                for (int b = 0; b <= a; b++) w[idx(a, b)] = wg_fma(li, gc[b], w[idx(a, b)]);
-            }
-            // entries of g for columns/rows outside [0,n) are never written: zero from the initial clear below
-        }
+        // The pivots are walked tile row by tile row: k = 32 ak + rk with ak a COMPILE-TIME constant (seven specialised copies of the
+        // pivot step at TT = 7) and rk the run-time inner loop.  With ak known, the owners publish exactly the TT - ak column entries
+        // and ak + 1 row entries that exist (the run-time version tested all 28 tile entries against ak: ~60 predicated stores per
+        // pivot), and only the tile rows a >= ak are updated (28, 27, 25, 22, 18, 13, 7 FMAs instead of 28) — the loop is bound by
+        // the instruction issue of the 16 waves (round 2: 2.65 k cycles per pivot at ~100 instructions).
+        pivot_rows<0>(n, g, dsv, NPl, r, c, good, w);
+        // entries of g for columns/rows outside [0,n) are never written: zero from the initial clear of the caller
         __syncthreads();
         {
             T rs[TT], sc[TT];

@@ -46,6 +46,17 @@
 #define SQPH_CHECK_UNROLL 1
 #endif
 
+// Measurement only (tests/test_f32_tiles.py): what fp32 STORAGE of the B / W' register tiles with fp64
+// accumulation would do to the results — the tiles are rounded through float once, when they are built.  Never in the shipped
+// library: -DSQPH_F32_TILE_STORAGE experiment builds, or the emulator's run-time switch.
+#if defined(SQPH_SIM)
+#define SQPH_TILE_QUANT(x) (::sqph_sim::tile_quant() ? (double)(float)(x) : (double)(x))
+#elif defined(SQPH_F32_TILE_STORAGE)
+#define SQPH_TILE_QUANT(x) ((double)(float)(x))
+#else
+#define SQPH_TILE_QUANT(x) (x)
+#endif
+
 namespace sqph {
 
 typedef double sqph_v2 __attribute__((vector_size(16)));
@@ -379,7 +390,7 @@ struct WgKernel {
                 }
             }
 #pragma unroll
-            for (int k = 0; k < TC; k++) at[s][k] = acc[k];
+            for (int k = 0; k < TC; k++) at[s][k] = SQPH_TILE_QUANT(acc[k]);
         }
         // The W' tile (vt[u][k] = W[TC c + k][R u + r]) is picked up from Wf by load_vt_lds() once the set-up block — and with it
         // the W tile's registers — has ended.  (Computing vt inside this block, next to the live W tile, put 20 tile registers of
@@ -395,7 +406,7 @@ struct WgKernel {
             T tmp[L::SLOT];
             wg_read<L::SLOT>(lds + (jp < L::NP ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
 #pragma unroll
-            for (int k = 0; k < TC; k++) vt[u][k] = (jp < n && TC * c + k < n) ? tmp[k] : T(0);
+            for (int k = 0; k < TC; k++) vt[u][k] = (jp < n && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
         }
         wsync();
     }
@@ -498,12 +509,12 @@ struct WgKernel {
         if constexpr (!L::P_STAGED) {
             return false;
         } else {
-            const unsigned bytes = (unsigned)(n * n) * (unsigned)sizeof(TIN);
             if ((reinterpret_cast<unsigned long long>(gP) & 15ull) != 0) return false;
             char *dst = reinterpret_cast<char *>(lds + L::O_PST);
 #ifdef SQPH_SIM
             for (unsigned e = (unsigned)t; e < (unsigned)(n * n); e += (unsigned)NT) reinterpret_cast<TIN *>(dst)[e] = gP[e];
 #else
+            const unsigned bytes = (unsigned)(n * n) * (unsigned)sizeof(TIN);
             const char *src = reinterpret_cast<const char *>(gP);
             const unsigned full = bytes & ~15u;
             for (unsigned off = (unsigned)(t >> 6) * 1024u + (unsigned)(t & 63) * 16u; off < full; off += (unsigned)NT * 16u)
@@ -1506,34 +1517,6 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_nocheck_kernel(KArgs<dou
     WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false>(a, lds);
 }
 
-// shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins.  The 32 x 8 grids are for
-// problems with many more constraints than variables (m <= 224 with n <= 16 / 32 / 56): measured 4,096 x (10,150) 1.43 ms against
-// 7.73 ms in the 16 x 16 / 13 x 7 shape it fell into before, 4,096 x (50,150) 2.94 against 8.68 ms; the 64 x 8 grids (8 waves) carry
-// m <= 448 with n <= 32 / 56: 2,048 x (50,400) 3.98 ms against 45.5 ms in the generic kernel; the 16 x 16 grids with 2 / 4 / 8 tile rows
-// serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x)
-// (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
-#ifdef SQPH_SLIM
-#define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
-#define SQPH_G32_SHAPES(X)
-#define SQPH_G16_SHAPES(X)
-#else
-#define SQPH_WG_SHAPES(X)        \
-    X(1, 8, 8, 1, 1, 1, 4)       \
-    X(1, 8, 8, 3, 2, 2, 4)       \
-    X(1, 8, 8, 5, 3, 3, 3)       \
-    X(1, 8, 8, 8, 4, 4, 2)       \
-    X(2, 16, 8, 7, 7, 4, 2)      \
-    X(4, 16, 16, 8, 4, 4, 2)     \
-    X(4, 32, 8, 7, 2, 1, 4)      \
-    X(4, 32, 8, 7, 4, 1, 3)      \
-    X(4, 32, 8, 7, 7, 2, 2)      \
-    X(4, 16, 16, 2, 7, 7, 2)     \
-    X(4, 16, 16, 4, 7, 7, 2)     \
-    X(4, 16, 16, 8, 7, 7, 2)     \
-    X(4, 16, 16, 13, 7, 7, 1)    \
-    X(8, 64, 8, 7, 4, 1, 2)      \
-    X(8, 64, 8, 7, 7, 1, 2)
-
 // four QPs per wavefront (run_group): block = one wavefront, LDS = 4 slices
 template <typename TIN, int TR, int TC, int WPE>
 __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a) {
@@ -1555,6 +1538,39 @@ __global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a)
 #endif
     WgKernel<TIN, 0, 8, 4, TR, TC, TW>::run_group(a, lds);
 }
+
+// shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins.  The 32 x 8 grids are for
+// problems with many more constraints than variables (m <= 224 with n <= 16 / 32 / 56): measured 4,096 x (10,150) 1.43 ms against
+// 7.73 ms in the 16 x 16 / 13 x 7 shape it fell into before, 4,096 x (50,150) 2.94 against 8.68 ms; the 64 x 8 grids (8 waves) carry
+// m <= 448 with n <= 32 / 56: 2,048 x (50,400) 3.98 ms against 45.5 ms in the generic kernel; the 16 x 16 grids with 2 / 4 / 8 tile rows
+// serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x)
+// (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
+#ifdef SQPH_SLIM
+#define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
+#ifdef SQPH_SLIM_G32  // ... plus the C2 shape (two QPs per wavefront)
+#define SQPH_G32_SHAPES(X) X(5, 5, 3, 2)
+#else
+#define SQPH_G32_SHAPES(X)
+#endif
+#define SQPH_G16_SHAPES(X)
+#else
+#define SQPH_WG_SHAPES(X)        \
+    X(1, 8, 8, 1, 1, 1, 4)       \
+    X(1, 8, 8, 3, 2, 2, 4)       \
+    X(1, 8, 8, 5, 3, 3, 3)       \
+    X(1, 8, 8, 8, 4, 4, 2)       \
+    X(2, 16, 8, 7, 7, 4, 2)      \
+    X(4, 16, 16, 8, 4, 4, 2)     \
+    X(4, 32, 8, 7, 2, 1, 4)      \
+    X(4, 32, 8, 7, 4, 1, 3)      \
+    X(4, 32, 8, 7, 7, 2, 2)      \
+    X(4, 16, 16, 2, 7, 7, 2)     \
+    X(4, 16, 16, 4, 7, 7, 2)     \
+    X(4, 16, 16, 8, 7, 7, 2)     \
+    X(4, 16, 16, 13, 7, 7, 1)    \
+    X(8, 64, 8, 7, 4, 1, 2)      \
+    X(8, 64, 8, 7, 7, 1, 2)
+
 // shapes {TR, TC, TW, WPE}.  Measured (200 iterations): n = 20, m = 40 at 4,096 QPs 0.415 ms against 0.477 ms for four QPs per
 // wave (10 x 5 tiles, one wave per SIMD) and 0.513 ms for one QP per wave; an 8 x 8 tile shape (m <= 64, n <= 32, 322 VGPRs)
 // lost to the one-wave-per-QP kernel (3.19 vs 2.44 ms at 16,384 QPs) and is not compiled.

@@ -56,6 +56,8 @@ inline Block *&cur_block() {
     return b;
 }
 
+inline bool &tile_quant() { static bool q = false; return q; }  // see SQPH_TILE_QUANT (admm_wg_kernel.h)
+
 inline dim3 &tls_threadIdx() { static dim3 v; return v; }
 inline dim3 &tls_blockIdx() { static dim3 v; return v; }
 inline dim3 &tls_blockDim() { static dim3 v; return v; }

@@ -47,6 +47,25 @@ sqph::KArgs<double, TIN> convert(const SimArgs &s) {
     return a;
 }
 
+// measurement only (tests/test_f32_tiles.py): the generic kernel with fp32 ARITHMETIC — state arrays of the SimArgs are float here
+int run_generic_f32_arith(const SimArgs &s, int nt) {
+    using T = float;
+    sqph::KArgs<T, float> a{};
+    a.n = s.n; a.m = s.m; a.batch = s.batch; a.mode = s.mode;
+    a.P = (const float *)s.P; a.q = (const float *)s.q; a.A = (const float *)s.A; a.l = (const float *)s.l; a.u = (const float *)s.u;
+    a.sP = s.sP; a.sq = s.sq; a.sA = s.sA; a.sl = s.sl; a.su = s.su;
+    a.x = (T *)s.x; a.z = (T *)s.z; a.y = (T *)s.y; a.rho_vec = (T *)s.rho_vec; a.ctype = s.ctype;
+    a.rho = (T *)s.rho; a.info = s.info; a.Sinv = (T *)s.Sinv; a.At = (T *)s.At;
+    a.rho0 = (T)s.rho0; a.sigma = (T)s.sigma; a.alpha = (T)s.alpha; a.eps_rel = (T)s.eps_rel; a.eps_abs = (T)s.eps_abs; a.rho_tol = (T)s.rho_tol;
+    a.rho_min = 1e-6f; a.rho_max = 1e+6f; a.eq_tol = 1e-4f; a.rho_eq_factor = 1e+3f; a.loose_thresh = 1e+16f;
+    a.regul = std::numeric_limits<float>::epsilon();
+    a.max_iter = s.max_iter; a.check_termination = s.check_termination; a.warm_start = s.warm_start;
+    a.adaptive_rho = s.adaptive_rho; a.adaptive_rho_interval = s.adaptive_rho_interval;
+    const size_t lds = sqph::generic_lds_elems<float>(s.n, s.m, nt) * sizeof(float);
+    sqph_sim::launch(sqph::admm_generic_kernel<float, float>, dim3(s.batch), dim3(nt), lds, a);
+    return 0;
+}
+
 template <typename TIN>
 int run_generic(const SimArgs &s, int nt) {
     auto a = convert<TIN>(s);
@@ -58,8 +77,12 @@ int run_generic(const SimArgs &s, int nt) {
 
 extern "C" {
 
+// measurement switch (tests/test_f32_tiles.py): the register-tiled kernels round their B and W' tiles through fp32 (SQPH_TILE_QUANT)
+void sim_set_tile_quant(int on) { ::sqph_sim::tile_quant() = on != 0; }
+
 // variant: 0 = generic (nt threads per QP); 2 = workgroup-tiled; 4 / 5 = four / two QPs per wavefront; 6 = one QP per lane
 int sim_run(const SimArgs *s, int variant, int dtype, int nt) {
+    if (variant == 9) return dtype == SQPH_F32 ? run_generic_f32_arith(*s, nt) : -1;
     if (variant == 0) return dtype == SQPH_F32 ? run_generic<float>(*s, nt) : run_generic<double>(*s, nt);
     if (variant == 5) return dtype == SQPH_F32 ? sqph::sim_run_g32<float>(convert<float>(*s)) : sqph::sim_run_g32<double>(convert<double>(*s));
     if (variant == 4) return dtype == SQPH_F32 ? sqph::sim_run_g16<float>(convert<float>(*s)) : sqph::sim_run_g16<double>(convert<double>(*s));

@@ -13,6 +13,7 @@ LIB = os.path.join(SIMDIR, "libsqph_sim.so")
 
 MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET, MODE_NO_FACTOR_STORE, MODE_REFACTOR, MODE_SAME_MATRICES = 1, 2, 4, 8, 16, 32, 64
 GENERIC, WG, CSR, G16, G32, LANE, LANE_F32 = 0, 2, 3, 4, 5, 6, 7
+GENERIC_F32_ARITH = 9  # measurement only: the generic kernel in fp32 arithmetic (fp32 state arrays)
 
 
 class SimArgs(ctypes.Structure):
@@ -63,16 +64,17 @@ class SimSolverBatch:
         s.adaptive_rho_tolerance, s.adaptive_rho_interval, s.verbose = 5, 25, 0
         mm = max(m, 1)
         # solver state is fp64 whatever the interface Scalar is (QPSolver<float>)
-        self.x = np.zeros((batch, n), np.float64)
-        self.zv = np.zeros((batch, mm), np.float64)
-        self.y = np.zeros((batch, mm), np.float64)
-        self.rho_vec = np.zeros((batch, mm), np.float64)
+        sdt = np.float32 if variant == GENERIC_F32_ARITH else np.float64
+        self.x = np.zeros((batch, n), sdt)
+        self.zv = np.zeros((batch, mm), sdt)
+        self.y = np.zeros((batch, mm), sdt)
+        self.rho_vec = np.zeros((batch, mm), sdt)
         self.ctype = np.zeros((batch, mm), np.int32)
-        self.rho = np.zeros(batch, np.float64)
+        self.rho = np.zeros(batch, sdt)
         self.info_arr = np.zeros(batch, _capi.INFO_DTYPE)
         self.info_arr["status"] = 4
-        self.Sinv = np.zeros((batch, 2 * n * n), np.float64)
-        self.At = np.zeros((batch, mm * n), np.float64)
+        self.Sinv = np.zeros((batch, 2 * n * n), sdt)
+        self.At = np.zeros((batch, mm * n), sdt)
 
     def _run(self, mode, P, q, A, l, u, csr=None):
         n, m = self.n, self.m
@@ -100,7 +102,7 @@ class SimSolverBatch:
         if (mode & MODE_SAME_MATRICES) and not self.factor_resident:
             a.mode &= ~MODE_SAME_MATRICES
         if (mode & (MODE_SETUP | MODE_UPDATE)) or (a.mode & MODE_REFACTOR):
-            self.factor_resident = self.variant == GENERIC or not (a.mode & MODE_NO_FACTOR_STORE)
+            self.factor_resident = self.variant in (GENERIC, GENERIC_F32_ARITH) or not (a.mode & MODE_NO_FACTOR_STORE)
         for name, arr, per in (("P", P, n * n), ("q", q, n), ("A", A, m * n), ("l", l, m), ("u", u, m)):
             setattr(a, name, arr.ctypes.data)
             shared = arr.ndim == (2 if name in ("P", "A") else 1)
