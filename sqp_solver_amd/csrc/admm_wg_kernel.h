@@ -811,6 +811,12 @@ struct WgKernel {
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         bool have_A = false;  // `at` currently holds A (as opposed to B)
+        // A x of the owned constraint row by the recurrence  A x_{k+1} = alpha z~_{k+1} + (1 - alpha) A x_k  (z~ = A x~ is the stage-2
+        // result, x_{k+1} = alpha x~ + (1 - alpha) x_k: qp.cpp:92-96) — exact in exact arithmetic, valid from x_0 = 0 (a solve that
+        // starts from retained iterates computes A x at its checks by streaming A, as before).  With it the PRIMAL half of a
+        // termination check needs no memory access at all, see the check block.
+        T ax = 0;
+        bool ax_valid = (mode & MODE_SETUP) != 0;
         const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
         int iter = 1;
         // countdowns to the next termination check / rho adaptation (0 or disabled: never fires)
@@ -853,7 +859,10 @@ struct WgKernel {
             if (!solving) {
                 solving = true;
                 state_dirty = true;
-                if ((mode & MODE_COLD_RESET) && !a.warm_start) x = z = y = 0;
+                if ((mode & MODE_COLD_RESET) && !a.warm_start) {
+                    x = z = y = 0;
+                    ax_valid = true;
+                }
             }
             // B = A W' replaces A in the iteration:  y1 = W u + B' w,  x~ = W' y1,  z~ = B y1   (u = sigma x - q)
             // => two dependent stages per iteration instead of four (A'w -> W -> W' -> A), i.e. 4 barriers, not 8.
@@ -940,6 +949,7 @@ struct WgKernel {
                     if (nown) x = alpha * reduce_xt(lds, t) + oma * x;
                     if (mown) {
                         const T zt = reduce_over_c(lds, t);
+                        if constexpr (CHECKS) ax = alpha * zt + oma * ax;
                         const T zr = alpha * zt + oma * z;
                         T zn = zr + c_rinv * y;
                         const T lo = c_lo, up = c_up;
@@ -965,7 +975,44 @@ struct WgKernel {
                         adapt = true;
                         next_adapt = a.adaptive_rho_interval;
                     }
-                    if (check || adapt) {
+                    // A termination check whose PRIMAL test fails cannot end the solve, and nothing else of it is observable: the
+                    // reference overwrites info.res_prim / res_dual at every check (qp.cpp:316-331) and the caller sees the values of
+                    // the last one.  With A x kept by recurrence the primal residual costs two reductions and no memory traffic, so
+                    // the dual half (A'y and P x: 60 KB streamed per QP at C3) is only computed when the primal test passes, when
+                    // rho is to be adapted (the estimate needs both residuals), or at the last check a solve can reach (its
+                    // residuals are what a MAX_ITER_EXCEEDED solve reports).
+                    bool full_check = check || adapt;
+                    if (check && !adapt && ax_valid && iter - 1 + a.check_termination <= a.max_iter) {
+                        __syncthreads();
+                        T vp[2] = {0, 0};  // nrm_prim | res_prim
+                        if (mown) {
+                            vp[0] = nanmax(tabs(ax), tabs(z));
+                            vp[1] = tabs(ax - z);
+                        }
+                        T *red = lds + L::O_RED;
+#pragma unroll
+                        for (int e = 0; e < 2; e++) vp[e] = wave_nanmax(vp[e]);
+                        if constexpr (NW > 1) {
+                            if ((t & 63) == 0) {
+#pragma unroll
+                                for (int e = 0; e < 2; e++) red[e * NW + (t >> 6)] = vp[e];
+                            }
+                            __syncthreads();
+#pragma unroll
+                            for (int e = 0; e < 2; e++) {
+                                T mval = red[e * NW];
+#pragma unroll
+                                for (int wv_ = 1; wv_ < NW; wv_++) mval = nanmax(mval, red[e * NW + wv_]);
+                                vp[e] = mval;
+                            }
+                            __syncthreads();
+                        }
+                        if (!(vp[1] <= a.eps_abs + a.eps_rel * vp[0])) {  // (a NaN residual fails the test as it does in the full check)
+                            info.res_prim = (double)vp[1];
+                            full_check = false;
+                        }
+                    }
+                    if (full_check) {
                         // update_state + residuals, qp.cpp:316-331, 353-361.  A and P are streamed from global
                         // memory here (the register tiles hold B and W); this block runs every check_termination
                         // iterations only.
@@ -982,7 +1029,9 @@ struct WgKernel {
                             stage_A_AT_gmem(gA_c, n_c, m_c, r_c, c_c, yr, lds);  // A x (over c) and A' y (over r)
                         }
                         __syncthreads();
-                        const T Ax = mown ? reduce_over_c(lds, t) : T(0);
+                        // (a variant streaming for A'y alone when A x is known, three columns in flight, measured equal: full checks are rare now)
+                        const T Ax_streamed = mown ? reduce_over_c(lds, t) : T(0);
+                        const T Ax = ax_valid ? (mown ? ax : T(0)) : Ax_streamed;
                         const T ATy = nown ? reduce_over_r(lds, t) : T(0);
                         __syncthreads();
                         {

@@ -364,7 +364,7 @@ def test_lane_kernel_paths():
     settings (QPs without a stable reference answer excluded by parity_termination), state paths, fused-then-solve"""
     for (n, m, B) in ((2, 3, 257), (1, 1, 65), (2, 1, 64), (3, 3, 130), (4, 6, 300)):
         cases.parity_fixed_iters(make_gpu, n, m, B, iters=150, dual_floor=True)
-    cases.parity_fixed_iters(make_gpu, 2, 3, 64, iters=100, alpha=1.6)
+    cases.parity_fixed_iters(make_gpu, 2, 3, 64, iters=100, alpha=1.6, dual_floor=True)  # (a tiny QP may have every constraint inactive: y = 0)
     cases.parity_fixed_iters(make_gpu, 4, 6, 64, iters=100, dtype=np.float32)
     for kw in (dict(), dict(adaptive=True), dict(sqp_settings=True)):
         # residual norms / rho estimate are compared on the QPs whose reference diagnostics are themselves reproducible
