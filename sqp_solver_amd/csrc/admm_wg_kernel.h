@@ -580,6 +580,7 @@ struct WgKernel {
                     for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
             }
         }
+        SQPH_STICK(1)
 #ifndef SQPH_SIM
         if (L::P_STAGED && p_staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the P block has landed in LDS
 #endif
@@ -628,6 +629,7 @@ struct WgKernel {
         for (int u = 0; u < TW; u++)
 #pragma unroll
             for (int k = 0; k < TC; k++) wt[u][k] = wt[u][k] * srow[u] * scol[k];
+        SQPH_STICK(2)
         // forward elimination of [S~ | I] in place; row k = R*u + rr is broadcast through LDS
         bool ok_all = true;
         T dsave[TW];
@@ -670,6 +672,7 @@ struct WgKernel {
                 dsave[u] = (r == rr) ? d : dsave[u];
             }
         }
+        SQPH_STICK(3)
         // W = D^-1/2 L^-1 D_J^-1/2
 #pragma unroll
         for (int u = 0; u < TW; u++) {
