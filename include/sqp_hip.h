@@ -148,11 +148,15 @@ enum {
      * same results, one extra factorisation.  sqph_setup / sqph_update_qp always leave their factor resident.  Set this for
      * callers that follow a fused call with sqph_solve on new q, l, u (SQP second-order correction, MPC). */
     SQPH_FLAG_KEEP_FACTOR = 16,
-    /* QPSolver<float> in TRUE single precision where a kernel for it exists (the one-QP-per-lane kernel, n <= 4, m <= 6):
-     * iterates, factor and residuals in fp32.  Default (flag clear): fp32 at the interface only, fp64 arithmetic — the
-     * Schur-complement factor loses ~3 digits more than the reference's KKT LDL' in fp32, so the true-fp32 solve
-     * agrees with the reference's QPSolver<float> to ~1e-3, not to fp32 round-off.  Ignored for dtype SQPH_F64 and for shapes
-     * without an fp32 kernel (they iterate in fp64). */
+    /* QPSolver<float> with single-precision ARITHMETIC where a kernel for it exists (reference src/qp.cpp:385-386):
+     *   - n <= 4, m <= 6 (one QP per lane): iterates, factor and residuals in fp32; agrees with the reference's QPSolver<float>
+     *     to ~1e-3 (the Schur-complement factor loses ~3 digits more in fp32 than the reference's KKT LDL');
+     *   - m <= 40, n <= 24 and m <= 112, n <= 56 (the BASELINE dense shapes; wg_f32.hip): the operator tiles, the operand vectors
+     *     and the partial sums of the iteration's two stages in fp32 (two multiply-adds per lane and instruction), the
+     *     factorisation that builds the tiles, the iterates and the residual checks in fp64; no further from the fp64 solution
+     *     than max(4x the reference's QPSolver<float>, 5e-4) (measured x ~1e-6, y ~2e-4), 1.2x the fp64 kernel's speed at (50,100).
+     * Default (flag clear): fp32 at the interface only, fp64 arithmetic.  Ignored for dtype SQPH_F64 and for shapes without an
+     * fp32 kernel (they iterate in fp64). */
     SQPH_FLAG_F32_ARITH = 32
 };
 

@@ -75,6 +75,9 @@ int wg_nocheck_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const
 extern template int wg_nocheck_try_launch<double>(const KArgs<double, double> &, hipStream_t, const char **, int);
 extern template int wg_nocheck_try_launch<float>(const KArgs<double, float> &, hipStream_t, const char **, int);
 
+// the fp32-product variant of the register-tiled kernels (wg_f32.hip): QPSolver<float> with SQPH_FLAG_F32_ARITH
+int wgf_try_launch(const KArgs<double, float> &a, hipStream_t stream, const char **name);
+
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>
 inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {

@@ -101,6 +101,59 @@ __device__ __forceinline__ double wg_sum(const double *p) {
     }
 }
 
+// ---- fp32 products (SQPH_FLAG_F32_ARITH on a QPSolver<float>): the B / W' tiles, the operand vectors and the partial sums of the two
+// iteration stages are single precision, two columns per register pair (v_pk_fma_f32: two multiply-adds per lane and instruction);
+// the factorisation that builds the tiles and the iterates x, z, y stay double.
+typedef float sqph_f2 __attribute__((vector_size(8)));
+typedef float sqph_f4 __attribute__((vector_size(16)));
+__device__ __forceinline__ sqph_f2 wgf_fma2(sqph_f2 a, sqph_f2 b, sqph_f2 c) {
+#ifdef SQPH_SIM
+    sqph_f2 r;
+    r[0] = __builtin_fmaf(a[0], b[0], c[0]);
+    r[1] = __builtin_fmaf(a[1], b[1], c[1]);
+    return r;
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
+// N floats from a 16-byte aligned LDS address (N rounded up to a multiple of four is read)
+template <int N>
+__device__ __forceinline__ void wgf_read(const float *p, float (&v)[N]) {
+    const sqph_f4 *q = reinterpret_cast<const sqph_f4 *>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int k = 0; k < (N + 3) / 4; k++) {
+        const sqph_f4 t = q[k];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (4 * k + e < N) v[4 * k + e] = t[e];
+    }
+}
+template <int N>
+__device__ __forceinline__ float wgf_sum(const float *p) {
+    float v[N];
+    wgf_read<N>(p, v);
+    if constexpr (N >= 8 && (N % 4) == 0) {
+        float s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3];
+#pragma unroll
+        for (int k = 4; k < N; k += 4) {
+            s0 += v[k];
+            s1 += v[k + 1];
+            s2 += v[k + 2];
+            s3 += v[k + 3];
+        }
+        return (s0 + s1) + (s2 + s3);
+    } else {
+        float s0 = v[0], s1 = N > 1 ? v[1] : 0.0f;
+#pragma unroll
+        for (int k = 2; k + 1 < N; k += 2) {
+            s0 += v[k];
+            s1 += v[k + 1];
+        }
+        if constexpr ((N & 1) && N > 1) s0 += v[N - 1];
+        return s0 + s1;
+    }
+}
+
 template <int NW, int R, int C, int TR, int TC, int TW>
 struct WgLayout {
     // NW >= 1: the R x C lane grid is a workgroup of NW wavefronts.  NW == 0: a 4 x 4 grid of 16 lanes — four
@@ -159,6 +212,13 @@ struct WgLayout {
     static_assert(O_AS2 + R * SSTR <= O_QV, "build_B stages all of W and a block of A rows in [0, O_QV)");
     // the workgroup kernels whose scratch has room for an n x n block of doubles take P through LDS
     static constexpr bool P_STAGED = NW > 0 && O_PST + NP * NP <= O_QV;
+    // fp32-product variant: the same regions viewed as floats (float offset = 2 x the double offset), rows padded to 16 bytes
+    static constexpr int r4(int x) { return (x + 3) & ~3; }
+    static constexpr int TRf = r4(TR), TWf = r4(TW), TCf = r4(TC);  // gather strides (floats)
+    static constexpr int Rf = r4(R) + 4, Cf = r4(C) + 4;           // staging strides (floats)
+    static constexpr int TC2 = (TC + 1) / 2;                       // column pairs of a tile row
+    static constexpr bool F32_FITS = R * TRf <= 2 * R * TRp && R * TWf <= 2 * R * TWp && C * TCf <= 2 * C * TCp && NP * Rf <= 2 * STAGE_X &&
+                                     mx(NR, MP) * Cf <= 2 * STAGE_Y && NR * Cf <= 2 * NR * Cp;
     static constexpr int slot(int j) { return SLOT * (j / TC) + (j % TC); }
 };
 
@@ -308,6 +368,73 @@ struct WgKernel {
         }
     }
     static __device__ __forceinline__ T reduce_xt(const T *lds, int i) { return wg_sum<C>(lds + L::O_STX + i * L::Cp); }
+
+    // ------------------------------------------------------------------ fp32-product variant of the two stages (see wgf_fma2)
+    static __device__ __forceinline__ void putf_rowv(float *lf, int r, int c, float v) { lf[2 * L::O_ROWV + r * L::TRf + c] = v; }
+    static __device__ __forceinline__ void getf_rowv(const float *lf, int r, float (&w)[TR]) { wgf_read<TR>(lf + 2 * L::O_ROWV + r * L::TRf, w); }
+    static __device__ __forceinline__ void putf_wrow(float *lf, int r, int c, float v) { lf[2 * L::O_WROW + r * L::TWf + c] = v; }
+    static __device__ __forceinline__ void getf_wrow(const float *lf, int r, float (&y)[TW]) { wgf_read<TW>(lf + 2 * L::O_WROW + r * L::TWf, y); }
+    static __device__ __forceinline__ void putf_colv2(float *lf, int j, float v) { lf[2 * L::O_COLV2 + (j / TC) * L::TCf + (j % TC)] = v; }
+    static __device__ __forceinline__ void getf_colv2(const float *lf, int c, float (&x)[TC]) { wgf_read<TC>(lf + 2 * L::O_COLV2 + c * L::TCf, x); }
+    // double tiles -> float pairs (column 2 kp | 2 kp + 1; the odd tail column is paired with a zero)
+    template <int NRW>
+    static __device__ __forceinline__ void tile_to_f32(const T (&src)[NRW][TC], sqph_f2 (&dst)[NRW][L::TC2]) {
+#pragma unroll
+        for (int s = 0; s < NRW; s++)
+#pragma unroll
+            for (int kp = 0; kp < L::TC2; kp++) {
+                dst[s][kp][0] = (float)src[s][2 * kp];
+                dst[s][kp][1] = (2 * kp + 1 < TC) ? (float)src[s][2 * kp + 1 < TC ? 2 * kp + 1 : 0] : 0.0f;
+            }
+    }
+    static __device__ __forceinline__ void stage1_f(const sqph_f2 (&bt)[TR][L::TC2], const sqph_f2 (&vt)[TW][L::TC2], const float (&w)[TR],
+                                                    const float (&ur)[TW], float *lf, int r, int c) {
+        sqph_f2 pb[L::TC2];
+#pragma unroll
+        for (int kp = 0; kp < L::TC2; kp++) pb[kp] = sqph_f2{0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < TR; s++) {
+            const sqph_f2 ws = {w[s], w[s]};
+#pragma unroll
+            for (int kp = 0; kp < L::TC2; kp++) pb[kp] = wgf_fma2(bt[s][kp], ws, pb[kp]);
+        }
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            const sqph_f2 us = {ur[u], ur[u]};
+#pragma unroll
+            for (int kp = 0; kp < L::TC2; kp++) pb[kp] = wgf_fma2(vt[u][kp], us, pb[kp]);
+        }
+        float *st = lf + 2 * L::O_STAGE;
+#pragma unroll
+        for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rf + r] = pb[k / 2][k & 1];
+    }
+    static __device__ __forceinline__ void stage2_f(const sqph_f2 (&bt)[TR][L::TC2], const sqph_f2 (&vt)[TW][L::TC2], const float (&y1)[TC],
+                                                    float *lf, int r, int c) {
+        sqph_f2 yp[L::TC2];
+#pragma unroll
+        for (int kp = 0; kp < L::TC2; kp++) {
+            yp[kp][0] = y1[2 * kp];
+            yp[kp][1] = (2 * kp + 1 < TC) ? y1[2 * kp + 1 < TC ? 2 * kp + 1 : 0] : 0.0f;
+        }
+        float *sty = lf + 2 * L::O_STAGE_Y;
+        float *stx = lf + 2 * L::O_STX;
+#pragma unroll
+        for (int s = 0; s < TR; s++) {
+            sqph_f2 acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int kp = 0; kp < L::TC2; kp++) acc = wgf_fma2(bt[s][kp], yp[kp], acc);
+            sty[(R * s + r) * L::Cf + c] = acc[0] + acc[1];
+        }
+#pragma unroll
+        for (int u = 0; u < TW; u++) {
+            sqph_f2 acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int kp = 0; kp < L::TC2; kp++) acc = wgf_fma2(vt[u][kp], yp[kp], acc);
+            stx[(R * u + r) * L::Cf + c] = acc[0] + acc[1];
+        }
+    }
+    static __device__ __forceinline__ T reducef_xt(const float *lf, int i) { return (T)wgf_sum<C>(lf + 2 * L::O_STX + i * L::Cf); }
+    static __device__ __forceinline__ T reducef_over_c(const float *lf, int t) { return (T)wgf_sum<C>(lf + 2 * L::O_STAGE_Y + t * L::Cf); }
 
     // owner-side reductions (lane t owns output t)
     static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? t : 0) * L::Rp); }
@@ -695,8 +822,11 @@ struct WgKernel {
     // reloads and a store inside the loop (256 VGPRs, 27 spilled); without it nothing is spilled (241 VGPRs) — 3.01 -> 2.75 ms per
     // 8,192 x 200 iterations on the C3 shard.  Those kernels live in a translation unit of their own (wg_nocheck.hip): instantiated next
     // to the checking ones, they changed the register allocation of the latter (+3.7 % on the default-termination run).
-    template <bool CHECKS = true>
+    // F32 = true: the iteration's two stages in single precision (stage1_f / stage2_f), everything else unchanged
+    template <bool CHECKS = true, bool F32 = false>
     static __device__ __forceinline__ void run(const KArgs<T, TIN> &a, T *lds) {
+        static_assert(!F32 || L::F32_FITS, "float views must fit the regions of the double layout");
+        float *lf = reinterpret_cast<float *>(lds);
         const int t = threadIdx.x;
         const int r = t % R, c = t / R;
         const int qp = blockIdx.x;
@@ -891,9 +1021,19 @@ struct WgKernel {
                 SQPH_STICK(6)
             }
             T (&bt)[TR][TC] = at;
+            sqph_f2 btf[F32 ? TR : 1][L::TC2], vtf[F32 ? TW : 1][L::TC2];
+            if constexpr (F32) {
+                tile_to_f32<TR>(at, btf);
+                tile_to_f32<TW>(vt, vtf);
+            }
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
-            if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
-            if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - qv[t < L::NP ? t : 0] : T(0));
+            if constexpr (F32) {
+                if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
+                if (t < L::NR) putf_wrow(lf, r, c, nown ? (float)(sigma * x - qv[t < L::NP ? t : 0]) : 0.0f);
+            } else {
+                if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
+                if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - qv[t < L::NP ? t : 0] : T(0));
+            }
 #ifdef SQPH_PHASE_TIMING
             unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define SQPH_TICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
@@ -911,7 +1051,12 @@ struct WgKernel {
                 for (int seg_i = 0; seg_i < seg; seg_i++) {
                     __syncthreads();
                     SQPH_TICK(0)
-                    {   // stage 1 partials:  B' w + W u, both reduced over r
+                    if constexpr (F32) {
+                        float w[TR], ur[TW];
+                        getf_rowv(lf, r, w);
+                        getf_wrow(lf, r, ur);
+                        stage1_f(btf, vtf, w, ur, lf, r, c);
+                    } else {   // stage 1 partials:  B' w + W u, both reduced over r
                         T w[TR], ur[TW];
                         get_rowv(lds, r, w);
                         get_wrow(lds, r, ur);
@@ -925,12 +1070,17 @@ struct WgKernel {
                     SQPH_TICK(2)
                     if (r < TC) {
                         const int j = TC * c + r;
-                        put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0));
+                        if constexpr (F32) putf_colv2(lf, j, j < n ? wgf_sum<R>(lf + 2 * L::O_STAGE + j * L::Rf) : 0.0f);
+                        else put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0));
                     }
                     SQPH_TICK(3)
                     wave_sync();
                     SQPH_TICK(4)
-                    {   // stage 2 partials:  z~ = B y1  and  x~ = W' y1, both reduced over c
+                    if constexpr (F32) {
+                        float y1c[TC];
+                        getf_colv2(lf, c, y1c);
+                        stage2_f(btf, vtf, y1c, lf, r, c);
+                    } else {   // stage 2 partials:  z~ = B y1  and  x~ = W' y1, both reduced over c
                         T y1c[TC];
                         get_colv2(lds, c, y1c);
                         stage2(bt, vt, y1c, lds, r, c);
@@ -949,9 +1099,9 @@ struct WgKernel {
                     SQPH_TICK(6)
                     // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
                     // SIMDs are issue-bound at two waves each (a branch-free variant measured 14 % slower)
-                    if (nown) x = alpha * reduce_xt(lds, t) + oma * x;
+                    if (nown) x = alpha * (F32 ? reducef_xt(lf, t) : reduce_xt(lds, t)) + oma * x;
                     if (mown) {
-                        const T zt = reduce_over_c(lds, t);
+                        const T zt = F32 ? reducef_over_c(lf, t) : reduce_over_c(lds, t);
                         if constexpr (CHECKS) ax = alpha * zt + oma * ax;
                         const T zr = alpha * zt + oma * z;
                         T zn = zr + c_rinv * y;
@@ -963,8 +1113,13 @@ struct WgKernel {
                     }
 
                     // operands of the next iteration (the barrier at the loop top orders them before the gathers)
-                    if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - c_rinv * y) : T(0));
-                    if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - c_q : T(0));
+                    if constexpr (F32) {
+                        if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - c_rinv * y)) : 0.0f);
+                        if (t < L::NR) putf_wrow(lf, r, c, nown ? (float)(sigma * x - c_q) : 0.0f);
+                    } else {
+                        if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - c_rinv * y) : T(0));
+                        if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - c_q : T(0));
+                    }
                     SQPH_TICK(7)
                 }
                 iter += seg;
@@ -1110,7 +1265,11 @@ struct WgKernel {
                             }
                         }
                         // the check borrowed the row-gather vector for y: publish w again for the next segment
-                        if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
+                        if constexpr (F32) {
+                            if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
+                        } else {
+                            if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
+                        }
                     }
                 }
             }
@@ -1569,6 +1728,29 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_nocheck_kernel(KArgs<dou
     WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false>(a, lds);
 }
 
+// fp32 products (SQPH_FLAG_F32_ARITH with QPSolver<float>): the same kernels with the iteration's two stages in single precision;
+// instantiated in wg_f32.hip only
+template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void admm_wgf_kernel(KArgs<double, TIN> a) {
+    __shared__ __attribute__((aligned(16))) double lds[WgLayout<NW, R, C, TR, TC, TW>::TOTAL];
+#ifdef SQPH_SIM
+    ::sqph_sim::poison_static_lds(lds, sizeof(lds));
+#endif
+    WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<true, true>(a, lds);
+}
+template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void admm_wgf_nocheck_kernel(KArgs<double, TIN> a) {
+    __shared__ __attribute__((aligned(16))) double lds[WgLayout<NW, R, C, TR, TC, TW>::TOTAL];
+#ifdef SQPH_SIM
+    ::sqph_sim::poison_static_lds(lds, sizeof(lds));
+#endif
+    WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false, true>(a, lds);
+}
+// shapes of the fp32-product variant {NW, R, C, TR, TC, TW, WPE}: the BASELINE dense shapes (20,40) and (50,100)
+#define SQPH_WGF_SHAPES(X)   \
+    X(1, 8, 8, 5, 3, 3, 3)   \
+    X(2, 16, 8, 7, 7, 4, 2)
+
 // four QPs per wavefront (run_group): block = one wavefront, LDS = 4 slices
 template <typename TIN, int TR, int TC, int WPE>
 __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a) {
@@ -1659,6 +1841,23 @@ inline int sim_run_g16(const KArgs<double, TIN> &a) {
         return 0;                                                                                          \
     }
     SQPH_G16_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_wgf(const KArgs<double, TIN> &a) {
+#define SQPH_SIM_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                         \
+    if (a.m <= R_ * TR_ && a.n <= C_ * TC_) {                                                                 \
+        if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0))                      \
+            ::sqph_sim::launch(admm_wgf_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>, dim3(a.batch), dim3(64 * NW_), 0, a); \
+        else                                                                                                  \
+            ::sqph_sim::launch(admm_wgf_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>, dim3(a.batch), dim3(64 * NW_), 0, a); \
+        return 0;                                                                                             \
+    }
+    SQPH_WGF_SHAPES(SQPH_SIM_CASE)
 #undef SQPH_SIM_CASE
     return -1;
 }

@@ -677,6 +677,9 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         int rc = 0;
         a.mode = for_family('t');
         if (sizeof(TIN) == 4 && (s->flags & SQPH_FLAG_F32_ARITH)) rc = lane_try_launch<TIN, float>(a, s->stream, &s->kernel_name);
+        if constexpr (sizeof(TIN) == 4) {
+            if (rc == 0 && (s->flags & SQPH_FLAG_F32_ARITH)) rc = wgf_try_launch(a, s->stream, &s->kernel_name);  // wg_f32.hip
+        }
         if (rc == 0) rc = lane_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = g32_try_launch<TIN>(a, s->stream, &s->kernel_name);

@@ -313,10 +313,50 @@ def test_true_fp32_variant():
     xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings), dtype=np.float32)
     assert ((info.status == io["status"]) & (info.iter == io["iter"])).mean() > 0.995  # fp32 stop tests sit on fp32-noisy residuals
     assert np.percentile(np.max(np.abs(x - xo), axis=1) / np.maximum(np.max(np.abs(xo), axis=1), 1e-30), 99) < cases.TOL_F32
-    s = mk(20, 40, 8)  # no fp32 kernel for this shape: fp64 arithmetic behind the float interface, as without the flag
+    s = mk(60, 120, 8)  # no fp32 kernel for this shape: fp64 arithmetic behind the float interface, as without the flag
     s.settings.max_iter, s.settings.check_termination = 50, 0
-    s.setup_solve(*random_qp_batch(8, 20, 40, seed=1, dtype=np.float32))
+    s.setup_solve(*random_qp_batch(8, 60, 120, seed=1, dtype=np.float32))
     assert not s.kernel_name().endswith("_f32")
+
+
+def test_fp32_product_variant_of_the_register_tiled_kernels():
+    """SQPH_FLAG_F32_ARITH at the BASELINE dense shapes (reference src/qp.cpp:385-386 and
+    tests/qp_solver_test.cpp:58-69): tiles, operands and partial sums of the two iteration stages in fp32 (wg_f32.hip), the
+    factorisation, the iterates and the residual checks in fp64.  Tolerance as in tests/test_sim_kernels.py: x within TOL_F32 of
+    the float oracle; x, y, z no further from the fp64 solution than max(4x the float oracle, 5e-4).  Default termination against
+    the FP64 oracle: status equal, iteration counts equal on >= 90 % of the batch, solutions of those within 1e-4."""
+    from sqp_solver_amd.problems import random_qp_batch
+
+    mk = lambda n, m, b, **kw: make_gpu(n, m, b, dtype=np.float32, f32_arith=True, keep_factor=kw.get("keep_factor", False))  # noqa: E731
+    worst = {}
+    for (n, m, b, kern) in ((20, 40, 512, "wg1_8x8_5x3_w3_f32"), (50, 100, 256, "wg2_16x8_7x7_w2_f32"), (30, 60, 64, "wg2_16x8_7x7_w2_f32"), (56, 112, 32, "wg2_16x8_7x7_w2_f32")):
+        ex, ey, ez = cases.parity_fixed_iters(mk, n, m, b, iters=200, dtype=np.float32, f32_floor=5e-4)
+        assert ex < 5e-5 and ey < 5e-4, (n, m, ex, ey)
+        worst[(n, m)] = (ex, ey)
+        P, q, A, l, u = random_qp_batch(b, n, m, seed=3, dtype=np.float32)
+        s = mk(n, m, b)
+        s.setup_solve(P, q, A, l, u)
+        assert s.kernel_name() == kern, s.kernel_name()
+        x, y, z, info = s.solution()
+        f64 = lambda a: np.asarray(a, dtype=np.float64)  # noqa: E731
+        xo, yo, zo, io = oracle.solve_batch(f64(P), f64(q), f64(A), f64(l), f64(u), cases.oracle_settings(s.settings), nthreads=0)
+        assert (info.status == io["status"]).mean() >= 0.98
+        same = (info.iter == io["iter"]) & (info.status == io["status"])
+        assert same.mean() >= 0.9, same.mean()
+        assert cases.relerr(x[same], xo[same]) < 1e-4
+        # solve() on the resident factor == the fused call, bit for bit, at a fixed iteration count (under termination the fused
+        # call keeps A x by recurrence from the fp32 products, a solve() on retained iterates streams A: the stop test may differ)
+        s.settings.max_iter, s.settings.check_termination = 60, 0
+        s.setup_solve(P, q, A, l, u)
+        x, y, z, info = s.solution()
+        s2 = mk(n, m, b, keep_factor=True)
+        s2.settings.max_iter, s2.settings.check_termination = 60, 0
+        s2.setup(P, q, A, l, u)
+        s2.solve(P, q, A, l, u)
+        x2, y2, z2, info2 = s2.solution()
+        assert np.array_equal(x2, x) and np.array_equal(y2, y) and np.array_equal(info2.iter, info.iter)
+    print("fp32-product kernels, error against the fp64 solution (x, y):", worst)
+    cases.ref_testSinglePrecisionFloat(mk)
 
 
 def test_verbose_trace():

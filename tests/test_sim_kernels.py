@@ -268,6 +268,47 @@ def test_lane_true_fp32_variant():
     cases.ref_testSinglePrecisionFloat(make_lane_f32)
 
 
+def make_wg_f32(n, m, batch, dtype=np.float32, legacy_cold_start=False, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=np.float32, variant=simlib.WG_F32, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
+
+
+def test_wg_fp32_product_variant():
+    """SQPH_FLAG_F32_ARITH at the BASELINE dense shapes (reference src/qp.cpp:385-386): B / W' tiles, operand
+    vectors and partial sums of the two iteration stages in fp32 (v_pk_fma_f32), factorisation / iterates / residual checks in
+    fp64.  Stated tolerance (cases.parity_fixed_iters): x within TOL_F32 = 5e-3 of the reference's QPSolver<float> (float oracle);
+    x, y, z no further from the fp64 solution of the same float-valued problem than max(4x the float oracle's error, 5e-4);
+    measured 6e-7..2e-6 (x) and 9e-5..2e-4 (y) against 1e-6 / 2e-5..4e-5 for the float oracle.  Default termination: status equal,
+    iteration counts equal to the FP64 oracle's on at least 3 of 4 QPs (the stop test sits on an fp32-noisy residual)."""
+    from sqp_solver_amd.problems import random_qp_batch
+
+    for (n, m, b) in ((20, 40, 12), (50, 100, 6), (30, 60, 4), (56, 112, 3)):
+        ex, ey, ez = cases.parity_fixed_iters(make_wg_f32, n, m, b, iters=150, dtype=np.float32, f32_floor=5e-4)
+        assert ex < 5e-5 and ey < 5e-4, (n, m, ex, ey)
+    for (n, m, b) in ((20, 40, 12), (50, 100, 6)):
+        P, q, A, l, u = random_qp_batch(b, n, m, seed=3, dtype=np.float32)
+        s = make_wg_f32(n, m, b)
+        s.setup_solve(P, q, A, l, u)
+        x, y, z, info = s.solution()
+        f64 = lambda a: np.asarray(a, dtype=np.float64)  # noqa: E731
+        xo, yo, zo, io = oracle.solve_batch(f64(P), f64(q), f64(A), f64(l), f64(u), cases.oracle_settings(s.settings))
+        assert (info.status == io["status"]).all()
+        assert (info.iter == io["iter"]).mean() >= 0.75, (info.iter, io["iter"])
+        same = info.iter == io["iter"]
+        assert cases.relerr(x[same], xo[same]) < 1e-4
+        # solve() on the resident factor == the fused call, bit for bit, at a fixed iteration count (under termination the fused
+        # call keeps A x by recurrence from the fp32 products, a solve() on retained iterates streams A: the stop test may differ)
+        s.settings.max_iter, s.settings.check_termination = 40, 0
+        s.setup_solve(P, q, A, l, u)
+        x, y, z, info = s.solution()
+        s2 = make_wg_f32(n, m, b, keep_factor=True)
+        s2.settings.max_iter, s2.settings.check_termination = 40, 0
+        s2.setup(P, q, A, l, u)
+        s2.solve(P, q, A, l, u)
+        x2, y2, z2, info2 = s2.solution()
+        assert np.array_equal(x2, x) and np.array_equal(y2, y) and np.array_equal(info2.iter, info.iter)
+    cases.ref_testSinglePrecisionFloat(make_wg_f32)
+
+
 @pytest.mark.parametrize("make,n,m", [(make_lane, 2, 3), (make_lane, 4, 6), (make_wg, 8, 12), (make_wg, 50, 100), (make_g16, 8, 12), (make_generic, 6, 9)],
                          ids=["lane2x3", "lane4x6", "wg1", "wg2", "g16", "generic"])
 def test_setup_solve_reuse(make, n, m):
