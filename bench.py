@@ -153,7 +153,7 @@ def main():
 
     def step():
         if csr is not None:
-            solver.setup_solve_csr(P, q, csr[0], csr[1], csr[2], l, u)
+            solver.setup_solve_csr(P, q, csr[0], csr[1], csr[2], l, u, colmajor=True)  # P handed over as it lies (column-major per QP)
         else:
             solver.setup_solve(P, q, A_cm, l, u, colmajor=True)
 

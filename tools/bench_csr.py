@@ -1,6 +1,7 @@
 """BASELINE config 5 timing: batch x (n=200, m=400) QPs with a 5 %-dense CSR constraint matrix, device resident.
 Usage: python tools/bench_csr.py [--batch 8192] [--iters 200] [--steps 3]"""
 import argparse
+import os
 import json
 import time
 
@@ -22,9 +23,19 @@ def make(batch, n, m, density, seed, dev):
         G = torch.randn((e - s, n, n), generator=g, dtype=f64, device=dev)
         Pc = G @ G.transpose(1, 2) / n + 0.1 * eye
         P[s:e] = 0.5 * (Pc + Pc.transpose(1, 2))
-        mask = torch.rand((e - s, m, n), generator=g, device=dev) < density
-        forced = torch.randint(0, n, (e - s, m, 1), generator=g, device=dev)
-        mask.scatter_(2, forced, True)
+        if os.environ.get("SQPH_BENCH_REGULAR_PATTERN"):
+            # what-if measurement only (balanced sparse phases): every row has exactly round(density n) entries and every column the
+            # same number — row i holds columns (7 i + k n / per_row) mod n
+            per_row = max(1, int(round(density * n)))
+            ii = torch.arange(m, device=dev).view(m, 1)
+            kk = torch.arange(per_row, device=dev).view(1, per_row)
+            cols = (7 * ii + kk * (n // per_row)) % n
+            mask = torch.zeros((e - s, m, n), dtype=torch.bool, device=dev)
+            mask[:, ii.expand(m, per_row), cols] = True
+        else:
+            mask = torch.rand((e - s, m, n), generator=g, device=dev) < density
+            forced = torch.randint(0, n, (e - s, m, 1), generator=g, device=dev)
+            mask.scatter_(2, forced, True)
         A[s:e] = torch.randn((e - s, m, n), generator=g, dtype=f64, device=dev) * mask
     q = torch.randn((batch, n), generator=g, dtype=f64, device=dev)
     x0 = torch.randn((batch, n), generator=g, dtype=f64, device=dev)
