@@ -13,9 +13,12 @@
 //   sqp::Info / Status             sqp.hpp:33-38       sqp::Info / Status
 //   sqp::SQP<Scalar>::solve        sqp.cpp:26-41       sqp::BatchSQP<Scalar>::solve (N instances)
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <functional>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "qp.hpp"
@@ -92,6 +95,80 @@ inline void bfgs_update(Scalar *B, int n, const Scalar *s, const Scalar *y, Scal
         for (int i = 0; i < n; i++) B[(size_t)j * n + i] += -Bs[i] * Bs[j] / sBs + r[i] * r[j] / sr;
 }
 
+// Host threads for the per-instance phases of the batched driver (linearisation + BFGS + QP assembly, second-order correction,
+// line search): the instances are independent, every one keeps the reference's arithmetic and order, so the results do not
+// depend on the thread count.  Workers spin briefly between the phases of an outer iteration (they are ~20 us apart) and yield /
+// sleep when idle for longer.
+class HostPool {
+   public:
+    explicit HostPool(int threads) { resize(threads); }
+    ~HostPool() { resize(1); }
+    HostPool(const HostPool &) = delete;
+    HostPool &operator=(const HostPool &) = delete;
+    int threads() const { return (int)workers_.size() + 1; }
+    void resize(int threads) {
+        if (threads < 1) threads = 1;
+        if (threads == this->threads()) return;
+        stop_.store(true, std::memory_order_release);
+        gen_.fetch_add(1, std::memory_order_release);
+        for (auto &t : workers_) t.join();
+        workers_.clear();
+        stop_.store(false, std::memory_order_release);
+        // the generation a worker starts from is read HERE: read inside the new thread, it could already be the first job's
+        const unsigned start = gen_.load(std::memory_order_acquire);
+        for (int i = 1; i < threads; i++) workers_.emplace_back([this, start] { worker(start); });
+    }
+    // body(lo, hi) over [0, n) in chunks; the calling thread takes part
+    void parallel_for(int n, const std::function<void(int, int)> &body) {
+        if (workers_.empty() || n < 2 * CHUNK) {
+            if (n > 0) body(0, n);
+            return;
+        }
+        job_ = &body;
+        n_ = n;
+        next_.store(0, std::memory_order_relaxed);
+        pending_.store((int)workers_.size(), std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        work();
+        while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
+    }
+
+   private:
+    static constexpr int CHUNK = 16;
+    static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    void work() {
+        for (;;) {
+            const int lo = next_.fetch_add(CHUNK, std::memory_order_relaxed);
+            if (lo >= n_) break;
+            (*job_)(lo, lo + CHUNK < n_ ? lo + CHUNK : n_);
+        }
+    }
+    void worker(unsigned last) {
+        for (;;) {
+            unsigned g, spins = 0;
+            while ((g = gen_.load(std::memory_order_acquire)) == last) {
+                if (++spins < 20000) cpu_relax();
+                else if (spins < 40000) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+            last = g;
+            if (stop_.load(std::memory_order_acquire)) return;
+            work();
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::atomic<unsigned> gen_{0};
+    std::atomic<int> next_{0}, pending_{0};
+    std::atomic<bool> stop_{false};
+    const std::function<void(int, int)> *job_ = nullptr;
+    int n_ = 0;
+};
+
 // QPBackend: the batched QP-subproblem solver (setup_solve / info / primal_solution / dual_solution over a packed
 // batch).  The product instantiates the default — qp_solver::BatchQPSolver, i.e. libsqp_hip; tests/cpp substitutes a
 // backend that calls the CPU oracle to separate "the host driver is exact" from "a QP rounding flipped a line search".
@@ -123,6 +200,11 @@ class BatchSQP {
     }
 
     Settings &settings() { return settings_; }
+    // Host threads for the per-instance phases (default 1).  With more than one, NonLinearProblem objects shared by several
+    // instances are called concurrently (for different instances) and must be stateless; the results do not depend on the count.
+    // The phases run on the calling thread while a trace or step callback is installed.
+    void set_host_threads(int threads) { pool_.resize(threads); }
+    int host_threads() const { return pool_.threads(); }
     qp_solver::QPSolverSettings<Scalar> &qp_settings() { return qp_.settings(); }
 
     // probs[i] is the NLP of instance i (several entries may point to one stateless object).
@@ -140,7 +222,8 @@ class BatchSQP {
         int iter;
         for (iter = 1; iter <= settings_.max_iter && !live.empty(); iter++) {
             // ---- solve_qp (src/sqp.cpp:139-199) for every live instance: build the QP on the host ...
-            for (size_t k = 0; k < live.size(); k++) {
+            phase((int)live.size(), [&](int k_lo, int k_hi) {
+            for (size_t k = (size_t)k_lo; k < (size_t)k_hi; k++) {
                 Inst &I = inst_[live[k]];
                 Problem &prob = *probs[live[k]];
                 I.info.iter = iter;
@@ -172,10 +255,12 @@ class BatchSQP {
                 }
                 pack(k, I);
             }
+            });
             // ---- ... and run_solve_qp (src/sqp.cpp:210-242) for all of them in one launch
             run_qp(live);
             if (settings_.second_order_correction) {  // src/sqp.cpp:244-276
-                for (size_t k = 0; k < live.size(); k++) {
+                phase((int)live.size(), [&](int k_lo, int k_hi) {
+                for (size_t k = (size_t)k_lo; k < (size_t)k_hi; k++) {
                     Inst &I = inst_[live[k]];
                     Problem &prob = *probs[live[k]];
                     for (int a = 0; a < n; a++) I.x_step[a] = I.x[a] + I.p[a];
@@ -189,11 +274,14 @@ class BatchSQP {
                     }
                     pack(k, I);
                 }
+                });
                 run_qp(live, /*same_matrices=*/true);
             }
             // ---- step, line search, termination (src/sqp.cpp:76-96)
             std::vector<int> still;
-            for (size_t k = 0; k < live.size(); k++) {
+            done_.assign(live.size(), 0);
+            phase((int)live.size(), [&](int k_lo, int k_hi) {
+            for (size_t k = (size_t)k_lo; k < (size_t)k_hi; k++) {
                 Inst &I = inst_[live[k]];
                 Problem &prob = *probs[live[k]];
                 for (int a = 0; a < m; a++) I.p_lambda[a] -= I.lambda[a];
@@ -210,10 +298,12 @@ class BatchSQP {
                 if (primal_step_norm <= settings_.eps_prim && dual_step_norm <= settings_.eps_dual &&
                     max_constraint_violation(I, prob) <= settings_.eps_prim) {
                     I.info.status = SOLVED;
-                } else {
-                    still.push_back(live[k]);
+                    done_[k] = 1;
                 }
             }
+            });
+            for (size_t k = 0; k < live.size(); k++)
+                if (!done_[k]) still.push_back(live[k]);
             live.swap(still);
         }
         for (int i : live) {  // exhausted: src/sqp.cpp:98-100 (iter == max_iter + 1)
@@ -256,6 +346,12 @@ class BatchSQP {
         }
     };
 
+    // a per-instance phase: on the pool unless a callback is installed (callbacks are invoked in instance order, from one thread)
+    template <typename F>
+    void phase(int count, F &&body) {
+        if (trace_ || step_ || pool_.threads() == 1) body(0, count);
+        else pool_.parallel_for(count, body);
+    }
     void pack(size_t k, const Inst &I) {
         const size_t n = n_, m = m_;
         std::copy(I.Hess.begin(), I.Hess.end(), P_.begin() + k * n * n);
@@ -363,6 +459,8 @@ class BatchSQP {
     void *trace_user_ = nullptr;
     std::vector<Inst> inst_;
     std::vector<Scalar> P_, q_, A_, l_, u_;
+    std::vector<char> done_;
+    HostPool pool_{1};
 };
 
 }  // namespace raw

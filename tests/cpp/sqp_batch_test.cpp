@@ -284,6 +284,7 @@ static int batch_exact(const char *name, NLP &prob, int batch, const std::vector
     sqp::BatchSQP<double, OracleBatchQP> solver(n, m, batch);
     solver.settings().max_iter = 100;
     solver.settings().second_order_correction = soc;
+    solver.set_host_threads(batch >= 64 ? 4 : 1);  // the per-instance phases on a thread pool: still bit-exact with the serial oracle
     std::vector<NLP *> probs(batch, &prob);
     solver.solve(probs, X0.data(), L0.data());
     int exact = 0;
@@ -626,6 +627,31 @@ static int batch_vs_oracle(const char *name, NLP &prob, int batch, const std::ve
         printf("       wall: batched driver %.1f ms of which %.1f ms in the QP backend over %d launches (%.0f instances/s), serial oracle %.1f ms (%.0f instances/s, 1 thread)\n",
                std::chrono::duration<double, std::milli>(t1 - t0).count(), solver.qp_backend_ms(), solver.qp_launches(), batch / std::chrono::duration<double>(t1 - t0).count(),
                std::chrono::duration<double, std::milli>(t2 - t1).count(), batch / std::chrono::duration<double>(t2 - t1).count());
+    if (batch > 1) {
+        // the same solve without the per-iteration trace callback, on 1 and on T host threads (BatchSQP::set_host_threads): the
+        // per-instance arithmetic does not depend on the thread count, so the end points must equal the traced run's bit for bit
+        const int T = getenv("SQPB_THREADS") ? atoi(getenv("SQPB_THREADS")) : 8;
+        for (int threads : {1, T}) {
+            sqp::BatchSQP<double> s2(n, m, batch);
+            s2.settings().max_iter = 100;
+            s2.settings().second_order_correction = soc;
+            s2.set_host_threads(threads);
+            s2.solve(probs, X0.data(), L0.data());  // warm-up (staging buffers, code objects)
+            const auto u0 = std::chrono::steady_clock::now();
+            s2.solve(probs, X0.data(), L0.data());
+            const auto u1 = std::chrono::steady_clock::now();
+            int same = 0;
+            for (int i = 0; i < batch; i++) {
+                bool eq = s2.info(i).status == solver.info(i).status && s2.info(i).iter == solver.info(i).iter;
+                for (int k = 0; k < n && eq; k++) eq = s2.primal_solution(i)[k] == solver.primal_solution(i)[k];
+                for (int k = 0; k < m && eq; k++) eq = s2.dual_solution(i)[k] == solver.dual_solution(i)[k];
+                same += eq ? 1 : 0;
+            }
+            printf("       wall without the trace callback, %d host thread(s): %.1f ms (%.0f instances/s); end points bit-identical to the traced run on %d / %d instances\n",
+                   threads, std::chrono::duration<double, std::milli>(u1 - u0).count(), batch / std::chrono::duration<double>(u1 - u0).count(), same, batch);
+            CHECK(same == batch);
+        }
+    }
     CHECK(n_unexpl == 0);
     CHECK(n_rec_bad == 0);
     CHECK(n_rec_iter <= 0.02 * n_rec + 1);

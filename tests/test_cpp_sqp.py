@@ -25,7 +25,7 @@ def build():
             os.path.join(odir, "libqp_oracle.so"), _capi.lib_path()]
     if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
         return EXE
-    cmd = ["g++", "-std=c++14", "-O1", "-o", EXE, SRC, "-L" + odir, "-lqp_oracle", "-L" + libdir, "-lsqp_hip",
+    cmd = ["g++", "-std=c++14", "-O1", "-pthread", "-o", EXE, SRC, "-L" + odir, "-lqp_oracle", "-L" + libdir, "-lsqp_hip",
            "-Wl,-rpath,$ORIGIN/../../oracle", "-Wl,-rpath,$ORIGIN/../../sqp_solver_amd/lib", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return EXE
