@@ -229,9 +229,17 @@ int sqph_own_stream(sqph_solver *s);
 typedef struct sqph_gather sqph_gather;
 int sqph_gather_create(sqph_gather **out, int device, int n, int m, long long total);
 void sqph_gather_destroy(sqph_gather *g);
-/* Enqueue, on src's stream, the copy of src's first `count` result records to positions [offset, offset+count) of the
- * gather buffers (peer copy when src lives on another device).  Asynchronous. */
+/* The same with flags: 0, or SQPH_GATHER_RCCL_ALWAYS (also shards that live on the root's device go through RCCL, as a send to
+ * self: exercises the RCCL leg on a one-GPU box), or SQPH_GATHER_NO_RCCL (peer copies only). */
+enum { SQPH_GATHER_RCCL_ALWAYS = 1, SQPH_GATHER_NO_RCCL = 2 };
+int sqph_gather_create_ex(sqph_gather **out, int device, int n, int m, long long total, int flags);
+/* Enqueue, on src's stream, the transfer of src's first `count` result records to positions [offset, offset+count) of the
+ * gather buffers.  A shard on another device than the root's is sent with RCCL (grouped ncclSend / ncclRecv, point to point
+ * over xGMI; librccl is opened on first use) — hipMemcpyPeerAsync where RCCL is not available; a shard on the root's own
+ * device is a device-to-device copy.  Asynchronous; safe to call from one host thread per shard. */
 int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int count);
+/* "rccl", "peer-copy" or "none": what the last sqph_gather_post on g used. */
+const char *sqph_gather_transport(const sqph_gather *g);
 /* Wait for every posted copy, then copy the gathered records to host buffers (NULL = skip; x/y narrowed to `dtype`). */
 int sqph_gather_fetch(sqph_gather *g, int dtype, void *x, void *y, sqph_info *info);
 /* Wait for every posted copy and expose the device buffers (valid until sqph_gather_destroy). */

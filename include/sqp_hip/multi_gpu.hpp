@@ -37,8 +37,9 @@ class MultiGpuBatchQPSolver {
     // Explicit placement: shard g of the contiguous split lives on devices[g].  A device may be listed more than once — several
     // shards per GPU, each with its own handle and stream (their host-to-device copies and kernels overlap; it is also how the
     // sharding and gather logic is exercised on a one-GPU machine).
-    MultiGpuBatchQPSolver(int n, int m, long long batch, const std::vector<int> &devices, int flags = 0, int root = 0)
-        : n_(n), m_(m), batch_(batch), root_(root) {
+    // gather_flags: 0, SQPH_GATHER_RCCL_ALWAYS or SQPH_GATHER_NO_RCCL (sqph_gather_create_ex)
+    MultiGpuBatchQPSolver(int n, int m, long long batch, const std::vector<int> &devices, int flags = 0, int root = 0, int gather_flags = 0)
+        : n_(n), m_(m), batch_(batch), root_(root), gather_flags_(gather_flags) {
         if (devices.empty()) throw std::runtime_error("MultiGpuBatchQPSolver: empty device list");
         init(devices, flags);
     }
@@ -78,6 +79,8 @@ class MultiGpuBatchQPSolver {
     const Scalar *dual_solution(long long b) { fetch(); return &y_[(size_t)b * m_]; }
     const Info &info(long long b) { fetch(); return info_[(size_t)b]; }
     // gathered records on the root device (fp64 x [batch][n], y [batch][m], sqph_info [batch]); waits for the copies
+    // "rccl" (shards on other devices than the root's: grouped ncclSend / ncclRecv over xGMI) or "peer-copy"
+    const char *gather_transport() const { return sqph_gather_transport(gather_); }
     void gathered_device(void **x, void **y, sqph_info **info) { detail::check(sqph_gather_device_ptrs(gather_, x, y, info), nullptr, "sqph_gather_device_ptrs"); }
 
    private:
@@ -92,7 +95,7 @@ class MultiGpuBatchQPSolver {
             parts_.emplace_back(new Single(n_, m_, (int)(hi - lo), devices[(size_t)g], flags));
             detail::check(sqph_own_stream(parts_.back()->handle()), parts_.back()->handle(), "sqph_own_stream");
         }
-        detail::check(sqph_gather_create(&gather_, root_, n_, m_, batch_), nullptr, "sqph_gather_create");
+        detail::check(sqph_gather_create_ex(&gather_, root_, n_, m_, batch_, gather_flags_), nullptr, "sqph_gather_create");
         x_.resize((size_t)batch_ * n_);
         y_.resize((size_t)batch_ * (m_ > 0 ? m_ : 1));
         raw_.resize((size_t)batch_);
@@ -148,6 +151,7 @@ class MultiGpuBatchQPSolver {
     std::vector<Single *> parts_;
     std::vector<long long> lo_, hi_;
     sqph_gather *gather_ = nullptr;
+    int gather_flags_ = 0;
     std::vector<Scalar> x_, y_;
     std::vector<sqph_info> raw_;
     std::vector<Info> info_;

@@ -1040,6 +1040,10 @@ struct WgKernel {
 #else
 #define SQPH_TICK(k)
 #endif
+            // Wave priorities: the two waves of a SIMD belong to different QPs; while one is in a latency-bound stretch (the wave-local
+            // y1 reduction, the owners' reduction + update behind the barrier: short dependent chains of LDS round trips) the other is
+            // usually issuing its multiply-add blocks.  s_setprio 3 for those stretches, 0 for the two FMA blocks, lets the short
+            // chains through first: 2.71 -> 2.67 ms fixed-200, -1.1 % in the default and SQP-settings modes (tools/ab_slim.sh).
             // Segments: the iterations up to the next residual check run in a tight loop that contains no check code (the allocator then
             // keeps its spill code out of it); the check follows, between two segments.
             while (iter <= a.max_iter) {
@@ -1066,6 +1070,9 @@ struct WgKernel {
                     // y1 = W u + B' w: the R producers of a column group's TC outputs and their consumers in stage 2 are the
                     // same R lanes of one wavefront, so the reduction is wave-local — lane r < TC of group c sums output
                     // TC c + r and publishes it for its group; no workgroup barrier between the two stages
+#ifndef SQPH_SIM
+                    __builtin_amdgcn_s_setprio(3);  // see the note on wave priorities at the top of the segment loop
+#endif
                     wave_sync();
                     SQPH_TICK(2)
                     if (r < TC) {
@@ -1076,6 +1083,9 @@ struct WgKernel {
                     SQPH_TICK(3)
                     wave_sync();
                     SQPH_TICK(4)
+#ifndef SQPH_SIM
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     if constexpr (F32) {
                         float y1c[TC];
                         getf_colv2(lf, c, y1c);
@@ -1095,6 +1105,9 @@ struct WgKernel {
                         c_up = upv[t];
                     }
                     if (t < L::NP) c_q = qv[t];
+#ifndef SQPH_SIM
+                    __builtin_amdgcn_s_setprio(3);  // see the note on wave priorities at the top of the segment loop
+#endif
                     __syncthreads();
                     SQPH_TICK(6)
                     // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
@@ -1120,6 +1133,9 @@ struct WgKernel {
                         if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - c_rinv * y) : T(0));
                         if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - c_q : T(0));
                     }
+#ifndef SQPH_SIM
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     SQPH_TICK(7)
                 }
                 iter += seg;

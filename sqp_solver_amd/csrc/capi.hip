@@ -2,6 +2,8 @@
 // Owns the per-batch device state of N QPSolver instances and launches the ADMM kernels.
 // There is deliberately NO CPU execution path in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library itself is opened with dlopen on the first cross-device gather
 
 #include <cmath>
 #include <cstdio>
@@ -968,33 +970,91 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
 }  // namespace
 
 
+// ---- RCCL leg of the single-process multi-GPU gather (north_star: "final RCCL gather over xGMI") -------------------------------
+// librccl is opened on first use (dlopen: a process that never gathers across devices does not load it) and ONE communicator per
+// visible device is created with ncclCommInitAll.  A cross-device sqph_gather_post is then a grouped ncclSend (producer's
+// communicator, producer's stream, right behind its solve) / ncclRecv (root's communicator, the gather's own stream) per array —
+// point to point over xGMI, the same direct-to-root pattern as the torch.distributed path (sqp_solver_amd/dist.py).  Where RCCL
+// cannot be had (library missing, initialisation refused) the post falls back to hipMemcpyPeerAsync; sqph_gather_transport()
+// says which one ran.
+namespace {
+struct RcclApi {
+    std::mutex mu;  // communicators are not thread-safe: posts from the shards' host threads enqueue one at a time
+    bool tried = false, ok = false;
+    void *lib = nullptr;
+    int ndev = 0;
+    std::vector<ncclComm_t> comms;
+    std::string why;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // call with mu held
+    bool init() {
+        if (tried) return ok;
+        tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { why = "librccl not found"; return false; }
+#define SQPH_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(lib, sym)); if (!field) { why = std::string("librccl lacks ") + sym; return false; }
+        SQPH_SYM(CommInitAll, "ncclCommInitAll") SQPH_SYM(CommDestroy, "ncclCommDestroy") SQPH_SYM(GroupStart, "ncclGroupStart")
+        SQPH_SYM(GroupEnd, "ncclGroupEnd") SQPH_SYM(Send, "ncclSend") SQPH_SYM(Recv, "ncclRecv") SQPH_SYM(GetErrorString, "ncclGetErrorString")
+#undef SQPH_SYM
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { why = "no HIP device"; return false; }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        std::vector<int> devs(ndev);
+        for (int d = 0; d < ndev; d++) devs[d] = d;
+        comms.assign(ndev, nullptr);
+        const ncclResult_t r = CommInitAll(comms.data(), ndev, devs.data());
+        (void)hipSetDevice(cur);
+        if (r != ncclSuccess) { why = std::string("ncclCommInitAll: ") + GetErrorString(r); comms.clear(); return false; }
+        ok = true;
+        return true;
+    }
+};
+RcclApi &rccl() {
+    static RcclApi *r = new RcclApi();  // leaked on purpose: communicators must not be torn down from a static destructor
+    return *r;
+}
+}  // namespace
+
 struct sqph_gather {
-    int device = 0, n = 0, m = 0;
+    int device = 0, n = 0, m = 0, flags = 0;
     long long total = 0;
     double *x = nullptr, *y = nullptr;
     sqph_info *info = nullptr;
+    hipStream_t stream = nullptr;      // the root's side of RCCL receives
     std::mutex mu;                     // shards post from their own host threads (MultiGpuBatchQPSolver::run_host)
-    std::vector<hipEvent_t> pending;   // one per posted copy, recorded on the producer's stream  (guarded by mu)
-    std::vector<int> pending_dev;      //                                                          (guarded by mu)
+    std::vector<hipEvent_t> pending;   // one per posted copy, recorded on the stream it was enqueued on  (guarded by mu)
+    std::vector<int> pending_dev;      //                                                                  (guarded by mu)
+    const char *transport = "none";    // of the last post
     std::string err;
 };
 
 extern "C" {
-int sqph_gather_create(sqph_gather **out, int device, int n, int m, long long total) {
+int sqph_gather_create_ex(sqph_gather **out, int device, int n, int m, long long total, int flags) {
     if (!out) return SQPH_ERR_INVALID;
     *out = nullptr;
     if (n <= 0 || m < 0 || total <= 0) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_gather_create: bad shape");
+    if ((flags & SQPH_GATHER_RCCL_ALWAYS) && (flags & SQPH_GATHER_NO_RCCL)) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_gather_create: contradictory flags");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_NO_DEVICE, "sqph_gather_create: no HIP device visible");
     if (device < 0 || device >= ndev) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_gather_create: device %d out of range", device);
     sqph_gather *g = new (std::nothrow) sqph_gather();
     if (!g) SQPH_FAIL((sqph_solver *)nullptr, SQPH_ERR_INVALID, "sqph_gather_create: out of host memory");
-    g->device = device; g->n = n; g->m = m; g->total = total;
+    g->device = device; g->n = n; g->m = m; g->total = total; g->flags = flags;
     DeviceGuard dg(device);
     const size_t mm = (size_t)(m > 0 ? m : 1);
     hipError_t e = hipMalloc((void **)&g->x, (size_t)total * n * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&g->y, (size_t)total * mm * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&g->info, (size_t)total * sizeof(sqph_info));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         g_err = std::string("sqph_gather_create: ") + hipGetErrorString(e);
         sqph_gather_destroy(g);
@@ -1003,6 +1063,7 @@ int sqph_gather_create(sqph_gather **out, int device, int n, int m, long long to
     *out = g;
     return SQPH_OK;
 }
+int sqph_gather_create(sqph_gather **out, int device, int n, int m, long long total) { return sqph_gather_create_ex(out, device, n, m, total, 0); }
 
 void sqph_gather_destroy(sqph_gather *g) {
     if (!g) return;
@@ -1012,35 +1073,72 @@ void sqph_gather_destroy(sqph_gather *g) {
         (void)hipEventDestroy(g->pending[i]);
     }
     DeviceGuard dg(g->device);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
     if (g->x) (void)hipFree(g->x);
     if (g->y) (void)hipFree(g->y);
     if (g->info) (void)hipFree(g->info);
     delete g;
 }
 
+const char *sqph_gather_transport(const sqph_gather *g) { return g ? g->transport : "none"; }
+
 int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int count) {
     if (!g || !src) return SQPH_ERR_INVALID;
     if (src->n != g->n || src->m != g->m) SQPH_FAIL(src, SQPH_ERR_INVALID, "sqph_gather_post: shape mismatch");
     if (count < 0 || count > src->cap || offset < 0 || offset + count > g->total) SQPH_FAIL(src, SQPH_ERR_INVALID, "sqph_gather_post: range [%lld, %lld) outside the gather buffers / solver capacity", offset, offset + count);
     if (count == 0) return SQPH_OK;
-    DeviceGuard dg(src->device);
     const size_t n = g->n, m = g->m, c = (size_t)count;
-    if (src->device != g->device) {
-        int can = 0;
-        (void)hipDeviceCanAccessPeer(&can, src->device, g->device);
-        if (can) (void)hipDeviceEnablePeerAccess(g->device, 0);  // idempotent (an "already enabled" error is cleared below)
-        (void)hipGetLastError();
+    const bool cross = src->device != g->device;
+    bool via_rccl = false;
+    if (!(g->flags & SQPH_GATHER_NO_RCCL) && (cross || (g->flags & SQPH_GATHER_RCCL_ALWAYS))) {
+        RcclApi &R = rccl();
+        std::lock_guard<std::mutex> lk(R.mu);
+        if (R.init() && src->device < R.ndev && g->device < R.ndev) {
+            // producer side on its stream (behind the solve), root side on the gather's stream; one group per post
+            ncclResult_t r = R.GroupStart();
+            const auto xfer = [&](const void *from, void *to, size_t bytes_or_elems, ncclDataType_t dt) {
+                if (r == ncclSuccess) r = R.Send(from, bytes_or_elems, dt, g->device, R.comms[src->device], src->stream);
+                if (r == ncclSuccess) r = R.Recv(to, bytes_or_elems, dt, src->device, R.comms[g->device], g->stream);
+            };
+            xfer(src->x, g->x + (size_t)offset * n, c * n, ncclFloat64);
+            if (m) xfer(src->y, g->y + (size_t)offset * m, c * m, ncclFloat64);
+            xfer(src->info, g->info + offset, c * sizeof(sqph_info), ncclInt8);
+            const ncclResult_t re = R.GroupEnd();
+            if (r == ncclSuccess) r = re;
+            if (r != ncclSuccess) SQPH_FAIL(src, SQPH_ERR_HIP, "sqph_gather_post: RCCL: %s", R.GetErrorString(r));
+            via_rccl = true;
+        }
     }
-    SQPH_HIP(src, hipMemcpyPeerAsync(g->x + (size_t)offset * n, g->device, src->x, src->device, c * n * sizeof(double), src->stream));
-    if (m) SQPH_HIP(src, hipMemcpyPeerAsync(g->y + (size_t)offset * m, g->device, src->y, src->device, c * m * sizeof(double), src->stream));
-    SQPH_HIP(src, hipMemcpyPeerAsync(g->info + offset, g->device, src->info, src->device, c * sizeof(sqph_info), src->stream));
-    hipEvent_t ev;
+    hipEvent_t ev, ev_root = nullptr;
+    if (via_rccl) {
+        g->transport = "rccl";
+        DeviceGuard dr(g->device);
+        SQPH_HIP(src, hipEventCreateWithFlags(&ev_root, hipEventDisableTiming));
+        SQPH_HIP(src, hipEventRecord(ev_root, g->stream));
+    }
+    DeviceGuard dg(src->device);
+    if (!via_rccl) {
+        g->transport = "peer-copy";
+        if (cross) {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, src->device, g->device);
+            if (can) (void)hipDeviceEnablePeerAccess(g->device, 0);  // idempotent (an "already enabled" error is cleared below)
+            (void)hipGetLastError();
+        }
+        SQPH_HIP(src, hipMemcpyPeerAsync(g->x + (size_t)offset * n, g->device, src->x, src->device, c * n * sizeof(double), src->stream));
+        if (m) SQPH_HIP(src, hipMemcpyPeerAsync(g->y + (size_t)offset * m, g->device, src->y, src->device, c * m * sizeof(double), src->stream));
+        SQPH_HIP(src, hipMemcpyPeerAsync(g->info + offset, g->device, src->info, src->device, c * sizeof(sqph_info), src->stream));
+    }
     SQPH_HIP(src, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     SQPH_HIP(src, hipEventRecord(ev, src->stream));
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->pending.push_back(ev);
         g->pending_dev.push_back(src->device);
+        if (ev_root) {
+            g->pending.push_back(ev_root);
+            g->pending_dev.push_back(g->device);
+        }
     }
     return SQPH_OK;
 }

@@ -81,8 +81,12 @@ static void sharded_vs_single(int n, int m, int B) {
         for (int g = 0; g < G; g++) d.push_back(g % ndev);
         placements.push_back(d);
     }
+    // every placement twice: default transport (RCCL between different devices, a device-to-device copy on the root's own), and
+    // with every shard's records forced through RCCL (a send to self on a one-GPU box: librccl opened, communicators created,
+    // grouped ncclSend / ncclRecv on the producer's and the gather's streams)
+    for (int pass = 0; pass < 2; pass++)
     for (const auto &devices : placements) {
-        MultiGpuBatchQPSolver<double> multi(n, m, B, devices);
+        MultiGpuBatchQPSolver<double> multi(n, m, B, devices, 0, 0, pass ? SQPH_GATHER_RCCL_ALWAYS : 0);
         const int G = (int)devices.size();
         CHECK(multi.num_devices() == (G < B ? G : B));
         multi.settings() = single.settings();
@@ -101,8 +105,11 @@ static void sharded_vs_single(int n, int m, int B) {
         single.solve(single.packed(B, P.data(), q.data(), A.data(), l.data(), u.data()));
         for (int b = 0; b < B; b++) CHECK(!std::memcmp(multi.primal_solution(b), single.primal_solution(b), sizeof(double) * n));
         single.setup_solve(single.packed(B, P.data(), q.data(), A.data(), l.data(), u.data()));
-        printf("multi-GPU n=%d m=%d batch=%d over %d shard(s) on %d device(s): gathered records bit-identical to the single-device solve\n", n, m, B,
-               multi.num_devices(), ndev < G ? ndev : G);
+        bool distinct = true;
+        for (size_t i = 0; i < devices.size(); i++) distinct = distinct && devices[i] == (int)i;
+        if (pass || (distinct && G > 1)) CHECK(!std::strcmp(multi.gather_transport(), "rccl"));
+        printf("multi-GPU n=%d m=%d batch=%d over %d shard(s) on %d device(s), gather transport %s: gathered records bit-identical to the single-device solve\n", n, m, B,
+               multi.num_devices(), ndev < G ? ndev : G, multi.gather_transport());
     }
 }
 
