@@ -957,6 +957,9 @@ struct WgKernel {
         int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
         for (;;) {
             {  // ---- set-up part of a pass; the W tile is a local of this block so that it is dead in the iteration loop
+#ifndef SQPH_SIM
+            __builtin_amdgcn_s_setprio(2);  // the set-up is one long dependent chain: ahead of the co-resident QPs' multiply-add blocks (note below)
+#endif
             T wt[TW][TC];
             if (!need_factor) load_sq_tile<T>(gW, n, r, c, wt);  // solve() on a previously set-up instance
             if (need_factor) {
@@ -1013,6 +1016,9 @@ struct WgKernel {
                 build_B_inplace(at, wt, n_t, lds, r_t, c_t SQPH_STICK_PASS);
                 SQPH_STICK(5)
             }
+#ifndef SQPH_SIM
+            __builtin_amdgcn_s_setprio(0);
+#endif
             }  // ---- end of the set-up part
             {
                 int n_t = n, r_t = r, c_t = c;
@@ -1043,7 +1049,9 @@ struct WgKernel {
             // Wave priorities: the two waves of a SIMD belong to different QPs; while one is in a latency-bound stretch (the wave-local
             // y1 reduction, the owners' reduction + update behind the barrier: short dependent chains of LDS round trips) the other is
             // usually issuing its multiply-add blocks.  s_setprio 3 for those stretches, 0 for the two FMA blocks, lets the short
-            // chains through first: 2.71 -> 2.67 ms fixed-200, -1.1 % in the default and SQP-settings modes (tools/ab_slim.sh).
+            // chains through first: 2.71 -> 2.67 ms fixed-200, -1.1 % in the default and SQP-settings modes (tools/ab_slim.sh).  The
+            // set-up block and the residual checks — dependent chains from end to end — run at priority 2 (1 or 3 measure the same):
+            // 2.67 -> 2.57 ms fixed-200, 2.14 -> 2.10 default, 1.97 -> 1.93 SQP settings.
             // Segments: the iterations up to the next residual check run in a tight loop that contains no check code (the allocator then
             // keeps its spill code out of it); the check follows, between two segments.
             while (iter <= a.max_iter) {
@@ -1134,7 +1142,7 @@ struct WgKernel {
                         if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - c_q : T(0));
                     }
 #ifndef SQPH_SIM
-                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_setprio(0);  // (held through the loop-top barrier and the operand gathers instead: +0.6 % fixed, -0.6 % default)
 #endif
                     SQPH_TICK(7)
                 }
@@ -1187,6 +1195,9 @@ struct WgKernel {
                         }
                     }
                     if (full_check) {
+#ifndef SQPH_SIM
+                        __builtin_amdgcn_s_setprio(2);  // a chain of memory round trips
+#endif
                         // update_state + residuals, qp.cpp:316-331, 353-361.  A and P are streamed from global
                         // memory here (the register tiles hold B and W); this block runs every check_termination
                         // iterations only.
@@ -1280,6 +1291,9 @@ struct WgKernel {
                                 break;  // leave the iteration loop WITHOUT advancing iter; the factor block does it
                             }
                         }
+#ifndef SQPH_SIM
+                        __builtin_amdgcn_s_setprio(0);
+#endif
                         // the check borrowed the row-gather vector for y: publish w again for the next segment
                         if constexpr (F32) {
                             if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
@@ -1448,6 +1462,9 @@ struct WgKernel {
         int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
         for (;;) {
             {  // ---- set-up part of a pass (the W tile is local to it)
+#ifndef SQPH_SIM
+            __builtin_amdgcn_s_setprio(2);  // as in run(): -0.9 % at C2
+#endif
             T wt[TW][TC];
             if (!need_factor) load_sq_tile<T>(SQPH_GW, n, r, c, wt);
             if (need_factor) {
@@ -1507,6 +1524,9 @@ struct WgKernel {
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
                 build_B_inplace(at, wt, n_t, lds, r_t, c_t);
             }
+#ifndef SQPH_SIM
+            __builtin_amdgcn_s_setprio(0);
+#endif
             }  // ---- end of the set-up part
             {
                 int n_t = n, r_t = r, c_t = c;
