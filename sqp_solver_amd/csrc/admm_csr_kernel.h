@@ -440,24 +440,49 @@ struct CsrKernel {
             __syncthreads();
             const int j = 32 * p + r;
             if (j < n) {
+                // software-pipelined by one entry: the index / coefficient loads of entry e + 1 (two dependent LDS round trips) are
+                // issued before the read-modify-writes of entry e, which the compiler will not move loads across
                 const int e1 = colptr[j + 1];
-                for (int e = colptr[j]; e < e1; e++) {
-                    const unsigned pk = csc[e];
-                    const int i = (int)(pk >> 16);
-                    const T coef = rho[i] * val[pk & 0xffffu];
-                    const int f1 = rowptr[i + 1];
-                    for (int f = rowptr[i] + c; f < f1; f += 32) {
-                        const int k = col[f];
-                        if (k >= j) Sp[r * LDP + k] = wg_fma(coef, val[f], Sp[r * LDP + k]);
+                int e = colptr[j];
+                if (e < e1) {
+                    unsigned pk = csc[e];
+                    int i = (int)(pk >> 16);
+                    T coef = rho[i] * val[pk & 0xffffu];
+                    int f0 = rowptr[i], f1 = rowptr[i + 1];
+                    for (; e < e1; e++) {
+                        const unsigned pkn = csc[e + 1 < e1 ? e + 1 : e];
+                        const int in = (int)(pkn >> 16);
+                        const T coefn = rho[in] * val[pkn & 0xffffu];
+                        const int f0n = rowptr[in], f1n = rowptr[in + 1];
+                        for (int f = f0 + c; f < f1; f += 32) {
+                            const int k = col[f];
+                            if (k >= j) Sp[r * LDP + k] = wg_fma(coef, val[f], Sp[r * LDP + k]);
+                        }
+                        coef = coefn;
+                        f0 = f0n;
+                        f1 = f1n;
                     }
                 }
             }
             __syncthreads();
-            // + lower triangle of P (only it reaches the reference's factor, Eigen::LDLT<.,Lower>, qp.hpp:129) + sigma I
-            for (int e = t; e < 32 * n; e += NT) {
-                const int jj = e / n, k = e - jj * n;
-                const int jc = 32 * p + jj;
-                if (jc < n && k >= jc) Sp[jj * LDP + k] += (T)gP[(long)jc * n + k] + (k == jc ? sigma : T(0));
+            // + lower triangle of P (only it reaches the reference's factor, Eigen::LDLT<.,Lower>, qp.hpp:129) + sigma I.
+            // All of a lane's loads are issued before the first of them is used: the panel additions are LDS read-modify-writes the
+            // compiler will not move a global load across, and one HBM round trip per element (seven per lane and panel, one after
+            // the other) was half of this function's time.
+            {
+                T pv[TT];
+#pragma unroll
+                for (int q = 0; q < TT; q++) {
+                    const int e = t + NT * q;
+                    const int jj = e / n, k = e - jj * n, jc = 32 * p + jj;
+                    pv[q] = (e < 32 * n && jc < n && k >= jc) ? (T)gP[(long)jc * n + k] : T(0);
+                }
+#pragma unroll
+                for (int q = 0; q < TT; q++) {
+                    const int e = t + NT * q;
+                    const int jj = e / n, k = e - jj * n, jc = 32 * p + jj;
+                    if (e < 32 * n && jc < n && k >= jc) Sp[jj * LDP + k] += pv[q] + (k == jc ? sigma : T(0));
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -495,8 +520,9 @@ struct CsrKernel {
                 const T d = gk[NPl];
                 // a bad pivot is only recorded (block-uniform: every lane reads the same word); leaving the loop from here
                 // costs the whole tile its registers (the extra exit made the allocator spill 120 VGPRs)
-                if (!(d > T(0)) || !(d * T(0) == T(0))) good = false;
-                const T dinv = T(1) / d;
+                // (a pivot of the Jacobi-scaled matrix below 1e-290 counts as non-positive: its reciprocal would overflow)
+                if (!(d > T(1e-290)) || !(d * T(0) == T(0))) good = false;
+                const T dinv = fast_rcp(d);  // admm_wg_kernel.h: v_rcp_f64 + two Newton steps (5 instead of 11 instructions)
                 T gc[TT];
 #pragma unroll
                 for (int b = 0; b < TT; b++) gc[b] = gk[c + 32 * b];

@@ -63,6 +63,19 @@ typedef double sqph_v2 __attribute__((vector_size(16)));
 
 __device__ __forceinline__ double wg_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// 1/d for a positive finite normal d: v_rcp_f64 refined by two Newton steps (the sequence inside the compiler's IEEE division without
+// its scaling and fix-up instructions); within 1 ulp of the quotient
+__device__ __forceinline__ double fast_rcp(double d) {
+#ifdef SQPH_SIM
+    return 1.0 / d;
+#else
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+#endif
+}
+
 // N contiguous doubles from a 16-byte aligned LDS address (N rounded up to even is read)
 template <int N>
 __device__ __forceinline__ void wg_read(const double *p, double (&v)[N]) {

@@ -21,8 +21,10 @@ run c3_sqp --workload c3 --mode sqp
 run c2 --workload c2
 run c5 --workload c5 --steps 5
 run lane --n 2 --m 3 --batch-per-gpu 65536
+run c3_full --global-batch 65536 --steps 5
+run c3_f32 --workload c3 --dtype f32 --f32-arith
+run c2_f32 --workload c2 --dtype f32 --f32-arith
 [ $PHASE = prof ] && exit 0
-python bench.py --global-batch 65536 --steps 5 >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
 python bench.py --global-batch 65536 --steps 5 --mode default >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
 python bench.py --n 2 --m 3 --batch-per-gpu 65536 --dtype f32 --f32-arith >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
 python bench.py --n 4 --m 6 --batch-per-gpu 65536 >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
