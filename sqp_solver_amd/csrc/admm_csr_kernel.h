@@ -491,6 +491,125 @@ struct CsrKernel {
         __syncthreads();
     }
 
+    // ---------------------------------------------------------------- DENSE A (run<CHECKS, DENSE = true>)
+    // Dense problems beyond the register-tiled kernels' shapes (112 < n <= 224, or m beyond their row counts, m <= 512): the factor
+    // W lives in the CU's register file exactly as above, A (column-major m x n, 640 KB at n = 200, m = 400) stays in global memory
+    // and is streamed twice per iteration with coalesced loads — once down its columns for A' w (one wavefront per column, w in
+    // registers, a wave reduction per column) and once across them for A x~ (a lane per row and column half, x~ broadcast from LDS).
+    // Such a solve is HBM / Infinity-Cache bound by construction (1.28 MB per QP and iteration); the generic kernel it replaces for
+    // these shapes streamed W and a row-major copy of A as well (1.9 MB) from eight or sixteen waves.
+    static __device__ __forceinline__ void form_S_dense(const TIN *__restrict__ gA, const TIN *__restrict__ gP, int n, int m, T sigma,
+                                                        const CsrLayout<TT> &L, unsigned char *smem, int t, T (&w)[NE]) {
+        const int c = t & 31, r = t >> 5;
+        T *lds = reinterpret_cast<T *>(smem);
+        const T *rho = lds + L.o_rho;
+        T *Ab = lds + L.o_stage;  // RB rows of A, column j at (j & 31) * 8 + (j >> 5): a lane's TT row-side and column-side operands are contiguous
+        constexpr int LDA = 256;
+        constexpr int RB = CsrLayout<TT>::o_tcol / LDA < 16 ? CsrLayout<TT>::o_tcol / LDA : 16;  // rows of A per block (16 from TT = 4 up)
+        static_assert(RB >= 1 && RB * LDA <= CsrLayout<TT>::o_tcol, "the block of A rows fits the staging area");
+#pragma unroll
+        for (int e = 0; e < NE; e++) w[e] = 0;
+        for (int i0 = 0; i0 < m; i0 += RB) {
+            __syncthreads();
+            for (int e = t; e < RB * NP; e += NT) {  // RB consecutive rows of a column are RB consecutive lanes
+                const int ib = e % RB, j = e / RB, i = i0 + ib;
+                Ab[ib * LDA + (j & 31) * 8 + (j >> 5)] = (j < n && i < m) ? (T)gA[(long)j * m + i] : T(0);
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int ib = 0; ib < RB; ib++) {
+                if (i0 + ib >= m) break;
+                const T ri = rho[i0 + ib];
+                T ar[TT], ac[TT];
+                wg_read<TT>(Ab + ib * LDA + r * 8, ar);
+                wg_read<TT>(Ab + ib * LDA + c * 8, ac);
+#pragma unroll
+                for (int a = 0; a < TT; a++) {
+                    const T sa = ar[a] * ri;
+#pragma unroll
+                    for (int b = 0; b <= a; b++) w[idx(a, b)] = wg_fma(sa, ac[b], w[idx(a, b)]);
+                }
+            }
+        }
+        __syncthreads();
+        // + lower triangle of P + sigma I (Eigen::LDLT<.,Lower>, qp.hpp:129); entries above the diagonal are zero as in form_S
+#pragma unroll
+        for (int a = 0; a < TT; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) {
+                const int i = r + 32 * a, j = c + 32 * b;
+                const bool low = i < n && j < n && i >= j;
+                const T pij = low ? (T)gP[(long)j * n + i] + (i == j ? sigma : T(0)) : T(0);
+                w[idx(a, b)] = low ? w[idx(a, b)] + pij : T(0);
+            }
+    }
+    // A' v for every column j < n: wavefront j % 16 takes column j (coalesced loads down the column, v in registers, one wave
+    // reduction per column) and hands  add[j] + (A' v)_j  to out[out_index(j)]; v plain-indexed in LDS.  GATHER: column-gather order.
+    template <bool GATHER>
+    static __device__ __forceinline__ void dense_ATv(const TIN *__restrict__ gA, int n, int m, const T *v, const T *add, T *out, int CS) {
+        const int t = threadIdx.x, l = t & 63, wave = t >> 6;
+        T vr[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) vr[s] = (l + 64 * s < m) ? v[l + 64 * s] : T(0);
+        for (int j = wave; j < n; j += 32) {  // two columns in flight
+            const int j2 = j + 16;
+            const TIN *c0 = gA + (long)j * m, *c1 = gA + (long)(j2 < n ? j2 : j) * m;
+            T x0[8], x1[8];
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int i = l + 64 * s;
+                x0[s] = i < m ? (T)c0[i] : T(0);
+                x1[s] = i < m ? (T)c1[i] : T(0);
+            }
+            T a0 = 0, a1 = 0;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                a0 = wg_fma(x0[s], vr[s], a0);
+                a1 = wg_fma(x1[s], vr[s], a1);
+            }
+            a0 = wave_sum(a0);
+            a1 = wave_sum(a1);
+            if (l == 0) {
+                out[GATHER ? (j & 31) * CS + (j >> 5) : j] = (add ? add[j] : T(0)) + a0;
+                if (j2 < n) out[GATHER ? (j2 & 31) * CS + (j2 >> 5) : j2] = (add ? add[j2] : T(0)) + a1;
+            }
+        }
+    }
+    static __device__ __forceinline__ T wave_sum(T s) {
+        s += xchg<1>(s);
+        s += xchg<2>(s);
+        s += xchg<4>(s);
+        s += xchg<8>(s);
+        s += xchg<16>(s);
+        s += xchg<32>(s);
+        return s;
+    }
+    // partial sums of A v: lane t takes row t & 511 and the column half t >> 9 (coalesced across the rows); zp[2][512]
+    static __device__ __forceinline__ void dense_Av_partial(const TIN *__restrict__ gA, int n, int m, const T *v, T *zp) {
+        const int t = threadIdx.x, i = t & 511, h = t >> 9;
+        const int nh = (n + 1) >> 1, j0 = h * nh, j1 = (j0 + nh < n) ? j0 + nh : n;
+        T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (i < m) {
+            const TIN *p = gA + i;
+            int j = j0;
+            for (; j + 8 <= j1; j += 8) {
+                T x[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = (T)p[(long)(j + k) * m];
+                T vv[8];
+                wg_read8_any(v + j, vv);
+                a0 = wg_fma(x[0], vv[0], a0); a1 = wg_fma(x[1], vv[1], a1); a2 = wg_fma(x[2], vv[2], a2); a3 = wg_fma(x[3], vv[3], a3);
+                a0 = wg_fma(x[4], vv[4], a0); a1 = wg_fma(x[5], vv[5], a1); a2 = wg_fma(x[6], vv[6], a2); a3 = wg_fma(x[7], vv[7], a3);
+            }
+            for (; j < j1; j++) a0 = wg_fma((T)p[(long)j * m], v[j], a0);
+        }
+        zp[h * 512 + i] = (a0 + a1) + (a2 + a3);
+    }
+    static __device__ __forceinline__ void wg_read8_any(const T *p, T (&v)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = p[k];
+    }
+
     // pivots k = 32 AK + rk, rk = 0..31 (see eliminate): g[j] = W-part of row k (j < k) | d + 1 (j = k) | column k of the trailing
     // matrix (j > k); every entry (i,j), i > k, j <= i, gets  e -= (g[i]/d) * g[j].  One barrier per pivot (g is double-buffered).
     template <int AK>
@@ -660,12 +779,14 @@ struct CsrKernel {
     // CHECKS = false: the instantiation for calls that never look at the residuals (check_termination == 0, no adaptive rho); without
     // the check block the tile stays out of scratch (no VGPR spilled instead of 6): 36.9 -> 35.7 ms per 8,192 x 200 iterations (config 5).
     // Instantiated in csr_nocheck.hip only.
-    template <bool CHECKS = true>
+    // DENSE = true: A is the dense column-major matrix of the KArgs (see form_S_dense), ca is unused
+    template <bool CHECKS = true, bool DENSE = false>
     static __device__ void run(const KArgs<T, TIN> &a, const CsrArgs<TIN> &ca, unsigned char *smem) {
         const int qp = blockIdx.x;
         if (qp >= a.batch) return;
         const int n = a.n, m = a.m;
-        const CsrLayout<TT> L = CsrLayout<TT>::make(m, ca.nnz_cap);
+        const CsrLayout<TT> L = CsrLayout<TT>::make(m, DENSE ? 0 : ca.nnz_cap);
+        const TIN *gA = DENSE ? a.A + (long)qp * a.sA : nullptr;
         T *lds = reinterpret_cast<T *>(smem);
         int *li = reinterpret_cast<int *>(smem);
         const int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr;
@@ -704,9 +825,12 @@ struct CsrKernel {
 #else
 #define SQPH_CTICK(k)
 #endif
-        load_sparse(ca, qp, n, m, L, smem);
         int lmap;  // row map in the low half, column map in the high half
-        {
+        if constexpr (DENSE) {  // a lane pair per constraint row (m <= 512); the column map is not used
+            const int t0 = (int)threadIdx.x;
+            lmap = (t0 >> 1) < m ? (MAP_VALID | (1 << 12) | ((t0 & 1) << 9) | (t0 >> 1)) : 0;
+        } else {
+        load_sparse(ca, qp, n, m, L, smem);
             unsigned short *tmap = reinterpret_cast<unsigned short *>(lds + L.o_stage);  // the staging area is idle during the set-up
             int *scratch = reinterpret_cast<int *>(tmap + 2 * NT);
             build_lane_map(rowptr, m, tmap, scratch);
@@ -807,7 +931,14 @@ struct CsrKernel {
                     const TIN *gP_f = gP;
                     SQPH_OPAQUE_S(n_f); SQPH_OPAQUE_S(gP_f);
                     SQPH_LANE(tf);
-                    form_S(gP_f, n_f, sigma, L, smem, tf, w);
+                    if constexpr (DENSE) {
+                        int m_f = m;
+                        const TIN *gA_f = gA;
+                        SQPH_OPAQUE_S(m_f); SQPH_OPAQUE_S(gA_f);
+                        form_S_dense(gA_f, gP_f, n_f, m_f, sigma, L, smem, tf, w);
+                    } else {
+                        form_S(gP_f, n_f, sigma, L, smem, tf, w);
+                    }
                     SQPH_CTICK(1)
                     ok = eliminate(n_f, L, lds, tf, w);
                     SQPH_CTICK(2)
@@ -859,7 +990,12 @@ struct CsrKernel {
                 SQPH_CTICK(8)
                 // every phase re-derives its lane indices from a laundered thread id: kept live across the loop, the LDS
                 // addresses they feed would not fit next to the tile (they were spilled to scratch and reloaded per phase)
-                {   // t = (sigma x - q) + A' w, published in column-gather order
+                if constexpr (DENSE) {
+                    int n_d = n, m_d = m;
+                    const TIN *gA_d = gA;
+                    SQPH_OPAQUE_S(n_d); SQPH_OPAQUE_S(m_d); SQPH_OPAQUE_S(gA_d);
+                    dense_ATv<true>(gA_d, n_d, m_d, wv, ux, tcol, CS);
+                } else {   // t = (sigma x - q) + A' w, published in column-gather order
                     const int cm = (lmap >> 16) & 0xffff;
                     const T s = csc_col_dot_m(colptr, csc, val, wv, cm);
                     const int j = cm & 511;
@@ -903,9 +1039,18 @@ struct CsrKernel {
                 }
                 __syncthreads();
                 SQPH_CTICK(7)
+                if constexpr (DENSE) {  // partial sums of A x~ by row and column half, through the (idle) staging area
+                    int n_d = n, m_d = m;
+                    const TIN *gA_d = gA;
+                    SQPH_OPAQUE_S(n_d); SQPH_OPAQUE_S(m_d); SQPH_OPAQUE_S(gA_d);
+                    dense_Av_partial(gA_d, n_d, m_d, xt, st);
+                    __syncthreads();
+                }
                 {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
                     SQPH_ROWMAP(mp, im, lead, mown);
-                    const T zt = csr_row_dot_m(rowptr, col, val, xt, mp);
+                    T zt;
+                    if constexpr (DENSE) zt = mown ? st[im] + st[512 + im] : T(0);
+                    else zt = csr_row_dot_m(rowptr, col, val, xt, mp);
                     if (mown) {
                         const T zr = alpha * zt + oma * z;
                         T zn = zr + rinvv[im] * y;
@@ -941,11 +1086,23 @@ struct CsrKernel {
                     }
                     if (lead) wv[im] = y;
                     __syncthreads();
-                    const T Ax = csr_row_dot_m(rowptr, col, val, xt, mp);
+                    T Ax;
+                    if constexpr (DENSE) {
+                        int n_d = n, m_d = m;
+                        const TIN *gA_d = gA;
+                        SQPH_OPAQUE_S(n_d); SQPH_OPAQUE_S(m_d); SQPH_OPAQUE_S(gA_d);
+                        dense_Av_partial(gA_d, n_d, m_d, xt, st);
+                        dense_ATv<false>(gA_d, n_d, m_d, wv, (const T *)nullptr, tcol, CS);  // A' y, plain-indexed
+                        __syncthreads();
+                        Ax = mown ? st[im] + st[512 + im] : T(0);
+                        __syncthreads();  // the staging area is handed to the P x partial sums next
+                    } else {
+                    Ax = csr_row_dot_m(rowptr, col, val, xt, mp);
                     {   // A' y by the column map's lanes, handed to the quads that track x through the (idle) column-gather vector
                         const int cm = (lmap >> 16) & 0xffff;
                         const T sATy = csc_col_dot_m(colptr, csc, val, wv, cm);
                         if ((cm & MAP_VALID) && ((cm >> 9) & 7) == 0) tcol[cm & 511] = sATy;
+                    }
                     }
                     {
                         int n_c = n, r_c = tl >> 5, c_c = tl & 31;
@@ -1066,6 +1223,23 @@ __global__ __launch_bounds__(1024) void admm_csr_nocheck_kernel(CsrLaunch<TIN> p
     SQPH_DYN_SMEM(smem_raw);
     CsrKernel<TIN, TT>::template run<false>(p.a, p.ca, smem_raw);
 }
+// dense A streamed from global memory (CsrKernel::run<CHECKS, DENSE = true>); instantiated in csr_dense.hip only
+template <typename TIN, int TT>
+__global__ __launch_bounds__(1024) void admm_csrd_kernel(CsrLaunch<TIN> p) {
+    SQPH_DYN_SMEM(smem_raw);
+    CsrKernel<TIN, TT>::template run<true, true>(p.a, p.ca, smem_raw);
+}
+template <typename TIN, int TT>
+__global__ __launch_bounds__(1024) void admm_csrd_nocheck_kernel(CsrLaunch<TIN> p) {
+    SQPH_DYN_SMEM(smem_raw);
+    CsrKernel<TIN, TT>::template run<false, true>(p.a, p.ca, smem_raw);
+}
+// > 0 launched, 0 shape not covered (n > 224 or m > 512), < 0 HIP error
+template <typename TIN>
+int csrd_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name);
+extern template int csrd_try_launch<double>(const KArgs<double, double> &, hipStream_t, const char **);
+extern template int csrd_try_launch<float>(const KArgs<double, float> &, hipStream_t, const char **);
+
 // launches it where a tile edge TT is compiled in: > 0 launched, 0 no such edge, < 0 HIP error (hipGetLastError has it)
 template <typename TIN>
 int csr_nocheck_launch(int TT, int m, int nnz_cap, int batch, hipStream_t stream, const CsrLaunch<TIN> &p);
@@ -1080,8 +1254,34 @@ extern template int csr_nocheck_launch<float>(int, int, int, int, hipStream_t, c
 #else
 #define SQPH_CSR_SHAPES(X) X(4) X(7)
 #endif
+// tile edges of the dense-A mode (csr_dense.hip): problems with n <= 128 that the register-tiled kernels do not take (m too large) and n <= 224
+#ifdef SQPH_SLIM
+#define SQPH_CSRD_SHAPES(X) X(7)
+#else
+#define SQPH_CSRD_SHAPES(X) X(4) X(7)
+#endif
 // additional small edges for the host SIMT emulation in the CPU test-suite
 #define SQPH_CSR_SIM_SHAPES(X) X(1) X(2) X(4) X(7)
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_csrd(const KArgs<double, TIN> &a) {
+    if (a.m > 512) return -1;
+    const CsrArgs<TIN> ca{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+#define SQPH_SIM_CASE(TT_)                                                                                              \
+    if (a.n <= 32 * TT_) {                                                                                              \
+        const CsrLayout<TT_> L = CsrLayout<TT_>::make(a.m, 0);                                                          \
+        if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0))                               \
+            ::sqph_sim::launch(admm_csrd_nocheck_kernel<TIN, TT_>, dim3(a.batch), dim3(1024), L.bytes, CsrLaunch<TIN>{a, ca}); \
+        else                                                                                                            \
+            ::sqph_sim::launch(admm_csrd_kernel<TIN, TT_>, dim3(a.batch), dim3(1024), L.bytes, CsrLaunch<TIN>{a, ca});  \
+        return 0;                                                                                                       \
+    }
+    SQPH_CSR_SIM_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
 
 #ifdef SQPH_SIM
 template <typename TIN>

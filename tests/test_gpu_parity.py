@@ -47,7 +47,7 @@ def test_reference_cases(case, make):
 
 @pytest.mark.parametrize("make", MAKERS, ids=IDS)
 @pytest.mark.parametrize("n,m,batch,iters", [(2, 3, 7, 200), (20, 40, 128, 200), (50, 100, 64, 200), (13, 57, 16, 100), (56, 104, 8, 50), (64, 30, 8, 50),
-                                             (60, 250, 3, 40), (120, 250, 3, 40)])  # the last two: the generic kernel with 8 / 16 waves per QP
+                                             (60, 250, 3, 40), (120, 250, 3, 40), (60, 600, 2, 30)])  # the last three: beyond the register-tiled shapes (CU-wide dense-A kernel; m > 512: generic)
 def test_parity_fixed_iters(n, m, batch, iters, make):
     cases.parity_fixed_iters(make, n, m, batch, iters=iters)
 
@@ -103,9 +103,25 @@ def test_four_wave_shapes():
     cases.parity_termination(make_gpu, 90, 180, 6, adaptive=True)
 
 
-def test_large_generic_shape():
-    """beyond the tiled kernels: n=120, m=260 takes the 4-wave generic kernel"""
-    cases.parity_fixed_iters(make_gpu, 120, 260, 4, iters=40)
+def test_dense_shapes_beyond_the_register_tiled_kernels():
+    """112 < n <= 224 (or m beyond the tiled shapes' rows), m <= 512: the CU-wide kernel in its dense-A mode (csr_dense.hip: W in the
+    CU's registers, A streamed from global memory twice per iteration) — fixed iterations, termination with adaptive rho, the
+    stateful call sequences at its limits; beyond (m > 512 or n > 224) the generic kernel"""
+    from sqp_solver_amd.problems import random_qp_batch
+
+    for (n, m, b, kern) in ((120, 260, 4, "cud_t4"), (200, 400, 3, "cud_t7"), (50, 500, 3, "cud_t4"), (224, 512, 2, "cud_t7"), (113, 1, 3, "cud_t4"),
+                            (230, 100, 2, "generic"), (100, 520, 2, "generic")):
+        cases.parity_fixed_iters(make_gpu, n, m, b, iters=40)
+        s = make_gpu(n, m, b)
+        s.settings.max_iter, s.settings.check_termination = 5, 0
+        s.setup_solve(*random_qp_batch(b, n, m, seed=1))
+        assert s.kernel_name().startswith(kern), (n, m, s.kernel_name())
+    cases.parity_termination(make_gpu, 150, 300, 4, adaptive=True)
+    cases.parity_termination(make_gpu, 200, 400, 3, sqp_settings=True)
+    cases.fused_then_solve(make_gpu, n=130, m=200, batch=3)
+    cases.warm_start_and_resolve(make_gpu, n=130, m=200)
+    log, kernels = cases.api_sequence_fuzz(make_gpu, 224, 512, 2, seed=77, steps=6)
+    assert any(k.startswith("cud_t7") for k in kernels), kernels
 
 
 def test_csr_reference_cases():
@@ -131,7 +147,8 @@ def test_csr_parity(n, m, batch, density, shared, make):
 
 
 def test_csr_falls_back_when_the_sparse_matrix_does_not_fit_lds():
-    """n=200, m=400 at 12 % density (~9,600 nnz > the ~6,000 the CU's LDS holds next to the vectors): expand + dense path"""
+    """n=200, m=400 at 12 % density (~9,600 nnz > the ~6,000 the CU's LDS holds next to the vectors): expanded to dense on the device,
+    then the dense dispatch — which at this shape is the CU-wide kernel's dense-A mode (round 2: the generic kernel)"""
     from sqp_solver_amd.problems import random_csr_qp_batch
 
     n, m, B = 200, 400, 2
@@ -139,7 +156,7 @@ def test_csr_falls_back_when_the_sparse_matrix_does_not_fit_lds():
     s = make_gpu(n, m, B)
     s.settings.max_iter, s.settings.check_termination = 30, 0
     s.setup_solve_csr(P, q, rp, ci, v, l, u)
-    assert s.kernel_name().startswith("generic"), s.kernel_name()
+    assert s.kernel_name().startswith("cud_t7"), s.kernel_name()
     x, y, z, info = s.solution()
     xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings))
     assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
