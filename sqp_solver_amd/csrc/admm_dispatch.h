@@ -78,6 +78,12 @@ extern template int wg_nocheck_try_launch<float>(const KArgs<double, float> &, h
 // the fp32-product variant of the register-tiled kernels (wg_f32.hip): QPSolver<float> with SQPH_FLAG_F32_ARITH
 int wgf_try_launch(const KArgs<double, float> &a, hipStream_t stream, const char **name);
 
+// the stacked-operator variant of the register-tiled kernels (wg_stack.hip)
+template <typename TIN>
+int wgs_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name);
+extern template int wgs_try_launch<double>(const KArgs<double, double> &, hipStream_t, const char **);
+extern template int wgs_try_launch<float>(const KArgs<double, float> &, hipStream_t, const char **);
+
 // workgroup-tiled kernels (admm_wg_kernel.h): >0 launched, 0 not covered, <0 launch error
 template <typename TIN>
 inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
@@ -90,6 +96,16 @@ inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const 
     constexpr bool always_checks = false;
 #endif
     int skip = skip_env;
+#ifdef SQPH_EXPERIMENTS
+    static const bool no_stack = getenv("SQPH_NO_STACK") != nullptr;
+#else
+    constexpr bool no_stack = false;
+#endif
+    // problems whose first fitting shape is the two-wave 16 x 8 grid and whose m + n fits ten stacked tile rows (wg_stack.hip)
+    if (!no_stack && skip == 0 && !always_checks && !(a.m <= 64 && a.n <= 32)) {
+        const int rc = wgs_try_launch<TIN>(a, stream, name);
+        if (rc != 0) return rc;
+    }
     if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0) && !always_checks)
         return wg_nocheck_try_launch<TIN>(a, stream, name, skip);
 #define SQPH_WG_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                                            \

@@ -23,7 +23,10 @@ namespace sqph {
 // (tests/cpp/sqp_batch_test.cpp) is unchanged by it: 936 / 869 / 149 / 231 strict instances against 937 / 874 / 150 / 231 before,
 // ~50,000 subproblems re-solved by the oracle on identical inputs, 0 mismatches (profiles/r03_sqp_parity_log.txt).
 #ifndef SQPH_LANE_NO_FMA
-#define LFMA(a, b, c) ((T)__builtin_fma((double)(a), (double)(b), (double)(c)))
+// in the arithmetic type itself (the true-fp32 instantiation through doubles cost three conversions per product: it ran slower than fp64)
+__device__ __forceinline__ double lane_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float lane_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#define LFMA(a, b, c) lane_fma((T)(a), (T)(b), (T)(c))
 #else
 #define LFMA(a, b, c) ((a) * (b) + (c))
 #endif

@@ -339,7 +339,8 @@ struct WgKernel {
     // reduction direction, so stage 1 stages ONE set of partial sums (W u and B'w accumulate into the same registers)
     // and every owner sums 16 + 8 + 8 instead of 16 + 8 + 16 + 8 partials per iteration; 18 instead of 25 LDS stores.
     //   stage 1:  y1[TC c + k] += sum_s B[R s + r][.] w[R s + r] + sum_u W[.][R u + r] u[R u + r]      (reduced over r)
-    static __device__ __forceinline__ void stage1(const T (&bt)[TR][TC], const T (&vt)[TW][TC], const T (&w)[TR], const T (&ur)[TW], T *lds,
+    template <int TX>
+    static __device__ __forceinline__ void stage1(const T (&bt)[TR][TC], const T (&vt)[TX][TC], const T (&w)[TR], const T (&ur)[TX], T *lds,
                                                   int r, int c) {
         T pb[TC];
 #pragma unroll
@@ -349,7 +350,7 @@ struct WgKernel {
 #pragma unroll
             for (int k = 0; k < TC; k++) pb[k] = wg_fma(bt[s][k], w[s], pb[k]);
 #pragma unroll
-        for (int u = 0; u < TW; u++)
+        for (int u = 0; u < TX; u++)
 #pragma unroll
             for (int k = 0; k < TC; k++) pb[k] = wg_fma(vt[u][k], ur[u], pb[k]);
         T *st = lds + L::O_STAGE;
@@ -357,7 +358,9 @@ struct WgKernel {
         for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = pb[k];
     }
     //   stage 2:  z~[R s + r] = sum_k B[.][TC c + k] y1[TC c + k] ,  x~[R u + r] = sum_k W[TC c + k][.] y1[TC c + k]   (both over c)
-    static __device__ __forceinline__ void stage2(const T (&bt)[TR][TC], const T (&vt)[TW][TC], const T (&y1)[TC], T *lds, int r, int c) {
+    // STACK: the x~ partial sums continue the z~ array (one stacked (m+n)-vector of outputs, see run())
+    template <int TX, bool STACK = false>
+    static __device__ __forceinline__ void stage2(const T (&bt)[TR][TC], const T (&vt)[TX][TC], const T (&y1)[TC], T *lds, int r, int c) {
         T pz[TR];
 #pragma unroll
         for (int s = 0; s < TR; s++) pz[s] = 0;
@@ -371,9 +374,9 @@ struct WgKernel {
         const int pos = (c + (r >> 3)) & (C - 1);
 #pragma unroll
         for (int s = 0; s < TR; s++) sty[(R * s + r) * L::Cp + pos] = pz[s];
-        T *stx = lds + L::O_STX;
+        T *stx = lds + (STACK ? L::O_STAGE_Y + R * TR * L::Cp : L::O_STX);
 #pragma unroll
-        for (int u = 0; u < TW; u++) {
+        for (int u = 0; u < TX; u++) {
             T acc = 0;
 #pragma unroll
             for (int k = 0; k < TC; k++) acc = wg_fma(vt[u][k], y1[k], acc);
@@ -550,6 +553,35 @@ struct WgKernel {
         }
         wsync();
     }
+    // STACKED operator (run<CHECKS, F32, STACK = true>, problems with m + n <= R (TR + TXS)): instead of padding B to R*TR rows and W' to
+    // R*TW, the rows of W' follow the m rows of B directly — stacked row sigma = m + j holds row j of W' — so the operator takes
+    // TR + TXS tile rows (10 instead of 11 at the C3 shape: 140 instead of 154 multiply-adds per lane and iteration, 14 VGPRs fewer).
+    // Row sigma = R s + r lives in tile row s of lane r as before; the tile rows s < TR are the B tile (rows >= m of it are zero)
+    // PLUS the W' rows that fall into them, the TXS rows beyond are W' only.  Both come from the staged transposed copy of W.
+    static constexpr int TXS = TW - 1;
+    static __device__ __forceinline__ void load_stacked_lds(T *lds, int n, int m, int r, int c, T (&at)[TR][TC], T (&xt)[TXS][TC]) {
+        wsync();
+#pragma unroll
+        for (int s = 0; s < TR + TXS; s++) {
+            const int jp = R * s + r - m;  // row of W' at stacked row R s + r
+            const bool in = jp >= 0 && jp < n;
+            T tmp[L::SLOT];
+            wg_read<L::SLOT>(lds + (in ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
+#pragma unroll
+            for (int k = 0; k < TC; k++) {
+                const T v = (in && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
+                if (s < TR) at[s < TR ? s : 0][k] += v;
+                else xt[s >= TR ? s - TR : 0][k] = v;
+            }
+        }
+        wsync();
+    }
+    // LDS slot of stacked row sigma in the operand vector: tile rows < TR in the row-gather region, the rest in the W-row region
+    static __device__ __forceinline__ int stacked_slot(int sigma) {
+        const int s = sigma / R, rr = sigma % R;
+        return s < TR ? L::O_ROWV + rr * L::TRp + s : L::O_WROW + rr * L::TWp + (s - TR);
+    }
+
     // residual check only: A x partials (staged for the reduction over c) and A' y partials (over r), with the A tile streamed from
     // global memory.  A check is a chain of dependent memory round trips (the register tiles hold B and W', so A and P come from
     // L2 / HBM), hence: loads are unconditional (indices clamped into the matrix; the padding needs no masking because x and y
@@ -836,8 +868,11 @@ struct WgKernel {
     // 8,192 x 200 iterations on the C3 shard.  Those kernels live in a translation unit of their own (wg_nocheck.hip): instantiated next
     // to the checking ones, they changed the register allocation of the latter (+3.7 % on the default-termination run).
     // F32 = true: the iteration's two stages in single precision (stage1_f / stage2_f), everything else unchanged
-    template <bool CHECKS = true, bool F32 = false>
+    // STACK = true: the stacked operator (load_stacked_lds); the host launches it only where m + n <= R (TR + TXS)
+    template <bool CHECKS = true, bool F32 = false, bool STACK = false>
     static __device__ __forceinline__ void run(const KArgs<T, TIN> &a, T *lds) {
+        static_assert(!(F32 && STACK), "the fp32-product variant runs on the padded operator");
+        constexpr int TX = STACK ? TXS : TW;  // tile rows of the iteration's second tile
         static_assert(!F32 || L::F32_FITS, "float views must fit the regions of the double layout");
         float *lf = reinterpret_cast<float *>(lds);
         const int t = threadIdx.x;
@@ -936,7 +971,7 @@ struct WgKernel {
 #ifdef SQPH_SETUP_TIMING
         unsigned long long sqph_stk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sqph_stp = __builtin_amdgcn_s_memtime();
 #endif
-        T vt[TW][TC];  // the tile of W' the iteration runs on (the W tile itself lives only inside the set-up block)
+        T vt[TX][TC];  // the tile of W' the iteration runs on (the W tile itself lives only inside the set-up block)
         T at[TR][TC];  // the A tile; turned into B = A W' in place once the factor is known
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
         if ((mode & MODE_SAME_MATRICES) && (mode & (MODE_SETUP | MODE_UPDATE)) && !(mode & MODE_REFACTOR) &&
@@ -1036,19 +1071,31 @@ struct WgKernel {
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                load_vt_lds(lds, n_t, r_t, c_t, vt);
+                if constexpr (STACK) {
+                    int m_t = m;
+                    SQPH_OPAQUE_S(m_t);
+                    load_stacked_lds(lds, n_t, m_t, r_t, c_t, at, vt);
+                } else {
+                    load_vt_lds(lds, n_t, r_t, c_t, vt);
+                }
                 SQPH_STICK(6)
             }
             T (&bt)[TR][TC] = at;
             sqph_f2 btf[F32 ? TR : 1][L::TC2], vtf[F32 ? TW : 1][L::TC2];
             if constexpr (F32) {
                 tile_to_f32<TR>(at, btf);
-                tile_to_f32<TW>(vt, vtf);
+                tile_to_f32<TX>(vt, vtf);
             }
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
             if constexpr (F32) {
                 if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
                 if (t < L::NR) putf_wrow(lf, r, c, nown ? (float)(sigma * x - qv[t < L::NP ? t : 0]) : 0.0f);
+            } else if constexpr (STACK) {
+                // stacked operand vector [w ; u ; 0]: w_i at stacked row i, u_j at row m + j, zeros beyond m + n
+                if (mown) put_rowv(lds, r, c, rho * (z - rinvv[t] * y));
+                if (nown) lds[stacked_slot(m + t)] = sigma * x - qv[t];
+                for (int sg = t; sg < R * (TR + TX); sg += NT)
+                    if (sg >= m + n) lds[stacked_slot(sg)] = T(0);
             } else {
                 if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
                 if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - qv[t < L::NP ? t : 0] : T(0));
@@ -1082,10 +1129,10 @@ struct WgKernel {
                         getf_wrow(lf, r, ur);
                         stage1_f(btf, vtf, w, ur, lf, r, c);
                     } else {   // stage 1 partials:  B' w + W u, both reduced over r
-                        T w[TR], ur[TW];
+                        T w[TR], ur[TX];
                         get_rowv(lds, r, w);
-                        get_wrow(lds, r, ur);
-                        stage1(bt, vt, w, ur, lds, r, c);
+                        wg_read<TX>(lds + L::O_WROW + r * L::TWp, ur);
+                        stage1<TX>(bt, vt, w, ur, lds, r, c);
                     }
                     SQPH_TICK(1)
                     // y1 = W u + B' w: the R producers of a column group's TC outputs and their consumers in stage 2 are the
@@ -1114,7 +1161,7 @@ struct WgKernel {
                     } else {   // stage 2 partials:  z~ = B y1  and  x~ = W' y1, both reduced over c
                         T y1c[TC];
                         get_colv2(lds, c, y1c);
-                        stage2(bt, vt, y1c, lds, r, c);
+                        stage2<TX, STACK>(bt, vt, y1c, lds, r, c);
                     }
                     SQPH_TICK(5)
                     // the owner's constants do not depend on the partial sums: fetched before the barrier, their LDS latency
@@ -1133,7 +1180,7 @@ struct WgKernel {
                     SQPH_TICK(6)
                     // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
                     // SIMDs are issue-bound at two waves each (a branch-free variant measured 14 % slower)
-                    if (nown) x = alpha * (F32 ? reducef_xt(lf, t) : reduce_xt(lds, t)) + oma * x;
+                    if (nown) x = alpha * (F32 ? reducef_xt(lf, t) : (STACK ? wg_sum<C>(lds + L::O_STAGE_Y + (m + t) * L::Cp) : reduce_xt(lds, t))) + oma * x;
                     if (mown) {
                         const T zt = F32 ? reducef_over_c(lf, t) : reduce_over_c(lds, t);
                         if constexpr (CHECKS) ax = alpha * zt + oma * ax;
@@ -1150,6 +1197,9 @@ struct WgKernel {
                     if constexpr (F32) {
                         if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - c_rinv * y)) : 0.0f);
                         if (t < L::NR) putf_wrow(lf, r, c, nown ? (float)(sigma * x - c_q) : 0.0f);
+                    } else if constexpr (STACK) {
+                        if (mown) put_rowv(lds, r, c, rho * (z - c_rinv * y));
+                        if (nown) lds[stacked_slot(m + t)] = sigma * x - c_q;
                     } else {
                         if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - c_rinv * y) : T(0));
                         if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - c_q : T(0));
@@ -1310,6 +1360,12 @@ struct WgKernel {
                         // the check borrowed the row-gather vector for y: publish w again for the next segment
                         if constexpr (F32) {
                             if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
+                        } else if constexpr (STACK) {
+                            // the check's y vector ran over the stacked rows of the row-gather region: w, the u entries and the zeros again
+                            if (mown) put_rowv(lds, r, c, rho * (z - rinvv[t] * y));
+                            if (nown) lds[stacked_slot(m + t)] = sigma * x - qv[t];
+                            for (int sg = t; sg < R * TR; sg += NT)
+                                if (sg >= m + n) lds[stacked_slot(sg)] = T(0);
                         } else {
                             if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
                         }
@@ -1565,7 +1621,7 @@ struct WgKernel {
                     T w[TR], ur[TW];
                     get_rowv(lds, r, w);
                     get_wrow(lds, r, ur);
-                    stage1(bt, vt, w, ur, lds, r, c);
+                    stage1<TW>(bt, vt, w, ur, lds, r, c);
                 }
                 wsync();
 #pragma unroll
@@ -1577,7 +1633,7 @@ struct WgKernel {
                 {
                     T y1c[TC];
                     get_colv2(lds, c, y1c);
-                    stage2(bt, vt, y1c, lds, r, c);
+                    stage2<TW>(bt, vt, y1c, lds, r, c);
                 }
                 wsync();
 #pragma unroll
@@ -1777,6 +1833,27 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_nocheck_kernel(KArgs<dou
     WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false>(a, lds);
 }
 
+// the stacked operator (WgKernel::run<CHECKS, false, STACK = true>) for problems with m + n <= R (TR + TW - 1); instantiated in
+// wg_stack.hip only
+template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void admm_wgs_kernel(KArgs<double, TIN> a) {
+    __shared__ __attribute__((aligned(16))) double lds[WgLayout<NW, R, C, TR, TC, TW>::TOTAL];
+#ifdef SQPH_SIM
+    ::sqph_sim::poison_static_lds(lds, sizeof(lds));
+#endif
+    WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<true, false, true>(a, lds);
+}
+template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
+__global__ __launch_bounds__(64 * NW, WPE) void admm_wgs_nocheck_kernel(KArgs<double, TIN> a) {
+    __shared__ __attribute__((aligned(16))) double lds[WgLayout<NW, R, C, TR, TC, TW>::TOTAL];
+#ifdef SQPH_SIM
+    ::sqph_sim::poison_static_lds(lds, sizeof(lds));
+#endif
+    WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false, false, true>(a, lds);
+}
+// shapes of the stacked variant {NW, R, C, TR, TC, TW, WPE}: the C3 shape (m <= 112, n <= 56, m + n <= 160)
+#define SQPH_WGS_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
+
 // fp32 products (SQPH_FLAG_F32_ARITH with QPSolver<float>): the same kernels with the iteration's two stages in single precision;
 // instantiated in wg_f32.hip only
 template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
@@ -1890,6 +1967,23 @@ inline int sim_run_g16(const KArgs<double, TIN> &a) {
         return 0;                                                                                          \
     }
     SQPH_G16_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_wgs(const KArgs<double, TIN> &a) {
+#define SQPH_SIM_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                         \
+    if (a.m <= R_ * TR_ && a.n <= C_ * TC_ && a.m + a.n <= R_ * (TR_ + TW_ - 1)) {                            \
+        if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0))                      \
+            ::sqph_sim::launch(admm_wgs_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>, dim3(a.batch), dim3(64 * NW_), 0, a); \
+        else                                                                                                  \
+            ::sqph_sim::launch(admm_wgs_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>, dim3(a.batch), dim3(64 * NW_), 0, a); \
+        return 0;                                                                                             \
+    }
+    SQPH_WGS_SHAPES(SQPH_SIM_CASE)
 #undef SQPH_SIM_CASE
     return -1;
 }

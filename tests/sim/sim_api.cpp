@@ -83,6 +83,7 @@ void sim_set_tile_quant(int on) { ::sqph_sim::tile_quant() = on != 0; }
 // variant: 0 = generic (nt threads per QP); 2 = workgroup-tiled; 4 / 5 = four / two QPs per wavefront; 6 = one QP per lane
 int sim_run(const SimArgs *s, int variant, int dtype, int nt) {
     if (variant == 9) return dtype == SQPH_F32 ? run_generic_f32_arith(*s, nt) : -1;
+    if (variant == 12) return dtype == SQPH_F32 ? sqph::sim_run_wgs<float>(convert<float>(*s)) : sqph::sim_run_wgs<double>(convert<double>(*s));  // stacked operator
     if (variant == 11) return dtype == SQPH_F32 ? sqph::sim_run_csrd<float>(convert<float>(*s)) : sqph::sim_run_csrd<double>(convert<double>(*s));  // dense A streamed, W in registers
     if (variant == 10) return dtype == SQPH_F32 ? sqph::sim_run_wgf<float>(convert<float>(*s)) : -1;  // fp32-product register-tiled kernels
     if (variant == 0) return dtype == SQPH_F32 ? run_generic<float>(*s, nt) : run_generic<double>(*s, nt);

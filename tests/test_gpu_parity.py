@@ -545,7 +545,22 @@ def test_hip_graph_capture_of_the_fused_call():
             xd, yd = (a.copy() for a in s.solution()[:2])
             assert np.array_equal(xg, xd) and np.array_equal(yg, yd)
             assert not np.array_equal(xg, x0)
-    assert s.kernel_name() == "wg2_16x8_7x7_w2"
+    assert s.kernel_name() == "wg2_16x8_7x7s_w2"  # (50,100): the stacked operator, wg_stack.hip
+
+
+def test_stacked_and_padded_operator_of_the_c3_grid():
+    """m <= 112, n <= 56 on the two-wave 16 x 8 grid: problems with m + n <= 160 run the iteration on the STACKED operator (10 tile rows,
+    wg_stack.hip), the others on the padded one (11 rows) — both against the oracle at their limits, fixed and under termination"""
+    from sqp_solver_amd.problems import random_qp_batch
+
+    for (n, m, kern) in ((50, 100, "wg2_16x8_7x7s_w2"), (56, 104, "wg2_16x8_7x7s_w2"), (48, 112, "wg2_16x8_7x7s_w2"), (33, 65, "wg2_16x8_7x7s_w2"),
+                         (56, 112, "wg2_16x8_7x7_w2"), (50, 111, "wg2_16x8_7x7_w2")):
+        cases.parity_fixed_iters(make_gpu, n, m, 16, iters=80)
+        s = make_gpu(n, m, 4)
+        s.setup_solve(*random_qp_batch(4, n, m, seed=1))
+        assert s.kernel_name() == kern, (n, m, s.kernel_name())
+        cases.parity_termination(make_gpu, n, m, 24, adaptive=True)
+    cases.parity_termination(make_gpu, 49, 111, 24, sqp_settings=True)
 
 
 @pytest.mark.parametrize("n,m,batch,adaptive_ok", [(2, 3, 5, False), (8, 12, 4, True), (20, 40, 3, True), (50, 100, 2, True)])

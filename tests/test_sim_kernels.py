@@ -268,6 +268,24 @@ def test_lane_true_fp32_variant():
     cases.ref_testSinglePrecisionFloat(make_lane_f32)
 
 
+def make_wg_stack(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.WG_STACK, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
+
+
+def test_wg_stacked_operator():
+    """WgKernel::run<CHECKS, false, STACK = true> (wg_stack.hip): the rows of W' follow the m rows of B in one stacked operator of
+    TR + TW - 1 tile rows — shapes with m not a multiple of the grid's 16 rows (the W' rows start inside a B tile row), m + n at the
+    limit of 160, tiny ones; termination in the three settings; state paths"""
+    for (n, m, b) in ((50, 100, 2), (56, 104, 2), (48, 112, 1), (33, 65, 2), (7, 3, 2)):
+        cases.parity_fixed_iters(make_wg_stack, n, m, b, iters=60)
+    cases.parity_fixed_iters(make_wg_stack, 49, 99, 2, iters=40, dtype=np.float32)
+    for kw in (dict(), dict(adaptive=True), dict(sqp_settings=True)):
+        cases.parity_termination(make_wg_stack, 50, 100, 3, **kw)
+    cases.fused_then_solve(make_wg_stack, n=50, m=100, batch=2)
+    cases.warm_start_and_resolve(make_wg_stack, n=40, m=77)
+    cases.soc_factor_reuse(make_wg_stack, n=50, m=100, batch=2)
+
+
 def make_csr_dense(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
     return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.CSR_DENSE, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
 
