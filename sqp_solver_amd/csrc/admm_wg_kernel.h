@@ -495,7 +495,10 @@ struct WgKernel {
     // B = A W' IN PLACE over the A tile (bt[s][k] = sum_j A[R s + r][j] * W[TC c + k][j], W lower triangular).
     // W is staged once (transposed) in LDS from the register tile, A goes through LDS one block of R rows at
     // a time — nothing is re-read from global memory.
-    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c SQPH_STICK_ARGS) {
+    // STACK (stacked operator, see load_stacked_lds): the rows of W' that fall into tile row s of the B tile (stacked row R s + r = m + j)
+    // are added as soon as that tile row is done — from the same staged copy, while nothing else is live that is not live anyway
+    template <bool STACK = false>
+    static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c, int m SQPH_STICK_ARGS) {
         // All of W is staged once, transposed, in [0, NP * WSTR): Wf[j][slot(i')] = W[i'][j].  It serves the B = A W' product below
         // (the W tile's registers are dead from here on) and, afterwards, the W -> W' transposition of load_vt_lds().  The A tile goes
         // through As one block of R rows at a time; nothing goes through global memory.
@@ -534,6 +537,14 @@ struct WgKernel {
             }
 #pragma unroll
             for (int k = 0; k < TC; k++) at[s][k] = SQPH_TILE_QUANT(acc[k]);
+            if constexpr (STACK) {
+                const int jp = R * s + r - m;  // row of W' at stacked row R s + r
+                const bool in = jp >= 0 && jp < n;
+                T tmp[L::SLOT];
+                wg_read<L::SLOT>(Wf + (in ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
+#pragma unroll
+                for (int k = 0; k < TC; k++) at[s][k] += (in && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
+            }
         }
         // The W' tile (vt[u][k] = W[TC c + k][R u + r]) is picked up from Wf by load_vt_lds() once the set-up block — and with it
         // the W tile's registers — has ended.  (Computing vt inside this block, next to the live W tile, put 20 tile registers of
@@ -559,20 +570,16 @@ struct WgKernel {
     // Row sigma = R s + r lives in tile row s of lane r as before; the tile rows s < TR are the B tile (rows >= m of it are zero)
     // PLUS the W' rows that fall into them, the TXS rows beyond are W' only.  Both come from the staged transposed copy of W.
     static constexpr int TXS = TW - 1;
-    static __device__ __forceinline__ void load_stacked_lds(T *lds, int n, int m, int r, int c, T (&at)[TR][TC], T (&xt)[TXS][TC]) {
+    static __device__ __forceinline__ void load_stacked_lds(T *lds, int n, int m, int r, int c, T (&xt)[TXS][TC]) {
         wsync();
 #pragma unroll
-        for (int s = 0; s < TR + TXS; s++) {
-            const int jp = R * s + r - m;  // row of W' at stacked row R s + r
+        for (int u = 0; u < TXS; u++) {  // the tile rows beyond the B tile (the W' rows inside it were added by build_B_inplace<true>)
+            const int jp = R * (TR + u) + r - m;
             const bool in = jp >= 0 && jp < n;
             T tmp[L::SLOT];
             wg_read<L::SLOT>(lds + (in ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
 #pragma unroll
-            for (int k = 0; k < TC; k++) {
-                const T v = (in && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
-                if (s < TR) at[s < TR ? s : 0][k] += v;
-                else xt[s >= TR ? s - TR : 0][k] = v;
-            }
+            for (int k = 0; k < TC; k++) xt[u][k] = (in && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
         }
         wsync();
     }
@@ -1061,7 +1068,7 @@ struct WgKernel {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
                 SQPH_STICK(7)
-                build_B_inplace(at, wt, n_t, lds, r_t, c_t SQPH_STICK_PASS);
+                build_B_inplace<STACK>(at, wt, n_t, lds, r_t, c_t, m SQPH_STICK_PASS);
                 SQPH_STICK(5)
             }
 #ifndef SQPH_SIM
@@ -1074,7 +1081,7 @@ struct WgKernel {
                 if constexpr (STACK) {
                     int m_t = m;
                     SQPH_OPAQUE_S(m_t);
-                    load_stacked_lds(lds, n_t, m_t, r_t, c_t, at, vt);
+                    load_stacked_lds(lds, n_t, m_t, r_t, c_t, vt);
                 } else {
                     load_vt_lds(lds, n_t, r_t, c_t, vt);
                 }
@@ -1591,7 +1598,7 @@ struct WgKernel {
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                build_B_inplace(at, wt, n_t, lds, r_t, c_t);
+                build_B_inplace<false>(at, wt, n_t, lds, r_t, c_t, m);
             }
 #ifndef SQPH_SIM
             __builtin_amdgcn_s_setprio(0);

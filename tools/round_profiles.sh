@@ -29,4 +29,5 @@ python bench.py --global-batch 65536 --steps 5 --mode default >> gpurun_out/${TA
 python bench.py --n 2 --m 3 --batch-per-gpu 65536 --dtype f32 --f32-arith >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
 python bench.py --n 4 --m 6 --batch-per-gpu 65536 >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
 python bench.py --n 4 --m 6 --batch-per-gpu 65536 --dtype f32 --f32-arith >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
+python bench.py --n 200 --m 400 --batch-per-gpu 512 --steps 5 >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null   # dense beyond the tiled shapes (csr_dense.hip)
 mv gpurun_out/${TAG}_bench_lines.new gpurun_out/${TAG}_bench_lines.jsonl
