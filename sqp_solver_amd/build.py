@@ -61,7 +61,7 @@ def build_f32_tiles_experiment(verbose=False):
     srcs = [os.path.join(CSRC, f) for f in ("capi.hip", "wg_nocheck.hip", "csr_nocheck.hip", "wg_f32.hip", "csr_dense.hip", "wg_stack.hip")]
     if os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in sources()):
         return out
-    cmd = [HIPCC] + FLAGS + ["-DSQPH_SLIM", "-DSQPH_SLIM_G32", "-DSQPH_F32_TILE_STORAGE", "-o", out] + srcs
+    cmd = [HIPCC] + FLAGS + ["-DSQPH_SLIM", "-DSQPH_SLIM_C2", "-DSQPH_F32_TILE_STORAGE", "-o", out] + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)

@@ -46,29 +46,6 @@ inline int g16_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const
     return 0;
 }
 
-// two QPs per wavefront (32 lanes each): >0 launched, 0 not covered, <0 error
-template <typename TIN>
-inline int g32_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name) {
-#ifdef SQPH_EXPERIMENTS
-    static const bool off = getenv("SQPH_NO_G32") != nullptr;
-    if (off) return 0;
-#endif
-    // Two QPs share a wavefront until the slower one is done.  With termination checks the iteration counts of the
-    // reference's default settings are heavy-tailed (most QPs stop at 75-200, some run to max_iter) and the 1.24x this
-    // kernel gains at equal counts is lost (measured at n = 20, m = 40: 1.51 vs 1.21 ms); the four-per-wave kernel's 3x
-    // on smaller shapes survives it (2.9 vs 4.6 ms at n = 8, m = 12).
-    if (a.check_termination != 0) return 0;
-#define SQPH_G32_CASE(TR_, TC_, TW_, W_)                                                                                       \
-    if (a.m <= 8 * TR_ && a.n <= 4 * TC_) {                                                                                    \
-        hipLaunchKernelGGL((admm_g32_kernel<TIN, TR_, TC_, TW_, W_>), dim3((a.batch + 1) / 2), dim3(64), 0, stream, a);        \
-        *name = "g32_" #TR_ "x" #TC_ "_w" #W_;                                                                                 \
-        return hipGetLastError() == hipSuccess ? 1 : -1;                                                                       \
-    }
-    SQPH_G32_SHAPES(SQPH_G32_CASE)
-#undef SQPH_G32_CASE
-    return 0;
-}
-
 // the same shapes without the residual-check block, for calls that never check (wg_nocheck.hip: a translation unit of its own)
 template <typename TIN>
 int wg_nocheck_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name, int skip);

@@ -899,7 +899,22 @@ struct WgKernel {
         int *sct = a.ctype + (long)qp * m;
         T *gW = a.Sinv + (long)qp * 2 * n * n;
 
-        sqph_info info = a.info[qp];
+        // Calls that never check (CHECKS = false) touch status / iter / rho_updates only: those three travel in scalar registers and
+        // the record's doubles stay where they are.  (Kept whole in registers, the record was spilled: 32 B of scratch per lane, 33 MB
+        // of HBM writes per C3 launch.  The checking kernels keep it whole: writing the residuals from the check block instead measured
+        // +0.4 % default / +1 % SQP settings.)
+        sqph_info info;
+        if constexpr (CHECKS) {
+            info = a.info[qp];
+        } else {
+#ifdef SQPH_SIM
+            info = a.info[qp];
+#else
+            info.status = __builtin_amdgcn_readfirstlane(a.info[qp].status);
+            info.iter = __builtin_amdgcn_readfirstlane(a.info[qp].iter);
+            info.rho_updates = __builtin_amdgcn_readfirstlane(a.info[qp].rho_updates);
+#endif
+        }
         T rho_s = a.rho[qp];
         const int mode = a.mode;
         if (!(mode & (MODE_SETUP | MODE_UPDATE)) &&
@@ -1402,7 +1417,13 @@ struct WgKernel {
             }
         }
         if (t == 0) {
-            a.info[qp] = info;
+            if constexpr (CHECKS) {
+                a.info[qp] = info;
+            } else {
+                a.info[qp].status = info.status;
+                a.info[qp].iter = info.iter;
+                a.info[qp].rho_updates = info.rho_updates;
+            }
             a.rho[qp] = rho_s;
         }
 #if defined(SQPH_EXPERIMENTS) && !defined(SQPH_SIM)
@@ -1896,15 +1917,9 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 // (the same path with one QP per wavefront — 8 x 8 grid, TR = 13, TC = 7, 481 VGPRs, one wave per SIMD — measured
 // 4.99 ms on the C3 shard against 3.72 ms for the two-waves-per-QP workgroup kernel: without a second wave per SIMD
 // nothing hides the LDS round trips)
-// two QPs per wavefront: an 8 x 4 grid of 32 lanes per QP (m <= 8 TR, n <= 4 TC, W rows 8 TW >= n)
-template <typename TIN, int TR, int TC, int TW, int WPE>
-__global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * WgKernel<TIN, 0, 8, 4, TR, TC, TW>::GTOTAL];
-#ifdef SQPH_SIM
-    ::sqph_sim::poison_static_lds(lds, sizeof(lds));
-#endif
-    WgKernel<TIN, 0, 8, 4, TR, TC, TW>::run_group(a, lds);
-}
+// (two QPs per wavefront — an 8 x 4 grid of 32 lanes per QP, `admm_g32_kernel`, rounds 1-2 — is retired: at its one shape, n <= 20 and
+// m <= 40 with fixed iteration counts, the one-wave-per-QP kernel is the faster one since round 3 (wave priorities): 0.332 against
+// 0.347 ms per 4,096 x 200 iterations, 1.19 against 1.30 ms per 16,384)
 
 // shapes compiled into the library: {NW, R, C, TR, TC, TW, WPE}; first fit (m <= R*TR, n <= C*TC) wins.  The 32 x 8 grids are for
 // problems with many more constraints than variables (m <= 224 with n <= 16 / 32 / 56): measured 4,096 x (10,150) 1.43 ms against
@@ -1913,11 +1928,10 @@ __global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a)
 // serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x)
 // (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
 #ifdef SQPH_SLIM
-#define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
-#ifdef SQPH_SLIM_G32  // ... plus the C2 shape (two QPs per wavefront)
-#define SQPH_G32_SHAPES(X) X(5, 5, 3, 2)
+#ifdef SQPH_SLIM_C2  // ... plus the C2 shape
+#define SQPH_WG_SHAPES(X) X(1, 8, 8, 5, 3, 3, 3) X(2, 16, 8, 7, 7, 4, 2)
 #else
-#define SQPH_G32_SHAPES(X)
+#define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
 #endif
 #define SQPH_G16_SHAPES(X)
 #else
@@ -1938,32 +1952,12 @@ __global__ __launch_bounds__(64, WPE) void admm_g32_kernel(KArgs<double, TIN> a)
     X(8, 64, 8, 7, 4, 1, 2)      \
     X(8, 64, 8, 7, 7, 1, 2)
 
-// shapes {TR, TC, TW, WPE}.  Measured (200 iterations): n = 20, m = 40 at 4,096 QPs 0.415 ms against 0.477 ms for four QPs per
-// wave (10 x 5 tiles, one wave per SIMD) and 0.513 ms for one QP per wave; an 8 x 8 tile shape (m <= 64, n <= 32, 322 VGPRs)
-// lost to the one-wave-per-QP kernel (3.19 vs 2.44 ms at 16,384 QPs) and is not compiled.
-#define SQPH_G32_SHAPES(X) \
-    X(5, 5, 3, 2)
-
 // shapes {TR, TC, WPE}: m <= 4 TR, n <= 4 TC; first fit wins
 #define SQPH_G16_SHAPES(X) \
     X(1, 1, 4)             \
     X(3, 2, 4)             \
     X(6, 3, 2)
 #endif  // SQPH_SLIM
-
-#ifdef SQPH_SIM
-template <typename TIN>
-inline int sim_run_g32(const KArgs<double, TIN> &a) {
-#define SQPH_SIM_CASE(TR_, TC_, TW_, W_)                                                                         \
-    if (a.m <= 8 * TR_ && a.n <= 4 * TC_) {                                                                      \
-        ::sqph_sim::launch(admm_g32_kernel<TIN, TR_, TC_, TW_, W_>, dim3((a.batch + 1) / 2), dim3(64), 0, a);    \
-        return 0;                                                                                                \
-    }
-    SQPH_G32_SHAPES(SQPH_SIM_CASE)
-#undef SQPH_SIM_CASE
-    return -1;
-}
-#endif
 
 #ifdef SQPH_SIM
 template <typename TIN>

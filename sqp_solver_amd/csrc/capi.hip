@@ -684,7 +684,6 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         }
         if (rc == 0) rc = lane_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = g16_try_launch<TIN>(a, s->stream, &s->kernel_name);
-        if (rc == 0) rc = g32_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc == 0) rc = wg_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "tiled kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         launched = rc > 0;

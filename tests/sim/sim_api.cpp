@@ -87,7 +87,6 @@ int sim_run(const SimArgs *s, int variant, int dtype, int nt) {
     if (variant == 11) return dtype == SQPH_F32 ? sqph::sim_run_csrd<float>(convert<float>(*s)) : sqph::sim_run_csrd<double>(convert<double>(*s));  // dense A streamed, W in registers
     if (variant == 10) return dtype == SQPH_F32 ? sqph::sim_run_wgf<float>(convert<float>(*s)) : -1;  // fp32-product register-tiled kernels
     if (variant == 0) return dtype == SQPH_F32 ? run_generic<float>(*s, nt) : run_generic<double>(*s, nt);
-    if (variant == 5) return dtype == SQPH_F32 ? sqph::sim_run_g32<float>(convert<float>(*s)) : sqph::sim_run_g32<double>(convert<double>(*s));
     if (variant == 4) return dtype == SQPH_F32 ? sqph::sim_run_g16<float>(convert<float>(*s)) : sqph::sim_run_g16<double>(convert<double>(*s));
     if (variant == 7) return dtype == SQPH_F32 ? sqph::sim_run_lane<float, float>(convert<float>(*s)) : -1;
     if (variant == 6) return dtype == SQPH_F32 ? sqph::sim_run_lane<float>(convert<float>(*s)) : sqph::sim_run_lane<double>(convert<double>(*s));

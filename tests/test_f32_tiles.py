@@ -47,6 +47,6 @@ def test_f32_tile_storage_on_the_gpu(tmp_path):
     env = dict(os.environ, SQPH_LIB=lib)
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "f32_tiles_measure.py"), "--backend", "gpu", "--out", out], env=env, timeout=900)
     recs = json.load(open(out))
-    assert [r["kernel"] for r in recs] == ["g32_5x5_w2", "wg2_16x8_7x7s_w2"]
+    assert [r["kernel"] for r in recs] == ["wg1_8x8_5x3_w3", "wg2_16x8_7x7s_w2"]
     for rec in recs:
         _check(rec)

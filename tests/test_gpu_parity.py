@@ -571,7 +571,7 @@ def test_api_sequence_fuzz(n, m, batch, adaptive_ok):
         log, kernels = cases.api_sequence_fuzz(make_gpu, n, m, batch, seed=100 * n + seed, adaptive_ok=adaptive_ok)
         seen |= kernels
     print(n, m, sorted(seen))
-    # the sequences did cross kernel families (verbose -> recording kernels, check_termination -> g32 / wg); the one-QP-per-lane
+    # the sequences did cross kernel families (verbose -> recording kernels, check_termination -> g16 / wg); the one-QP-per-lane
     # kernel records traces itself and serves every setting
     assert len(seen) >= (1 if n <= 4 else 2), seen
 

@@ -181,31 +181,8 @@ def test_wg_tall_shapes(n, m):
         cases.fused_then_solve(mk, n, m, 2, adaptive=False)  # (adaptive rho on these constraint-heavy QPs sits at the fp64 noise floor)
 
 
-# ------------------------------------------------------------------ two QPs per wavefront (8 x 4 lane grid per QP)
-def make_g32(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
-    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G32, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
-
-
-@pytest.mark.parametrize("n,m,batch", [(5, 7, 5), (20, 40, 5), (17, 33, 3)])
-def test_g32_parity_fixed(n, m, batch):
-    cases.parity_fixed_iters(make_g32, n, m, batch, iters=100)
-
-
-@pytest.mark.parametrize("kw", [dict(), dict(adaptive=True), dict(sqp_settings=True)], ids=["default", "adaptive", "sqp"])
-def test_g32_parity_termination(kw):
-    cases.parity_termination(make_g32, 20, 40, 5, **kw)
-
-
-def test_g32_state_paths():
-    cases.ref_testSimpleQP(make_g32)
-    cases.warm_start_and_resolve(make_g32)
-    cases.set_state_warm_start(make_g32)
-    cases.uninitialized_and_numerical_issues(make_g32)
-    cases.shared_matrices(make_g32)
-
-
-@pytest.mark.parametrize("make,n,m", [(make_generic, 6, 9), (make_wg, 8, 12), (make_wg, 50, 100), (make_g16, 8, 12), (make_g32, 20, 40)],
-                         ids=["generic", "wg1", "wg2", "g16", "g32"])
+@pytest.mark.parametrize("make,n,m", [(make_generic, 6, 9), (make_wg, 8, 12), (make_wg, 50, 100), (make_g16, 8, 12), (make_wg, 20, 40)],
+                         ids=["generic", "wg1", "wg2", "g16", "wg1_c2"])
 def test_fused_call_then_solve(make, n, m):
     """factor residency policy (capi.hip, mirrored by simlib): fused setup_solve without / with keep_factor, then solve()"""
     cases.fused_then_solve(make, n=n, m=m, batch=2)

@@ -52,7 +52,7 @@ def measure(backend, n, m, batch, iters, seed=11):
     if backend == "sim":
         import simlib
 
-        variant = simlib.G32 if (n <= 20 and m <= 40) else simlib.WG
+        variant = simlib.WG
         simlib.lib().sim_set_tile_quant(0)
         x0, y0, _ = run(lambda: simlib.SimSolverBatch(n, m, batch, dtype=np.float32, variant=variant))
         simlib.lib().sim_set_tile_quant(1)
@@ -63,7 +63,7 @@ def measure(backend, n, m, batch, iters, seed=11):
         xg, yg, _ = run(lambda: simlib.SimSolverBatch(n, m, batch, dtype=np.float32, variant=simlib.GENERIC_F32_ARITH, nt=64))
         rec["schur32_vs_truth"] = {"x": rel(xg, xt), "y": rel(yg, yt, 1e-3)}
         rec["schur32_vs_ref32"] = {"x": rel(xg, xr), "y": rel(yg, yr, 1e-3)}
-        rec["kernel"] = "g32" if variant == simlib.G32 else "wg"
+        rec["kernel"] = "wg"
     else:
         from sqp_solver_amd import QPSolverBatch
 
