@@ -403,8 +403,9 @@ struct WgKernel {
                 dst[s][kp][1] = (2 * kp + 1 < TC) ? (float)src[s][2 * kp + 1 < TC ? 2 * kp + 1 : 0] : 0.0f;
             }
     }
-    static __device__ __forceinline__ void stage1_f(const sqph_f2 (&bt)[TR][L::TC2], const sqph_f2 (&vt)[TW][L::TC2], const float (&w)[TR],
-                                                    const float (&ur)[TW], float *lf, int r, int c) {
+    template <int TX>
+    static __device__ __forceinline__ void stage1_f(const sqph_f2 (&bt)[TR][L::TC2], const sqph_f2 (&vt)[TX][L::TC2], const float (&w)[TR],
+                                                    const float (&ur)[TX], float *lf, int r, int c) {
         sqph_f2 pb[L::TC2];
 #pragma unroll
         for (int kp = 0; kp < L::TC2; kp++) pb[kp] = sqph_f2{0.0f, 0.0f};
@@ -415,7 +416,7 @@ struct WgKernel {
             for (int kp = 0; kp < L::TC2; kp++) pb[kp] = wgf_fma2(bt[s][kp], ws, pb[kp]);
         }
 #pragma unroll
-        for (int u = 0; u < TW; u++) {
+        for (int u = 0; u < TX; u++) {
             const sqph_f2 us = {ur[u], ur[u]};
 #pragma unroll
             for (int kp = 0; kp < L::TC2; kp++) pb[kp] = wgf_fma2(vt[u][kp], us, pb[kp]);
@@ -424,7 +425,8 @@ struct WgKernel {
 #pragma unroll
         for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rf + r] = pb[k / 2][k & 1];
     }
-    static __device__ __forceinline__ void stage2_f(const sqph_f2 (&bt)[TR][L::TC2], const sqph_f2 (&vt)[TW][L::TC2], const float (&y1)[TC],
+    template <int TX, bool STACK = false>
+    static __device__ __forceinline__ void stage2_f(const sqph_f2 (&bt)[TR][L::TC2], const sqph_f2 (&vt)[TX][L::TC2], const float (&y1)[TC],
                                                     float *lf, int r, int c) {
         sqph_f2 yp[L::TC2];
 #pragma unroll
@@ -433,7 +435,7 @@ struct WgKernel {
             yp[kp][1] = (2 * kp + 1 < TC) ? y1[2 * kp + 1 < TC ? 2 * kp + 1 : 0] : 0.0f;
         }
         float *sty = lf + 2 * L::O_STAGE_Y;
-        float *stx = lf + 2 * L::O_STX;
+        float *stx = lf + (STACK ? 2 * L::O_STAGE_Y + R * TR * L::Cf : 2 * L::O_STX);
 #pragma unroll
         for (int s = 0; s < TR; s++) {
             sqph_f2 acc = {0.0f, 0.0f};
@@ -442,7 +444,7 @@ struct WgKernel {
             sty[(R * s + r) * L::Cf + c] = acc[0] + acc[1];
         }
 #pragma unroll
-        for (int u = 0; u < TW; u++) {
+        for (int u = 0; u < TX; u++) {
             sqph_f2 acc = {0.0f, 0.0f};
 #pragma unroll
             for (int kp = 0; kp < L::TC2; kp++) acc = wgf_fma2(vt[u][kp], yp[kp], acc);
@@ -582,6 +584,10 @@ struct WgKernel {
             for (int k = 0; k < TC; k++) xt[u][k] = (in && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
         }
         wsync();
+    }
+    static __device__ __forceinline__ int stacked_slot_f(int sigma) {  // the same for the float views of the fp32-product variant
+        const int s = sigma / R, rr = sigma % R;
+        return s < TR ? 2 * L::O_ROWV + rr * L::TRf + s : 2 * L::O_WROW + rr * L::TWf + (s - TR);
     }
     // LDS slot of stacked row sigma in the operand vector: tile rows < TR in the row-gather region, the rest in the W-row region
     static __device__ __forceinline__ int stacked_slot(int sigma) {
@@ -878,9 +884,9 @@ struct WgKernel {
     // STACK = true: the stacked operator (load_stacked_lds); the host launches it only where m + n <= R (TR + TXS)
     template <bool CHECKS = true, bool F32 = false, bool STACK = false>
     static __device__ __forceinline__ void run(const KArgs<T, TIN> &a, T *lds) {
-        static_assert(!(F32 && STACK), "the fp32-product variant runs on the padded operator");
         constexpr int TX = STACK ? TXS : TW;  // tile rows of the iteration's second tile
         static_assert(!F32 || L::F32_FITS, "float views must fit the regions of the double layout");
+        static_assert(!(F32 && STACK) || R * (TR + TXS) * L::Cf <= 2 * L::STAGE_Y, "stacked float partial sums fit the z~ staging region");
         float *lf = reinterpret_cast<float *>(lds);
         const int t = threadIdx.x;
         const int r = t % R, c = t / R;
@@ -1103,13 +1109,18 @@ struct WgKernel {
                 SQPH_STICK(6)
             }
             T (&bt)[TR][TC] = at;
-            sqph_f2 btf[F32 ? TR : 1][L::TC2], vtf[F32 ? TW : 1][L::TC2];
+            sqph_f2 btf[F32 ? TR : 1][L::TC2], vtf[F32 ? TX : 1][L::TC2];
             if constexpr (F32) {
                 tile_to_f32<TR>(at, btf);
                 tile_to_f32<TX>(vt, vtf);
             }
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
-            if constexpr (F32) {
+            if constexpr (F32 && STACK) {
+                if (mown) putf_rowv(lf, r, c, (float)(rho * (z - rinvv[t] * y)));
+                if (nown) lf[stacked_slot_f(m + t)] = (float)(sigma * x - qv[t]);
+                for (int sg = t; sg < R * (TR + TX); sg += NT)
+                    if (sg >= m + n) lf[stacked_slot_f(sg)] = 0.0f;
+            } else if constexpr (F32) {
                 if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
                 if (t < L::NR) putf_wrow(lf, r, c, nown ? (float)(sigma * x - qv[t < L::NP ? t : 0]) : 0.0f);
             } else if constexpr (STACK) {
@@ -1146,10 +1157,10 @@ struct WgKernel {
                     __syncthreads();
                     SQPH_TICK(0)
                     if constexpr (F32) {
-                        float w[TR], ur[TW];
+                        float w[TR], ur[TX];
                         getf_rowv(lf, r, w);
-                        getf_wrow(lf, r, ur);
-                        stage1_f(btf, vtf, w, ur, lf, r, c);
+                        wgf_read<TX>(lf + 2 * L::O_WROW + r * L::TWf, ur);
+                        stage1_f<TX>(btf, vtf, w, ur, lf, r, c);
                     } else {   // stage 1 partials:  B' w + W u, both reduced over r
                         T w[TR], ur[TX];
                         get_rowv(lds, r, w);
@@ -1179,7 +1190,7 @@ struct WgKernel {
                     if constexpr (F32) {
                         float y1c[TC];
                         getf_colv2(lf, c, y1c);
-                        stage2_f(btf, vtf, y1c, lf, r, c);
+                        stage2_f<TX, STACK>(btf, vtf, y1c, lf, r, c);
                     } else {   // stage 2 partials:  z~ = B y1  and  x~ = W' y1, both reduced over c
                         T y1c[TC];
                         get_colv2(lds, c, y1c);
@@ -1202,7 +1213,7 @@ struct WgKernel {
                     SQPH_TICK(6)
                     // owner work sits behind wave-uniform branches on purpose: waves without owners skip it, and the
                     // SIMDs are issue-bound at two waves each (a branch-free variant measured 14 % slower)
-                    if (nown) x = alpha * (F32 ? reducef_xt(lf, t) : (STACK ? wg_sum<C>(lds + L::O_STAGE_Y + (m + t) * L::Cp) : reduce_xt(lds, t))) + oma * x;
+                    if (nown) x = alpha * (F32 ? (STACK ? (T)wgf_sum<C>(lf + 2 * L::O_STAGE_Y + (m + t) * L::Cf) : reducef_xt(lf, t)) : (STACK ? wg_sum<C>(lds + L::O_STAGE_Y + (m + t) * L::Cp) : reduce_xt(lds, t))) + oma * x;
                     if (mown) {
                         const T zt = F32 ? reducef_over_c(lf, t) : reduce_over_c(lds, t);
                         if constexpr (CHECKS) ax = alpha * zt + oma * ax;
@@ -1216,7 +1227,10 @@ struct WgKernel {
                     }
 
                     // operands of the next iteration (the barrier at the loop top orders them before the gathers)
-                    if constexpr (F32) {
+                    if constexpr (F32 && STACK) {
+                        if (mown) putf_rowv(lf, r, c, (float)(rho * (z - c_rinv * y)));
+                        if (nown) lf[stacked_slot_f(m + t)] = (float)(sigma * x - c_q);
+                    } else if constexpr (F32) {
                         if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - c_rinv * y)) : 0.0f);
                         if (t < L::NR) putf_wrow(lf, r, c, nown ? (float)(sigma * x - c_q) : 0.0f);
                     } else if constexpr (STACK) {
@@ -1380,7 +1394,12 @@ struct WgKernel {
                         __builtin_amdgcn_s_setprio(0);
 #endif
                         // the check borrowed the row-gather vector for y: publish w again for the next segment
-                        if constexpr (F32) {
+                        if constexpr (F32 && STACK) {
+                            if (mown) putf_rowv(lf, r, c, (float)(rho * (z - rinvv[t] * y)));
+                            if (nown) lf[stacked_slot_f(m + t)] = (float)(sigma * x - qv[t]);
+                            for (int sg = t; sg < R * TR; sg += NT)
+                                if (sg >= m + n) lf[stacked_slot_f(sg)] = 0.0f;
+                        } else if constexpr (F32) {
                             if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
                         } else if constexpr (STACK) {
                             // the check's y vector ran over the stacked rows of the row-gather region: w, the u entries and the zeros again
@@ -1884,21 +1903,21 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wgs_nocheck_kernel(KArgs<do
 
 // fp32 products (SQPH_FLAG_F32_ARITH with QPSolver<float>): the same kernels with the iteration's two stages in single precision;
 // instantiated in wg_f32.hip only
-template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
+template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE, bool STACK = false>
 __global__ __launch_bounds__(64 * NW, WPE) void admm_wgf_kernel(KArgs<double, TIN> a) {
     __shared__ __attribute__((aligned(16))) double lds[WgLayout<NW, R, C, TR, TC, TW>::TOTAL];
 #ifdef SQPH_SIM
     ::sqph_sim::poison_static_lds(lds, sizeof(lds));
 #endif
-    WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<true, true>(a, lds);
+    WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<true, true, STACK>(a, lds);
 }
-template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
+template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE, bool STACK = false>
 __global__ __launch_bounds__(64 * NW, WPE) void admm_wgf_nocheck_kernel(KArgs<double, TIN> a) {
     __shared__ __attribute__((aligned(16))) double lds[WgLayout<NW, R, C, TR, TC, TW>::TOTAL];
 #ifdef SQPH_SIM
     ::sqph_sim::poison_static_lds(lds, sizeof(lds));
 #endif
-    WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false, true>(a, lds);
+    WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false, true, STACK>(a, lds);
 }
 // shapes of the fp32-product variant {NW, R, C, TR, TC, TW, WPE}: the BASELINE dense shapes (20,40) and (50,100)
 #define SQPH_WGF_SHAPES(X)   \
@@ -1993,9 +2012,13 @@ inline int sim_run_wgs(const KArgs<double, TIN> &a) {
 #ifdef SQPH_SIM
 template <typename TIN>
 inline int sim_run_wgf(const KArgs<double, TIN> &a) {
+    const bool nochk = a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0);
 #define SQPH_SIM_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                         \
     if (a.m <= R_ * TR_ && a.n <= C_ * TC_) {                                                                 \
-        if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0))                      \
+        if (NW_ == 2 && a.m + a.n <= R_ * (TR_ + TW_ - 1)) {  /* the stacked operator, as the host dispatch */ \
+            if (nochk) ::sqph_sim::launch(admm_wgf_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_, NW_ == 2>, dim3(a.batch), dim3(64 * NW_), 0, a); \
+            else ::sqph_sim::launch(admm_wgf_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_, NW_ == 2>, dim3(a.batch), dim3(64 * NW_), 0, a); \
+        } else if (nochk)                                                                                     \
             ::sqph_sim::launch(admm_wgf_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>, dim3(a.batch), dim3(64 * NW_), 0, a); \
         else                                                                                                  \
             ::sqph_sim::launch(admm_wgf_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>, dim3(a.batch), dim3(64 * NW_), 0, a); \

