@@ -1140,10 +1140,10 @@ struct WgKernel {
 #define SQPH_TICK(k)
 #endif
             // The owners' constants (1/rho, l, u, q of the owned elements) live in LDS for the padded fp64 operator, whose 154 tile
-            // registers leave no room; the stacked operator (140) and the fp32 tiles (70-77) do: there they are registers, re-read here
+            // registers leave no room; the stacked operator (140), the fp32 tiles (70-77) and the small tiles do: there they are registers, re-read here
             // after every (re)factorisation — four LDS reads fewer per wave and iteration (C3 shard fixed-200 2.42 -> 2.39 ms, default
             // 2.02 -> 1.98).
-            constexpr bool REGCONST = STACK || F32;
+            constexpr bool REGCONST = STACK || F32 || (!CHECKS && (TR + TW) * TC <= 48);  // ... and the small tiles of calls that never check (C2: 0.326 -> 0.309 ms)
             const T k_rinv = (REGCONST && t < L::MP) ? rinvv[t] : T(1), k_lo = (REGCONST && t < L::MP) ? lov[t] : T(0),
                     k_up = (REGCONST && t < L::MP) ? upv[t] : T(0), k_q = (REGCONST && t < L::NP) ? qv[t] : T(0);
             // Wave priorities: the two waves of a SIMD belong to different QPs; while one is in a latency-bound stretch (the wave-local
