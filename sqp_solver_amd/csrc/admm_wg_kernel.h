@@ -2,8 +2,13 @@
 //
 // Lanes form an R x C grid (t = c*R + r, R*C = 64*NW).  Lane (r,c) keeps two register tiles for the
 // whole solve:
-//     at[s][k] = A[R*s + r][TC*c + k]     s < TR, k < TC      (rows cyclic over r, columns blocked by c)
-//     wt[u][k] = W[R*u + r][TC*c + k]     u < TW, k < TC      (W lower triangular, S^-1 = W'W)
+//     at[s][k] = A[R*s + r][C*k + c]      s < TR, k < TC      (rows cyclic over r, columns cyclic over c)
+//     wt[u][k] = W[R*u + r][C*k + c]      u < TW, k < TC      (W lower triangular, S^-1 = W'W)
+// Both index directions are cyclic, so the zeros of a triangular matrix fall on the SAME tile positions in every lane: entry (u, k)
+// of the W tile is structurally zero when C k > R u + R - 1, entry (u, k) of the W' tile when C k + C - 1 < R u — those multiply-adds
+// are never issued (the n^2 of the reference's two triangular solves, src/qp.cpp:90, instead of 2 n^2), the factorisation's products
+// run over the non-zero half, and both wavefronts of a QP carry the same share of every triangular phase.  A column j = C k + c has
+// the SLOT index TC c + k (its position among the tile columns of all lanes): staging areas and gather vectors are addressed by slot.
 // so that A x / A'w and W b / W'y all run out of the same registers.  Vectors never live in more than
 // one lane's registers: a product is   gather operand from LDS -> FMAs on the tile -> write partial sums
 // to an LDS staging area -> owners (lane t owns element t) reduce them.   Measured on gfx950
@@ -195,7 +200,7 @@ struct WgLayout {
     static constexpr int STAGE_Y = mx(NR, MP) * Cp;
     // set-up scratch, aliasing the staging areas:  rho[MP] | rowbuf[NP+2] | sj[NP] | As[R][SSTR] | Wl[NP][SSTR]
     // As = one block of R rows of A, Wl = W transposed (Wl[j][slot(i')] = W[i'][j]); column groups are
-    // padded to SLOT = 8 (4 when TC <= 4) entries (slot(j) = SLOT*(j/TC) + j%TC) so a lane's TC consecutive columns are one aligned read.
+    // padded to SLOT = 8 (4 when TC <= 4) entries (slot(j) = SLOT*(j%C) + j/C) so a lane's TC tile columns are one aligned read.
     // (the set-up scratch starts at offset 0: no vector is live in LDS while a factor is being built)
     static constexpr int SLOT = TC <= 4 ? 4 : 8;
     static constexpr int SSTR = SLOT * C + 2;  // As row stride (padded: the R rows are written by different lanes)
@@ -232,7 +237,13 @@ struct WgLayout {
     static constexpr int TC2 = (TC + 1) / 2;                       // column pairs of a tile row
     static constexpr bool F32_FITS = R * TRf <= 2 * R * TRp && R * TWf <= 2 * R * TWp && C * TCf <= 2 * C * TCp && NP * Rf <= 2 * STAGE_X &&
                                      mx(NR, MP) * Cf <= 2 * STAGE_Y && NR * Cf <= 2 * NR * Cp;
-    static constexpr int slot(int j) { return SLOT * (j / TC) + (j % TC); }
+    // column distribution (cyclic over c): tile column k of lane group c is matrix column col(c, k); cslot(j) = its slot index
+    static constexpr int col(int c, int k) { return C * k + c; }
+    static constexpr int cslot(int j) { return TC * (j % C) + j / C; }
+    static constexpr int slot(int j) { return SLOT * (j % C) + j / C; }  // the same with column groups padded to SLOT entries
+    // structural zeros shared by all lanes: W tile entry (u, k) = W[R u + r][C k + c], W' tile entry (u, k) = W[C k + c][R u + r]
+    static constexpr bool wt_zero(int u, int k) { return C * k > R * u + R - 1; }
+    static constexpr bool vt_zero(int u, int k) { return C * k + C - 1 < R * u; }
 };
 
 template <typename TIN, int NW, int R, int C, int TR, int TC, int TW>
@@ -274,9 +285,9 @@ struct WgKernel {
     // ------------------------------------------------------------------ gathers (operand from LDS)
     static __device__ __forceinline__ void put_rowv(T *lds, int r, int c, T v) { lds[L::O_ROWV + r * L::TRp + c] = v; }
     static __device__ __forceinline__ void get_rowv(const T *lds, int r, T (&w)[TR]) { wg_read<TR>(lds + L::O_ROWV + r * L::TRp, w); }
-    static __device__ __forceinline__ void put_colv(T *lds, int j, T v) { lds[L::O_COLV + (j / TC) * L::TCp + (j % TC)] = v; }
+    static __device__ __forceinline__ void put_colv(T *lds, int j, T v) { lds[L::O_COLV + (j % C) * L::TCp + (j / C)] = v; }
     static __device__ __forceinline__ void get_colv(const T *lds, int c, T (&x)[TC]) { wg_read<TC>(lds + L::O_COLV + c * L::TCp, x); }
-    static __device__ __forceinline__ void put_colv2(T *lds, int j, T v) { lds[L::O_COLV2 + (j / TC) * L::TCp + (j % TC)] = v; }
+    static __device__ __forceinline__ void put_colv2(T *lds, int j, T v) { lds[L::O_COLV2 + (j % C) * L::TCp + (j / C)] = v; }
     static __device__ __forceinline__ void get_colv2(const T *lds, int c, T (&x)[TC]) { wg_read<TC>(lds + L::O_COLV2 + c * L::TCp, x); }
     static __device__ __forceinline__ void put_wrow(T *lds, int r, int c, T v) { lds[L::O_WROW + r * L::TWp + c] = v; }
     static __device__ __forceinline__ void get_wrow(const T *lds, int r, T (&y)[TW]) { wg_read<TW>(lds + L::O_WROW + r * L::TWp, y); }
@@ -339,7 +350,12 @@ struct WgKernel {
     // reduction direction, so stage 1 stages ONE set of partial sums (W u and B'w accumulate into the same registers)
     // and every owner sums 16 + 8 + 8 instead of 16 + 8 + 16 + 8 partials per iteration; 18 instead of 25 LDS stores.
     //   stage 1:  y1[TC c + k] += sum_s B[R s + r][.] w[R s + r] + sum_u W[.][R u + r] u[R u + r]      (reduced over r)
-    template <int TX>
+    // entry (u, k) of the second tile that no lane ever holds a non-zero in (W' is upper triangular, both tile directions cyclic)
+    template <int TX, bool STACK>
+    static constexpr bool xzero(int u, int k) {
+        return STACK ? (C * k + C - 1 < R * (TR + u) - (R * (TR + TX) - L::NP)) : L::vt_zero(u, k);
+    }
+    template <int TX, bool STACK = false>
     static __device__ __forceinline__ void stage1(const T (&bt)[TR][TC], const T (&vt)[TX][TC], const T (&w)[TR], const T (&ur)[TX], T *lds,
                                                   int r, int c) {
         T pb[TC];
@@ -352,7 +368,8 @@ struct WgKernel {
 #pragma unroll
         for (int u = 0; u < TX; u++)
 #pragma unroll
-            for (int k = 0; k < TC; k++) pb[k] = wg_fma(vt[u][k], ur[u], pb[k]);
+            for (int k = 0; k < TC; k++)
+                if (!xzero<TX, STACK>(u, k)) pb[k] = wg_fma(vt[u][k], ur[u], pb[k]);
         T *st = lds + L::O_STAGE;
 #pragma unroll
         for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = pb[k];
@@ -379,7 +396,8 @@ struct WgKernel {
         for (int u = 0; u < TX; u++) {
             T acc = 0;
 #pragma unroll
-            for (int k = 0; k < TC; k++) acc = wg_fma(vt[u][k], y1[k], acc);
+            for (int k = 0; k < TC; k++)
+                if (!xzero<TX, STACK>(u, k)) acc = wg_fma(vt[u][k], y1[k], acc);
             stx[(R * u + r) * L::Cp + pos] = acc;
         }
     }
@@ -390,7 +408,7 @@ struct WgKernel {
     static __device__ __forceinline__ void getf_rowv(const float *lf, int r, float (&w)[TR]) { wgf_read<TR>(lf + 2 * L::O_ROWV + r * L::TRf, w); }
     static __device__ __forceinline__ void putf_wrow(float *lf, int r, int c, float v) { lf[2 * L::O_WROW + r * L::TWf + c] = v; }
     static __device__ __forceinline__ void getf_wrow(const float *lf, int r, float (&y)[TW]) { wgf_read<TW>(lf + 2 * L::O_WROW + r * L::TWf, y); }
-    static __device__ __forceinline__ void putf_colv2(float *lf, int j, float v) { lf[2 * L::O_COLV2 + (j / TC) * L::TCf + (j % TC)] = v; }
+    static __device__ __forceinline__ void putf_colv2(float *lf, int j, float v) { lf[2 * L::O_COLV2 + (j % C) * L::TCf + (j / C)] = v; }
     static __device__ __forceinline__ void getf_colv2(const float *lf, int c, float (&x)[TC]) { wgf_read<TC>(lf + 2 * L::O_COLV2 + c * L::TCf, x); }
     // double tiles -> float pairs (column 2 kp | 2 kp + 1; the odd tail column is paired with a zero)
     template <int NRW>
@@ -403,7 +421,10 @@ struct WgKernel {
                 dst[s][kp][1] = (2 * kp + 1 < TC) ? (float)src[s][2 * kp + 1 < TC ? 2 * kp + 1 : 0] : 0.0f;
             }
     }
-    template <int TX>
+    // column pair kp of the second tile's row u is zero in every lane (the zeros of a tile row are its first columns)
+    template <int TX, bool STACK>
+    static constexpr bool xzero2(int u, int kp) { return xzero<TX, STACK>(u, 2 * kp + 1 < TC ? 2 * kp + 1 : 2 * kp); }
+    template <int TX, bool STACK = false>
     static __device__ __forceinline__ void stage1_f(const sqph_f2 (&bt)[TR][L::TC2], const sqph_f2 (&vt)[TX][L::TC2], const float (&w)[TR],
                                                     const float (&ur)[TX], float *lf, int r, int c) {
         sqph_f2 pb[L::TC2];
@@ -419,7 +440,8 @@ struct WgKernel {
         for (int u = 0; u < TX; u++) {
             const sqph_f2 us = {ur[u], ur[u]};
 #pragma unroll
-            for (int kp = 0; kp < L::TC2; kp++) pb[kp] = wgf_fma2(vt[u][kp], us, pb[kp]);
+            for (int kp = 0; kp < L::TC2; kp++)
+                if (!xzero2<TX, STACK>(u, kp)) pb[kp] = wgf_fma2(vt[u][kp], us, pb[kp]);
         }
         float *st = lf + 2 * L::O_STAGE;
 #pragma unroll
@@ -447,7 +469,8 @@ struct WgKernel {
         for (int u = 0; u < TX; u++) {
             sqph_f2 acc = {0.0f, 0.0f};
 #pragma unroll
-            for (int kp = 0; kp < L::TC2; kp++) acc = wgf_fma2(vt[u][kp], yp[kp], acc);
+            for (int kp = 0; kp < L::TC2; kp++)
+                if (!xzero2<TX, STACK>(u, kp)) acc = wgf_fma2(vt[u][kp], yp[kp], acc);
             stx[(R * u + r) * L::Cf + c] = acc[0] + acc[1];
         }
     }
@@ -455,14 +478,14 @@ struct WgKernel {
     static __device__ __forceinline__ T reducef_over_c(const float *lf, int t) { return (T)wgf_sum<C>(lf + 2 * L::O_STAGE_Y + t * L::Cf); }
 
     // owner-side reductions (lane t owns output t)
-    static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? t : 0) * L::Rp); }
+    static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? L::cslot(t) : 0) * L::Rp); }  // t = column index
     static __device__ __forceinline__ T reduce_over_c(const T *lds, int t) { return wg_sum<C>(lds + L::O_STAGE_Y + t * L::Cp); }
 
     // ------------------------------------------------------------------ tile loads
     static __device__ __forceinline__ void load_A_tile(const TIN *__restrict__ gA, int n, int m, int r, int c, T (&at)[TR][TC]) {
 #pragma unroll
         for (int k = 0; k < TC; k++) {
-            const int j = TC * c + k;
+            const int j = L::col(c, k);
 #pragma unroll
             for (int s = 0; s < TR; s++) {
                 const int i = R * s + r;
@@ -477,7 +500,7 @@ struct WgKernel {
             const int i = R * u + r;
 #pragma unroll
             for (int k = 0; k < TC; k++) {
-                const int j = TC * c + k;
+                const int j = L::col(c, k);
                 wt[u][k] = (i < n && j < n) ? (T)M[(long)j * n + i] : T(0);
             }
         }
@@ -488,22 +511,29 @@ struct WgKernel {
             const int i = R * u + r;
 #pragma unroll
             for (int k = 0; k < TC; k++) {
-                const int j = TC * c + k;
+                const int j = L::col(c, k);
                 if (i < n && j < n) M[(long)j * n + i] = wt[u][k];
             }
         }
     }
 
-    // B = A W' IN PLACE over the A tile (bt[s][k] = sum_j A[R s + r][j] * W[TC c + k][j], W lower triangular).
+    // B = A W' IN PLACE over the A tile (bt[s][k] = sum_j A[R s + r][j] * W[C k + c][j], W lower triangular).
     // W is staged once (transposed) in LDS from the register tile, A goes through LDS one block of R rows at
     // a time — nothing is re-read from global memory.
-    // STACK (stacked operator, see load_stacked_lds): the rows of W' that fall into tile row s of the B tile (stacked row R s + r = m + j)
+    // Triangular: column j = C kj + cj of A meets W[C k + c][j], which is zero for k < kj in EVERY lane (cyclic columns), so the
+    // products of column block kj run over the tile columns k >= kj only — (TC + 1) / 2 TC of the full count, the same in both
+    // wavefronts of a QP (with blocked columns the wave holding the last column groups ran all of them: no gain on the critical path).
+    // STACK (stacked operator, see load_stacked_lds): the rows of W' that fall into tile row s of the B tile (stacked row R s + r = SOFF + j)
     // are added as soon as that tile row is done — from the same staged copy, while nothing else is live that is not live anyway
+    static constexpr int TXS = TW - 1;
+    // stacked row of W' row j is SOFF + j: a compile-time offset (the structural zeros of the W' tile rows must not depend on m);
+    // the host launches the stacked kernels where m <= SOFF
+    static constexpr int SOFF = R * (TR + TXS) - L::NP;
     template <bool STACK = false>
     static __device__ __forceinline__ void build_B_inplace(T (&at)[TR][TC], const T (&wt)[TW][TC], int n, T *lds, int r, int c, int m SQPH_STICK_ARGS) {
         // All of W is staged once, transposed, in [0, NP * WSTR): Wf[j][slot(i')] = W[i'][j].  It serves the B = A W' product below
         // (the W tile's registers are dead from here on) and, afterwards, the W -> W' transposition of load_vt_lds().  The A tile goes
-        // through As one block of R rows at a time; nothing goes through global memory.
+        // through As one block of R rows at a time (natural column order: As[r][j]); nothing goes through global memory.
         T *Wf = lds, *As = lds + L::O_AS2;
         wsync();  // the factorisation's scratch in this region is dead
 #pragma unroll
@@ -511,49 +541,52 @@ struct WgKernel {
             const int i = R * u + r;
             if (i < L::NP) {
 #pragma unroll
-                for (int k = 0; k < TC; k++) Wf[(TC * c + k) * L::WSTR + L::slot(i)] = wt[u][k];
+                for (int k = 0; k < TC; k++) Wf[L::col(c, k) * L::WSTR + L::slot(i)] = wt[u][k];
             }
         }
 #pragma unroll
         for (int s = 0; s < TR; s++) {
             wsync();
 #pragma unroll
-            for (int k = 0; k < TC; k++) As[r * L::SSTR + L::SLOT * c + k] = at[s][k];
+            for (int k = 0; k < TC; k++) As[r * L::SSTR + L::col(c, k)] = at[s][k];
             wsync();
             T acc[TC];
 #pragma unroll
             for (int k = 0; k < TC; k++) acc[k] = 0;
-            // W[TC c + k][j] = 0 for j > TC c + k: column groups beyond my own contribute nothing
-#pragma unroll 1
-            for (int cj = 0; cj <= c; cj++) {
-                T av[L::SLOT];
-                wg_read<L::SLOT>(As + r * L::SSTR + L::SLOT * cj, av);
 #pragma unroll
-                for (int kj = 0; kj < TC; kj++) {
-                    if (TC * cj + kj >= n) break;
+            for (int kj = 0; kj < TC; kj++) {
+                const int cjn = n - C * kj < C ? n - C * kj : C;  // columns of this block inside the matrix (block-uniform)
+                const T *ap = As + r * L::SSTR + C * kj;
+                const T *wp = Wf + (C * kj) * L::WSTR + L::SLOT * c;
+#pragma unroll 2
+                for (int cj = 0; cj < cjn; cj++) {
+                    const T av = ap[cj];
                     T wv[L::SLOT];
-                    wg_read<L::SLOT>(Wf + (TC * cj + kj) * L::WSTR + L::SLOT * c, wv);
+                    wg_read<L::SLOT>(wp + cj * L::WSTR, wv);  // the reads of the entries below kj are dead code
 #pragma unroll
-                    for (int k = 0; k < TC; k++) acc[k] = wg_fma(av[kj], wv[k], acc[k]);
+                    for (int k = kj; k < TC; k++) acc[k] = wg_fma(av, wv[k], acc[k]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < TC; k++) at[s][k] = SQPH_TILE_QUANT(acc[k]);
             if constexpr (STACK) {
-                const int jp = R * s + r - m;  // row of W' at stacked row R s + r
-                const bool in = jp >= 0 && jp < n;
-                T tmp[L::SLOT];
-                wg_read<L::SLOT>(Wf + (in ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
+                if (R * s + R - 1 >= SOFF) {  // (compile-time: tile rows below the W' rows skip this)
+                    const int jp = R * s + r - SOFF;  // row of W' at stacked row R s + r
+                    const bool in = jp >= 0 && jp < n;
+                    T tmp[L::SLOT];
+                    wg_read<L::SLOT>(Wf + (in ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
 #pragma unroll
-                for (int k = 0; k < TC; k++) at[s][k] += (in && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
+                    for (int k = 0; k < TC; k++) at[s][k] += (in && L::col(c, k) < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
+                }
             }
         }
-        // The W' tile (vt[u][k] = W[TC c + k][R u + r]) is picked up from Wf by load_vt_lds() once the set-up block — and with it
+        // The W' tile (vt[u][k] = W[C k + c][R u + r]) is picked up from Wf by load_vt_lds() once the set-up block — and with it
         // the W tile's registers — has ended.  (Computing vt inside this block, next to the live W tile, put 20 tile registers of
         // the iteration loop into scratch.)
     }
-    // second half of the W -> W' transposition: vt[u][k] = W[TC c + k][R u + r] from the staged copy (the tile of W' in the tile
-    // layout — rows cyclic over r, columns blocked by c — that the iteration loop runs on).  Nothing goes through global memory.
+    // second half of the W -> W' transposition: vt[u][k] = W[C k + c][R u + r] from the staged copy (the tile of W' in the tile
+    // layout — rows cyclic over r, columns cyclic over c — that the iteration loop runs on).  Nothing goes through global memory.
+    // Entries that are structurally zero (L::vt_zero) are never read by the stages: left at zero here.
     static __device__ __forceinline__ void load_vt_lds(T *lds, int n, int r, int c, T (&vt)[TW][TC]) {
         wsync();
 #pragma unroll
@@ -562,26 +595,27 @@ struct WgKernel {
             T tmp[L::SLOT];
             wg_read<L::SLOT>(lds + (jp < L::NP ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
 #pragma unroll
-            for (int k = 0; k < TC; k++) vt[u][k] = (jp < n && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
+            for (int k = 0; k < TC; k++) vt[u][k] = (!L::vt_zero(u, k) && jp < n && L::col(c, k) < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
         }
         wsync();
     }
-    // STACKED operator (run<CHECKS, F32, STACK = true>, problems with m + n <= R (TR + TXS)): instead of padding B to R*TR rows and W' to
-    // R*TW, the rows of W' follow the m rows of B directly — stacked row sigma = m + j holds row j of W' — so the operator takes
-    // TR + TXS tile rows (10 instead of 11 at the C3 shape: 140 instead of 154 multiply-adds per lane and iteration, 14 VGPRs fewer).
+    // STACKED operator (run<CHECKS, F32, STACK = true>, problems with m <= SOFF): instead of padding B to R*TR rows and W' to
+    // R*TW, the rows of W' share the last tile rows of B — stacked row sigma = SOFF + j holds row j of W' — so the operator takes
+    // TR + TXS tile rows (10 instead of 11 at the C3 shape, 14 VGPRs fewer), of which the multiply-adds with the structural zeros of W' are dropped
+    // (stacked_zero: 9 of the 21 W'-only tile entries at the C3 shape — 122 instead of 154 multiply-adds per lane and iteration).
     // Row sigma = R s + r lives in tile row s of lane r as before; the tile rows s < TR are the B tile (rows >= m of it are zero)
     // PLUS the W' rows that fall into them, the TXS rows beyond are W' only.  Both come from the staged transposed copy of W.
-    static constexpr int TXS = TW - 1;
-    static __device__ __forceinline__ void load_stacked_lds(T *lds, int n, int m, int r, int c, T (&xt)[TXS][TC]) {
+    static constexpr bool stacked_zero(int u, int k) { return C * k + C - 1 < R * (TR + u) - SOFF; }  // entry (u, k) of the W'-only tile rows
+    static __device__ __forceinline__ void load_stacked_lds(T *lds, int n, int r, int c, T (&xt)[TXS][TC]) {
         wsync();
 #pragma unroll
         for (int u = 0; u < TXS; u++) {  // the tile rows beyond the B tile (the W' rows inside it were added by build_B_inplace<true>)
-            const int jp = R * (TR + u) + r - m;
+            const int jp = R * (TR + u) + r - SOFF;
             const bool in = jp >= 0 && jp < n;
             T tmp[L::SLOT];
             wg_read<L::SLOT>(lds + (in ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
 #pragma unroll
-            for (int k = 0; k < TC; k++) xt[u][k] = (in && TC * c + k < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
+            for (int k = 0; k < TC; k++) xt[u][k] = (!stacked_zero(u, k) && in && L::col(c, k) < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
         }
         wsync();
     }
@@ -615,7 +649,7 @@ struct WgKernel {
         const T *xv = lds + L::O_COLV + c * L::TCp;
 #pragma unroll 1
         for (int k = 0; k < TC; k += 2) {
-            const int j0 = TC * c + k, j1 = j0 + ((k + 1 < TC) ? 1 : 0);
+            const int j0 = L::col(c, k), j1 = L::col(c, k + ((k + 1 < TC) ? 1 : 0));
             const TIN *p0 = gA + (long)(j0 < n ? j0 : n - 1) * m;
             const TIN *p1 = gA + (long)(j1 < n ? j1 : n - 1) * m;
             T a0[TR], a1[TR];
@@ -655,7 +689,7 @@ struct WgKernel {
         int jo[TC];
 #pragma unroll
         for (int k = 0; k < TC; k++) {
-            const int j = TC * c + k;
+            const int j = L::col(c, k);
             jo[k] = (j < n ? j : n - 1) * n;
         }
         T *sty = lds + L::O_STAGE_Y;
@@ -715,8 +749,14 @@ struct WgKernel {
 
     // ------------------------------------------------------------------ factor (see admm_generic.h factor_schur)
     // Scratch inside the staging area: rho[MP] | rowbuf[NP + 1] | sj[NP]   (doubles)
-    // `at` is the A register tile (rows R s + r, columns TC c + k); it is only read here.
+    // `at` is the A register tile (rows R s + r, columns C k + c); it is only read here.
     // p_staged: P lies in LDS at O_PST (stage_P_async was issued before the call; block-uniform)
+    // Only the LOWER triangle of S is formed and eliminated (tile entries (u, k) with L::wt_zero(u, k) are never touched: both tile
+    // directions are cyclic, so they are the same entries in every lane): S = P_lower + sigma I + A'RA over the non-zero tile entries;
+    // at pivot k the entries right of the diagonal of row k — by symmetry column k below the diagonal — are published by the lanes
+    // that own column k, the entries left of it (the L^-1 part) by the lanes that own row k.
+    static constexpr int RC = R / C;  // pivot rows R u + C h + rr2 (h < RC, rr2 < C) lie in tile column RC u + h of lane group rr2
+    static_assert(R % C == 0, "a tile row of pivots covers whole column groups");
     static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const T (&at)[TR][TC], int n, int m, T sigma,
                                                   T *lds, int t, int r, int c, T (&wt)[TW][TC], bool p_staged SQPH_STICK_ARGS) {
         T *rho_l = lds + L::O_RHO;
@@ -731,7 +771,7 @@ struct WgKernel {
         }
 #pragma unroll
         for (int k = 0; k < TC; k++) {
-            const int j = TC * c + k;
+            const int j = L::col(c, k);
             jc[k] = j < n ? j : 0;
         }
 #pragma unroll
@@ -762,7 +802,8 @@ struct WgKernel {
 #pragma unroll
                 for (int u = 0; u < TW; u++)
 #pragma unroll
-                    for (int k = 0; k < TC; k++) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
+                    for (int k = 0; k < TC; k++)
+                        if (!L::wt_zero(u, k)) wt[u][k] = wg_fma(a1[u], a2[k], wt[u][k]);
             }
         }
         SQPH_STICK(1)
@@ -781,7 +822,8 @@ struct WgKernel {
             const int i = R * u + r;
 #pragma unroll
             for (int k = 0; k < TC; k++) {
-                const int j = TC * c + k;
+                if (L::wt_zero(u, k)) continue;
+                const int j = L::col(c, k);
                 const bool ok = i < n && j < n;
                 const int lo = i > j ? i : j, hi = i > j ? j : i;
                 // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>)
@@ -813,48 +855,64 @@ struct WgKernel {
 #pragma unroll
         for (int u = 0; u < TW; u++)
 #pragma unroll
-            for (int k = 0; k < TC; k++) wt[u][k] = wt[u][k] * srow[u] * scol[k];
+            for (int k = 0; k < TC; k++)
+                if (!L::wt_zero(u, k)) wt[u][k] = wt[u][k] * srow[u] * scol[k];
         SQPH_STICK(2)
-        // forward elimination of [S~ | I] in place; row k = R*u + rr is broadcast through LDS
+        // forward elimination of [S~ | I] in place on the lower triangle; pivot row k = R u + C h + rr2 is published through LDS
+        // (slot order): its columns <= k by the lanes that hold row k, its columns > k — column k below the diagonal — by the
+        // lanes that hold column k (lane group rr2, tile column RC u + h)
         bool ok_all = true;
         T dsave[TW];
 #pragma unroll
         for (int u = 0; u < TW; u++) dsave[u] = T(1);
 #pragma unroll
         for (int u = 0; u < TW; u++) {
+#pragma unroll
+            for (int h = 0; h < RC; h++) {
+                constexpr int kkmax = TC - 1;
+                const int kk = RC * u + h < kkmax ? RC * u + h : kkmax;  // tile column of the pivots of this stretch (beyond TC: k >= n, not run)
 #pragma unroll 1
-            for (int rr = 0; rr < R; rr++) {
-                const int k = R * u + rr;
-                if (k >= n || !ok_all) break;
-                if (r == rr) {
+                for (int rr2 = 0; rr2 < C; rr2++) {
+                    const int rr = C * h + rr2;
+                    const int k = R * u + rr;
+                    if (k >= n || RC * u + h >= TC || !ok_all) break;
+                    if (r == rr) {
 #pragma unroll
-                    for (int q = 0; q < TC; q++) rowbuf[TC * c + q] = wt[u][q];
+                        for (int q = 0; q < TC; q++)
+                            if (q <= kk && !L::wt_zero(u, q) && (q < kk || c <= rr2)) rowbuf[TC * c + q] = wt[u][q];
+                    }
+                    if (c == rr2) {
+#pragma unroll
+                        for (int v = u; v < TW; v++) {
+                            const int i = R * v + r;
+                            if (!L::wt_zero(v, kk) && i > k && i < L::NP) rowbuf[L::cslot(i)] = wt[v][kk];
+                        }
+                    }
+                    wsync();
+                    const T d = rowbuf[L::cslot(k)];
+                    if (!(d > T(0)) || !(d * T(0) == T(0))) {
+                        ok_all = false;
+                        break;
+                    }
+                    const T dinv = T(1) / d;
+                    T g[TC], f[TW];
+#pragma unroll
+                    for (int q = 0; q < TC; q++) g[q] = rowbuf[TC * c + q];
+                    g[kk] = (c == rr2) ? d + T(1) : g[kk];
+#pragma unroll
+                    for (int v = u; v < TW; v++) {
+                        const int i = R * v + r;
+                        const T gi = rowbuf[i < L::NP ? L::cslot(i) : 0];
+                        f[v] = (i > k && i < n) ? gi * dinv : T(0);
+                    }
+                    wsync();
+#pragma unroll
+                    for (int v = u; v < TW; v++)
+#pragma unroll
+                        for (int q = 0; q < TC; q++)
+                            if (!L::wt_zero(v, q)) wt[v][q] = wg_fma(-f[v], g[q], wt[v][q]);
+                    dsave[u] = (r == rr) ? d : dsave[u];
                 }
-                wsync();
-                const T d = rowbuf[k];
-                if (!(d > T(0)) || !(d * T(0) == T(0))) {
-                    ok_all = false;
-                    break;
-                }
-                const T dinv = T(1) / d;
-                T g[TC], f[TW];
-#pragma unroll
-                for (int q = 0; q < TC; q++) {
-                    const T gq = rowbuf[TC * c + q];
-                    g[q] = (TC * c + q == k) ? d + T(1) : gq;
-                }
-#pragma unroll
-                for (int v = 0; v < TW; v++) {
-                    const int i = R * v + r;
-                    const T gi = rowbuf[i < L::NP ? i : 0];
-                    f[v] = (i > k && i < n) ? gi * dinv : T(0);
-                }
-                wsync();
-#pragma unroll
-                for (int v = 0; v < TW; v++)
-#pragma unroll
-                    for (int q = 0; q < TC; q++) wt[v][q] = wg_fma(-f[v], g[q], wt[v][q]);
-                dsave[u] = (r == rr) ? d : dsave[u];
             }
         }
         SQPH_STICK(3)
@@ -865,10 +923,10 @@ struct WgKernel {
             const T rs = T(1) / (T)sqrt((double)dsave[u]);
 #pragma unroll
             for (int k = 0; k < TC; k++) {
-                const int j = TC * c + k;
+                const int j = L::col(c, k);
                 const bool ok = i < n && j < n;
                 const T v = i > j ? wt[u][k] * rs : (i == j ? rs : T(0));
-                wt[u][k] = ok ? v * scol[k] : T(0);
+                wt[u][k] = (ok && !L::wt_zero(u, k)) ? v * scol[k] : T(0);
             }
         }
         return ok_all;
@@ -881,7 +939,7 @@ struct WgKernel {
     // 8,192 x 200 iterations on the C3 shard.  Those kernels live in a translation unit of their own (wg_nocheck.hip): instantiated next
     // to the checking ones, they changed the register allocation of the latter (+3.7 % on the default-termination run).
     // F32 = true: the iteration's two stages in single precision (stage1_f / stage2_f), everything else unchanged
-    // STACK = true: the stacked operator (load_stacked_lds); the host launches it only where m + n <= R (TR + TXS)
+    // STACK = true: the stacked operator (load_stacked_lds); the host launches it only where m <= SOFF
     template <bool CHECKS = true, bool F32 = false, bool STACK = false>
     static __device__ __forceinline__ void run(const KArgs<T, TIN> &a, T *lds) {
         constexpr int TX = STACK ? TXS : TW;  // tile rows of the iteration's second tile
@@ -1100,9 +1158,7 @@ struct WgKernel {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
                 if constexpr (STACK) {
-                    int m_t = m;
-                    SQPH_OPAQUE_S(m_t);
-                    load_stacked_lds(lds, n_t, m_t, r_t, c_t, vt);
+                    load_stacked_lds(lds, n_t, r_t, c_t, vt);
                 } else {
                     load_vt_lds(lds, n_t, r_t, c_t, vt);
                 }
@@ -1117,18 +1173,18 @@ struct WgKernel {
             // publish w = R (z - R^-1 y) [rhs tail of qp.cpp:275 pre-multiplied by R] and u = sigma x - q
             if constexpr (F32 && STACK) {
                 if (mown) putf_rowv(lf, r, c, (float)(rho * (z - rinvv[t] * y)));
-                if (nown) lf[stacked_slot_f(m + t)] = (float)(sigma * x - qv[t]);
+                if (nown) lf[stacked_slot_f(SOFF + t)] = (float)(sigma * x - qv[t]);
                 for (int sg = t; sg < R * (TR + TX); sg += NT)
-                    if (sg >= m + n) lf[stacked_slot_f(sg)] = 0.0f;
+                    if ((sg >= m && sg < SOFF) || sg >= SOFF + n) lf[stacked_slot_f(sg)] = 0.0f;
             } else if constexpr (F32) {
                 if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
                 if (t < L::NR) putf_wrow(lf, r, c, nown ? (float)(sigma * x - qv[t < L::NP ? t : 0]) : 0.0f);
             } else if constexpr (STACK) {
-                // stacked operand vector [w ; u ; 0]: w_i at stacked row i, u_j at row m + j, zeros beyond m + n
+                // stacked operand vector [w ; 0 ; u ; 0]: w_i at stacked row i, u_j at row SOFF + j, zeros in between and beyond SOFF + n
                 if (mown) put_rowv(lds, r, c, rho * (z - rinvv[t] * y));
-                if (nown) lds[stacked_slot(m + t)] = sigma * x - qv[t];
+                if (nown) lds[stacked_slot(SOFF + t)] = sigma * x - qv[t];
                 for (int sg = t; sg < R * (TR + TX); sg += NT)
-                    if (sg >= m + n) lds[stacked_slot(sg)] = T(0);
+                    if ((sg >= m && sg < SOFF) || sg >= SOFF + n) lds[stacked_slot(sg)] = T(0);
             } else {
                 if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
                 if (t < L::NR) put_wrow(lds, r, c, nown ? sigma * x - qv[t < L::NP ? t : 0] : T(0));
@@ -1167,12 +1223,12 @@ struct WgKernel {
                         float w[TR], ur[TX];
                         getf_rowv(lf, r, w);
                         wgf_read<TX>(lf + 2 * L::O_WROW + r * L::TWf, ur);
-                        stage1_f<TX>(btf, vtf, w, ur, lf, r, c);
+                        stage1_f<TX, STACK>(btf, vtf, w, ur, lf, r, c);
                     } else {   // stage 1 partials:  B' w + W u, both reduced over r
                         T w[TR], ur[TX];
                         get_rowv(lds, r, w);
                         wg_read<TX>(lds + L::O_WROW + r * L::TWp, ur);
-                        stage1<TX>(bt, vt, w, ur, lds, r, c);
+                        stage1<TX, STACK>(bt, vt, w, ur, lds, r, c);
                     }
                     SQPH_TICK(1)
                     // y1 = W u + B' w: the R producers of a column group's TC outputs and their consumers in stage 2 are the
@@ -1188,21 +1244,21 @@ struct WgKernel {
                         // rotation inside the 16-lane row combines them — half the LDS reads and adds in the wave's instruction
                         // stream and a shorter chain (C3 shard fixed-200 2.49 -> 2.42 ms)
                         const int o = r & 7, hh = r >> 3;
-                        const int j = TC * c + o;
+                        const int sj = TC * c + o, j = L::col(c, o);  // slot and column of the output
                         if constexpr (F32) {
-                            float part = (o < TC) ? wgf_sum<8>(lf + 2 * L::O_STAGE + j * L::Rf + 8 * hh) : 0.0f;
+                            float part = (o < TC) ? wgf_sum<8>(lf + 2 * L::O_STAGE + sj * L::Rf + 8 * hh) : 0.0f;
                             part += xchg16<8>(part);
                             if (r < TC) putf_colv2(lf, j, j < n ? part : 0.0f);
                         } else {
-                            T part = (o < TC) ? wg_sum<8>(lds + L::O_STAGE + j * L::Rp + 8 * hh) : T(0);
+                            T part = (o < TC) ? wg_sum<8>(lds + L::O_STAGE + sj * L::Rp + 8 * hh) : T(0);
                             part += xchg16<8>(part);
                             if (r < TC) put_colv2(lds, j, j < n ? part : T(0));
                         }
                     } else
                     if (r < TC) {
-                        const int j = TC * c + r;
-                        if constexpr (F32) putf_colv2(lf, j, j < n ? wgf_sum<R>(lf + 2 * L::O_STAGE + j * L::Rf) : 0.0f);
-                        else put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0));
+                        const int sj = TC * c + r, j = L::col(c, r);  // slot and column of the output
+                        if constexpr (F32) putf_colv2(lf, j, j < n ? wgf_sum<R>(lf + 2 * L::O_STAGE + sj * L::Rf) : 0.0f);
+                        else put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + sj * L::Rp) : T(0));
                     }
                     SQPH_TICK(3)
                     wave_sync();
@@ -1243,7 +1299,7 @@ struct WgKernel {
                     // the owners' updates with fused multiply-adds, like the products (6 instructions fewer on the chain that follows
                     // the barrier: -0.7 % fixed, -1.3 % default / SQP settings; status and iteration counts still equal to the oracle's)
 #define SQPH_OFMA(a_, b_, c_) wg_fma((a_), (b_), (c_))
-                    if (nown) x = SQPH_OFMA(alpha, (F32 ? (STACK ? (T)wgf_sum<C>(lf + 2 * L::O_STAGE_Y + (m + t) * L::Cf) : reducef_xt(lf, t)) : (STACK ? wg_sum<C>(lds + L::O_STAGE_Y + (m + t) * L::Cp) : reduce_xt(lds, t))), oma * x);
+                    if (nown) x = SQPH_OFMA(alpha, (F32 ? (STACK ? (T)wgf_sum<C>(lf + 2 * L::O_STAGE_Y + (SOFF + t) * L::Cf) : reducef_xt(lf, t)) : (STACK ? wg_sum<C>(lds + L::O_STAGE_Y + (SOFF + t) * L::Cp) : reduce_xt(lds, t))), oma * x);
                     if (mown) {
                         const T zt = F32 ? reducef_over_c(lf, t) : reduce_over_c(lds, t);
                         if constexpr (CHECKS) ax = SQPH_OFMA(alpha, zt, oma * ax);
@@ -1259,13 +1315,13 @@ struct WgKernel {
                     // operands of the next iteration (the barrier at the loop top orders them before the gathers)
                     if constexpr (F32 && STACK) {
                         if (mown) putf_rowv(lf, r, c, (float)(rho * SQPH_OFMA(-c_rinv, y, z)));
-                        if (nown) lf[stacked_slot_f(m + t)] = (float)SQPH_OFMA(sigma, x, -c_q);
+                        if (nown) lf[stacked_slot_f(SOFF + t)] = (float)SQPH_OFMA(sigma, x, -c_q);
                     } else if constexpr (F32) {
                         if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * SQPH_OFMA(-c_rinv, y, z)) : 0.0f);
                         if (t < L::NR) putf_wrow(lf, r, c, nown ? (float)SQPH_OFMA(sigma, x, -c_q) : 0.0f);
                     } else if constexpr (STACK) {
                         if (mown) put_rowv(lds, r, c, rho * SQPH_OFMA(-c_rinv, y, z));
-                        if (nown) lds[stacked_slot(m + t)] = SQPH_OFMA(sigma, x, -c_q);
+                        if (nown) lds[stacked_slot(SOFF + t)] = SQPH_OFMA(sigma, x, -c_q);
                     } else {
                         if (t < L::MP) put_rowv(lds, r, c, mown ? rho * SQPH_OFMA(-c_rinv, y, z) : T(0));
                         if (t < L::NR) put_wrow(lds, r, c, nown ? SQPH_OFMA(sigma, x, -c_q) : T(0));
@@ -1427,17 +1483,17 @@ struct WgKernel {
                         // the check borrowed the row-gather vector for y: publish w again for the next segment
                         if constexpr (F32 && STACK) {
                             if (mown) putf_rowv(lf, r, c, (float)(rho * (z - rinvv[t] * y)));
-                            if (nown) lf[stacked_slot_f(m + t)] = (float)(sigma * x - qv[t]);
+                            if (nown) lf[stacked_slot_f(SOFF + t)] = (float)(sigma * x - qv[t]);
                             for (int sg = t; sg < R * TR; sg += NT)
-                                if (sg >= m + n) lf[stacked_slot_f(sg)] = 0.0f;
+                                if ((sg >= m && sg < SOFF) || sg >= SOFF + n) lf[stacked_slot_f(sg)] = 0.0f;
                         } else if constexpr (F32) {
                             if (t < L::MP) putf_rowv(lf, r, c, mown ? (float)(rho * (z - rinvv[t] * y)) : 0.0f);
                         } else if constexpr (STACK) {
                             // the check's y vector ran over the stacked rows of the row-gather region: w, the u entries and the zeros again
                             if (mown) put_rowv(lds, r, c, rho * (z - rinvv[t] * y));
-                            if (nown) lds[stacked_slot(m + t)] = sigma * x - qv[t];
+                            if (nown) lds[stacked_slot(SOFF + t)] = sigma * x - qv[t];
                             for (int sg = t; sg < R * TR; sg += NT)
-                                if (sg >= m + n) lds[stacked_slot(sg)] = T(0);
+                                if ((sg >= m && sg < SOFF) || sg >= SOFF + n) lds[stacked_slot(sg)] = T(0);
                         } else {
                             if (t < L::MP) put_rowv(lds, r, c, mown ? rho * (z - rinvv[t] * y) : T(0));
                         }
@@ -1704,8 +1760,9 @@ struct WgKernel {
                 wsync();
 #pragma unroll
                 for (int k = 0; k < NON; k++) {
-                    const int j = t + GL * k;
-                    if (j < L::NP) put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0));
+                    const int sj = t + GL * k;                     // slot of the output ...
+                    const int j = C * (sj % TC) + sj / TC;         // ... and its column (slot TC c + k <-> column C k + c)
+                    if (sj < L::NP) put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + sj * L::Rp) : T(0));
                 }
                 wsync();
                 {
@@ -1772,7 +1829,7 @@ struct WgKernel {
 #pragma unroll
                     for (int k = 0; k < NON; k++) {
                         const int j = t + GL * k;
-                        ATy[k] = j < n ? wg_sum<R>(lds + L::O_STAGE + j * L::Rp) : T(0);
+                        ATy[k] = j < n ? wg_sum<R>(lds + L::O_STAGE + L::cslot(j) * L::Rp) : T(0);
                     }
                     wsync();
                     {
@@ -1911,7 +1968,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_nocheck_kernel(KArgs<dou
     WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false>(a, lds);
 }
 
-// the stacked operator (WgKernel::run<CHECKS, false, STACK = true>) for problems with m + n <= R (TR + TW - 1); instantiated in
+// the stacked operator (WgKernel::run<CHECKS, false, STACK = true>) for problems with m <= R (TR + TW - 1) - C TC (WgKernel::SOFF); instantiated in
 // wg_stack.hip only
 template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
 __global__ __launch_bounds__(64 * NW, WPE) void admm_wgs_kernel(KArgs<double, TIN> a) {
@@ -1929,7 +1986,7 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wgs_nocheck_kernel(KArgs<do
 #endif
     WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false, false, true>(a, lds);
 }
-// shapes of the stacked variant {NW, R, C, TR, TC, TW, WPE}: the C3 shape (m <= 112, n <= 56, m + n <= 160)
+// shapes of the stacked variant {NW, R, C, TR, TC, TW, WPE}: the C3 shape (m <= 104, n <= 56)
 #define SQPH_WGS_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
 
 // fp32 products (SQPH_FLAG_F32_ARITH with QPSolver<float>): the same kernels with the iteration's two stages in single precision;
@@ -2027,7 +2084,7 @@ inline int sim_run_g16(const KArgs<double, TIN> &a) {
 template <typename TIN>
 inline int sim_run_wgs(const KArgs<double, TIN> &a) {
 #define SQPH_SIM_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                         \
-    if (a.m <= R_ * TR_ && a.n <= C_ * TC_ && a.m + a.n <= R_ * (TR_ + TW_ - 1)) {                            \
+    if (a.m <= R_ * TR_ && a.n <= C_ * TC_ && a.m <= R_ * (TR_ + TW_ - 1) - C_ * TC_) {                            \
         if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0))                      \
             ::sqph_sim::launch(admm_wgs_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>, dim3(a.batch), dim3(64 * NW_), 0, a); \
         else                                                                                                  \
@@ -2046,7 +2103,7 @@ inline int sim_run_wgf(const KArgs<double, TIN> &a) {
     const bool nochk = a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0);
 #define SQPH_SIM_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                         \
     if (a.m <= R_ * TR_ && a.n <= C_ * TC_) {                                                                 \
-        if (NW_ == 2 && a.m + a.n <= R_ * (TR_ + TW_ - 1)) {  /* the stacked operator, as the host dispatch */ \
+        if (NW_ == 2 && a.m <= R_ * (TR_ + TW_ - 1) - C_ * TC_) {  /* the stacked operator, as the host dispatch */ \
             if (nochk) ::sqph_sim::launch(admm_wgf_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_, NW_ == 2>, dim3(a.batch), dim3(64 * NW_), 0, a); \
             else ::sqph_sim::launch(admm_wgf_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_, NW_ == 2>, dim3(a.batch), dim3(64 * NW_), 0, a); \
         } else if (nochk)                                                                                     \

@@ -15,9 +15,9 @@ int wgf_try_launch(const KArgs<double, float> &a, hipStream_t stream, const char
     const bool checks = !(a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0));
 #define SQPH_WGF_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                                                       \
     if (a.m <= R_ * TR_ && a.n <= C_ * TC_) {                                                                                               \
-        /* the two-wave shape runs the stacked operator where m + n fits its ten tile rows (as the fp64 kernels do, wg_stack.hip) */      \
+        /* the two-wave shape runs the stacked operator where m <= 104 leaves room for W' in ten tile rows (as the fp64 kernels do, wg_stack.hip) */      \
         constexpr bool CAN_STACK = NW_ == 2;                                                                                                \
-        const bool stack = CAN_STACK && a.m + a.n <= R_ * (TR_ + TW_ - 1);                                                                  \
+        const bool stack = CAN_STACK && a.m <= R_ * (TR_ + TW_ - 1) - C_ * TC_;                                                                  \
         if (stack && checks)                                                                                                                \
             hipLaunchKernelGGL((admm_wgf_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_, CAN_STACK>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
         else if (stack)                                                                                                                     \

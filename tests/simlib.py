@@ -14,7 +14,7 @@ LIB = os.path.join(SIMDIR, "libsqph_sim.so")
 MODE_SETUP, MODE_UPDATE, MODE_SOLVE, MODE_COLD_RESET, MODE_NO_FACTOR_STORE, MODE_REFACTOR, MODE_SAME_MATRICES = 1, 2, 4, 8, 16, 32, 64
 GENERIC, WG, CSR, G16, LANE, LANE_F32 = 0, 2, 3, 4, 6, 7
 GENERIC_F32_ARITH = 9  # measurement only: the generic kernel in fp32 arithmetic (fp32 state arrays)
-WG_STACK = 12  # register-tiled kernel on the stacked operator (m + n <= 160 at the C3 shape)
+WG_STACK = 12  # register-tiled kernel on the stacked operator (m <= 104 at the C3 shape)
 CSR_DENSE = 11  # the sparse kernel's dense-A mode (A streamed from global memory, W in the CU's registers)
 WG_F32 = 10  # register-tiled kernels with fp32 products (SQPH_FLAG_F32_ARITH), float interface only
 

@@ -549,11 +549,11 @@ def test_hip_graph_capture_of_the_fused_call():
 
 
 def test_stacked_and_padded_operator_of_the_c3_grid():
-    """m <= 112, n <= 56 on the two-wave 16 x 8 grid: problems with m + n <= 160 run the iteration on the STACKED operator (10 tile rows,
+    """m <= 112, n <= 56 on the two-wave 16 x 8 grid: problems with m <= 104 run the iteration on the STACKED operator (10 tile rows,
     wg_stack.hip), the others on the padded one (11 rows) — both against the oracle at their limits, fixed and under termination"""
     from sqp_solver_amd.problems import random_qp_batch
 
-    for (n, m, kern) in ((50, 100, "wg2_16x8_7x7s_w2"), (56, 104, "wg2_16x8_7x7s_w2"), (48, 112, "wg2_16x8_7x7s_w2"), (33, 65, "wg2_16x8_7x7s_w2"),
+    for (n, m, kern) in ((50, 100, "wg2_16x8_7x7s_w2"), (56, 104, "wg2_16x8_7x7s_w2"), (48, 103, "wg2_16x8_7x7s_w2"), (48, 105, "wg2_16x8_7x7_w2"), (33, 65, "wg2_16x8_7x7s_w2"),
                          (56, 112, "wg2_16x8_7x7_w2"), (50, 111, "wg2_16x8_7x7_w2")):
         cases.parity_fixed_iters(make_gpu, n, m, 16, iters=80)
         s = make_gpu(n, m, 4)

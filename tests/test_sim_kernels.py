@@ -251,9 +251,9 @@ def make_wg_stack(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
 
 def test_wg_stacked_operator():
     """WgKernel::run<CHECKS, false, STACK = true> (wg_stack.hip): the rows of W' follow the m rows of B in one stacked operator of
-    TR + TW - 1 tile rows — shapes with m not a multiple of the grid's 16 rows (the W' rows start inside a B tile row), m + n at the
-    limit of 160, tiny ones; termination in the three settings; state paths"""
-    for (n, m, b) in ((50, 100, 2), (56, 104, 2), (48, 112, 1), (33, 65, 2), (7, 3, 2)):
+    TR + TW - 1 tile rows — W' row j at stacked row 104 + j (inside the last B tile row), m at the limit of 104 and just below,
+    tiny ones; termination in the three settings; state paths"""
+    for (n, m, b) in ((50, 100, 2), (56, 104, 2), (48, 103, 1), (33, 65, 2), (7, 3, 2)):
         cases.parity_fixed_iters(make_wg_stack, n, m, b, iters=60)
     cases.parity_fixed_iters(make_wg_stack, 49, 99, 2, iters=40, dtype=np.float32)
     for kw in (dict(), dict(adaptive=True), dict(sqp_settings=True)):
