@@ -246,10 +246,21 @@ struct WgLayout {
     static constexpr bool vt_zero(int u, int k) { return C * k + C - 1 < R * u; }
 };
 
+}  // namespace sqph
+#include "admm_wg_msetup.h"
+namespace sqph {
+
 template <typename TIN, int NW, int R, int C, int TR, int TC, int TW>
 struct WgKernel {
     using T = double;
     using L = WgLayout<NW, R, C, TR, TC, TW>;
+    // the matrix phases of the set-up on the f64 MFMA where the lane grid and the LDS budget allow (admm_wg_msetup.h)
+    using MS = MSetup<NW, R, C, TR, TC, TW>;
+#ifdef SQPH_NO_MSETUP  // A/B experiment builds only
+    static constexpr bool MSET = false;
+#else
+    static constexpr bool MSET = MS::ENABLED;
+#endif
     static constexpr int NT = L::NT;
 
     // barrier of the lanes that work on one QP: the workgroup, or (NW == 0) a 16-lane group of a wavefront, whose LDS
@@ -721,15 +732,17 @@ struct WgKernel {
     // read is coalesced — the factor's own access P[min(i,j) n + max(i,j)] (lower triangle only, qp.cpp:159-189) is a stride-n
     // gather for half of the tile (measured: ~20 k of the set-up's 191 k cycles waiting for it).  Returns false (nothing issued)
     // when the block is not 16-byte aligned; the factor then reads P from global memory as before.
+    static constexpr bool P_STAGED = MSET || L::P_STAGED;
+    static constexpr int O_PST = MSET ? MS::O_SB : L::O_PST;
     static __device__ __forceinline__ bool stage_P_async(const TIN *__restrict__ gP, int n, T *lds, int t) {
 #ifdef SQPH_NO_P_STAGE  // A/B experiment builds only
         return false;
 #endif
-        if constexpr (!L::P_STAGED) {
+        if constexpr (!P_STAGED) {
             return false;
         } else {
             if ((reinterpret_cast<unsigned long long>(gP) & 15ull) != 0) return false;
-            char *dst = reinterpret_cast<char *>(lds + L::O_PST);
+            char *dst = reinterpret_cast<char *>(lds + O_PST);
 #ifdef SQPH_SIM
             for (unsigned e = (unsigned)t; e < (unsigned)(n * n); e += (unsigned)NT) reinterpret_cast<TIN *>(dst)[e] = gP[e];
 #else
@@ -1094,8 +1107,16 @@ struct WgKernel {
 #ifndef SQPH_SIM
             __builtin_amdgcn_s_setprio(2);  // the set-up is one long dependent chain: ahead of the co-resident QPs' multiply-add blocks (note below)
 #endif
-            T wt[TW][TC];
-            if (!need_factor) load_sq_tile<T>(gW, n, r, c, wt);  // solve() on a previously set-up instance
+            T wt[MSET ? 1 : TW][TC];  // (MFMA set-up: W lives in LDS blocks, never in a register tile)
+            if (!need_factor) {   // solve() on a previously set-up instance
+                if constexpr (MSET) {
+                    __syncthreads();
+                    MS::load_W(gW, n, lds, t);
+                    __syncthreads();
+                } else {
+                    load_sq_tile<T>(gW, n, r, c, wt);
+                }
+            }
             if (need_factor) {
                 __syncthreads();
                 if (t < L::MP) lds[L::O_RHO + t] = mown ? rho : T(0);
@@ -1108,10 +1129,15 @@ struct WgKernel {
                 const bool p_staged = stage_P_async(gP_f, n_f, lds, t_f);  // P -> LDS in flight next to the loads of A
                 load_A_tile(gA_f, n_f, m_f, r_f, c_f, at);  // the only read of A from global memory per factorisation
                 SQPH_STICK(0)
-                const bool ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt, p_staged SQPH_STICK_PASS);
+                bool ok;
+                if constexpr (MSET) ok = MS::template factor<TIN, MS::O_SB, true>(gP_f, at, n_f, m_f, sigma, lds, t_f, p_staged SQPH_STICK_PASS);
+                else ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt, p_staged SQPH_STICK_PASS);
                 SQPH_STICK(4)
                 // the factor is kept for later solve() calls unless the host asked for a fused setup+solve without it
-                if (!(mode & MODE_NO_FACTOR_STORE)) store_sq_tile(gW, n_f, r_f, c_f, wt);
+                if (!(mode & MODE_NO_FACTOR_STORE)) {
+                    if constexpr (MSET) MS::store_W(gW, n_f, lds, t_f);
+                    else store_sq_tile(gW, n_f, r_f, c_f, wt);
+                }
                 __syncthreads();
                 need_factor = false;
                 have_A = true;
@@ -1147,7 +1173,13 @@ struct WgKernel {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
                 SQPH_STICK(7)
-                build_B_inplace<STACK>(at, wt, n_t, lds, r_t, c_t, m SQPH_STICK_PASS);
+                if constexpr (MSET) {
+                    int m_t = m, t_t = t;
+                    SQPH_OPAQUE_S(m_t); SQPH_OPAQUE_V(t_t);
+                    MS::template build_B<STACK, SOFF>(at, n_t, m_t, lds, t_t SQPH_STICK_PASS);
+                } else {
+                    build_B_inplace<STACK>(at, wt, n_t, lds, r_t, c_t, m SQPH_STICK_PASS);
+                }
                 SQPH_STICK(5)
             }
 #ifndef SQPH_SIM
@@ -1157,7 +1189,11 @@ struct WgKernel {
             {
                 int n_t = n, r_t = r, c_t = c;
                 SQPH_OPAQUE_S(n_t); SQPH_OPAQUE_V(r_t); SQPH_OPAQUE_V(c_t);
-                if constexpr (STACK) {
+                if constexpr (MSET) {
+                    __syncthreads();
+                    MS::template load_vt<TX, STACK, SOFF>(lds, n_t, r_t, c_t, vt);
+                    __syncthreads();  // W in LDS is dead from here on: the operand vectors of the iteration take its place
+                } else if constexpr (STACK) {
                     load_stacked_lds(lds, n_t, r_t, c_t, vt);
                 } else {
                     load_vt_lds(lds, n_t, r_t, c_t, vt);

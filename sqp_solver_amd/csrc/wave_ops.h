@@ -201,4 +201,51 @@ __device__ __forceinline__ T wave_nanmax(T v) {
     return v;
 }
 
+
+// ---- matrix instruction and 16-lane row broadcasts (MFMA set-up of the register-tiled kernels, admm_wg_msetup.h) -------------------
+// four doubles of a 16 x 16 f64 MFMA accumulator: lane l holds D[(l >> 4) + 4 q][l & 15], q < 4
+struct sqph_acc4 {
+    double v[4];
+};
+// D = C + A(16 x 4) B(4 x 16): lane l passes a = A[l & 15][l >> 4], b = B[l >> 4][l & 15]   (v_mfma_f64_16x16x4_f64; measured on the
+// MI355X: 64 cycles per instruction and SIMD whatever the accumulator dependence — 16 multiply-adds per cycle, the vector pipe's peak,
+// from ONE instruction and two 8-byte operands per lane: tools/ubench/mfma_f64_rate.hip)
+__device__ __forceinline__ void mfma16(double a, double b, sqph_acc4 &c) {
+#ifdef SQPH_SIM
+    ::sqph_sim::mfma_f64_16x16x4(a, b, c.v);
+#else
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    d4_t r = {c.v[0], c.v[1], c.v[2], c.v[3]};
+    r = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, r, 0, 0, 0);
+    c.v[0] = r[0]; c.v[1] = r[1]; c.v[2] = r[2]; c.v[3] = r[3];
+#endif
+}
+// value of lane N of my aligned 16-lane row (DPP row_newbcast)
+template <int N>
+__device__ __forceinline__ double bcast16(double x) {
+#ifdef SQPH_SIM
+    uint64_t bits = 0;
+    memcpy(&bits, &x, 8);
+    const uint64_t r = ::sqph_sim::group16_exchange(bits, N);
+    double out;
+    memcpy(&out, &r, 8);
+    return out;
+#else
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+#endif
+}
+// acc + x(lane N of my 16-lane row) * y in one instruction (v_fmac_f64 with the row_newbcast control on its first source; the two wait
+// states a DPP read needs behind the VALU write of its source are part of the statement: the compiler does not see into inline asm)
+template <int N>
+__device__ __forceinline__ double fmac_bcast16(double acc, double x, double y) {
+#ifdef SQPH_SIM
+    return __builtin_fma(bcast16<N>(x), y, acc);
+#else
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(N));
+    return acc;
+#endif
+}
+
 }  // namespace sqph

@@ -48,7 +48,8 @@ struct Block {
     int cur = -1;
     std::vector<unsigned char> smem;
     std::function<void()> body;
-    uint64_t xchg[1024];  // per-lane exchange slots for cross-lane ops
+    uint64_t xchg[1024];   // per-lane exchange slots for cross-lane ops
+    uint64_t xchg2[1024];  // second operand of the matrix instruction (mfma_f64_16x16x4)
 };
 
 inline Block *&cur_block() {
@@ -176,6 +177,28 @@ inline uint64_t wave_exchange(uint64_t v, int src_lane_in_wave) {
     uint64_t r = (s < (int)b->lanes.size()) ? b->xchg[s] : 0;
     yield_wait(2);
     return r;
+}
+
+// v_mfma_f64_16x16x4_f64: D(16x16) = C + A(16x4) B(4x16) over one wavefront; lane l passes A[l & 15][l >> 4] and B[l >> 4][l & 15] and
+// holds D[(l >> 4) + 4 q][l & 15], q < 4 (layout verified on the MI355X, tools/ubench/mfma_f64.hip).  Every lane of the wave takes part.
+inline void mfma_f64_16x16x4(double a, double b, double (&c)[4]) {
+    Block *blk = cur_block();
+    const int t = blk->cur, base = t & ~63, l = t & 63;
+    memcpy(&blk->xchg[t], &a, 8);
+    memcpy(&blk->xchg2[t], &b, 8);
+    yield_wait(2);
+    for (int q = 0; q < 4; q++) {
+        const int i = (l >> 4) + 4 * q, j = l & 15;
+        double acc = c[q];
+        for (int k = 0; k < 4; k++) {
+            double av, bv;
+            memcpy(&av, &blk->xchg[base + i + 16 * k], 8);
+            memcpy(&bv, &blk->xchg2[base + 16 * k + j], 8);
+            acc = __builtin_fma(av, bv, acc);
+        }
+        c[q] = acc;
+    }
+    yield_wait(2);
 }
 
 // statically allocated __shared__ arrays are plain statics here: kernels poison them on entry (thread 0 runs first)
