@@ -339,7 +339,10 @@ struct MSetup {
                         acc[q].v[e] = ok ? v : (i == j ? T(1) : T(0));
                     }
                     if (bI[q] == bJ[q]) {  // a diagonal block (scalar test): the lanes with lr % 4 == lq hold its diagonal, element lr / 4
-                        const T d01 = (lr & 4) ? acc[q].v[1] : acc[q].v[0], d23 = (lr & 4) ? acc[q].v[3] : acc[q].v[2];
+                        // (values first, selects second: a select between two loads of the accumulator array becomes a load through a
+                        // selected address, which sends the whole array to scratch)
+                        const T a0 = acc[q].v[0], a1 = acc[q].v[1], a2 = acc[q].v[2], a3 = acc[q].v[3];
+                        const T d01 = (lr & 4) ? a1 : a0, d23 = (lr & 4) ? a3 : a2;
                         const T dv = (lr & 8) ? d23 : d01;
                         if ((lr & 3) == lq) sj[16 * bI[q] + lr] = dv;
                     }
