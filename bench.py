@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL gather of results (N>1)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the `extra` object (the other BASELINE configs, measured after the headline; default run at N=1 only)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (the N>1 code path — process group, "
                          "RCCL gather — on one device); --gpus N > 1 without RANK in the environment always does")
@@ -74,6 +76,128 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--spawn"]
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def apply_mode(st, mode, iters):
+    """The three settings the bench lines are quoted on (see the module docstring)."""
+    if mode == "fixed":
+        st.max_iter = iters
+        st.check_termination = 0
+    elif mode == "sqp":  # SQP constructor, src/sqp.cpp:15-23
+        st.warm_start, st.check_termination, st.eps_abs, st.eps_rel = 1, 10, 1e-4, 1e-4
+        st.max_iter, st.adaptive_rho, st.adaptive_rho_interval, st.alpha = 100, 1, 50, 1.6
+
+
+def oracle_settings(st):
+    import oracle
+
+    return oracle.default_settings(
+        rho=st.rho, sigma=st.sigma, alpha=st.alpha, eps_rel=st.eps_rel, eps_abs=st.eps_abs,
+        max_iter=st.max_iter, check_termination=st.check_termination, warm_start=st.warm_start,
+        adaptive_rho=st.adaptive_rho, adaptive_rho_tolerance=st.adaptive_rho_tolerance,
+        adaptive_rho_interval=st.adaptive_rho_interval)
+
+
+def extra_line(name, n, m, B, mode, data, dev, steps=5, warmup=2, csr=None, nnz_avg=0.0, oracle_k=64, A_dense=None):
+    """One of the other BASELINE configs, measured like the headline (device-resident inputs, HIP events around every launch on the
+    launch stream, wall clock around `steps` launches) on a short run, with the GPU results of the first `oracle_k` QPs checked
+    against the CPU oracle.  Returns the record that goes into the JSON line's `extra` object."""
+    import numpy as np
+    import torch
+
+    import oracle
+    from sqp_solver_amd import QPSolverBatch
+
+    P, q, A_cm, l, u = data
+    solver = QPSolverBatch(n, m, B, dtype=np.float64, device=dev.index or 0)
+    st = solver.settings
+    apply_mode(st, mode, 200)
+    solver.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        if csr is not None:
+            solver.setup_solve_csr(P, q, csr[0], csr[1], csr[2], l, u, colmajor=True)
+        else:
+            solver.setup_solve(P, q, A_cm, l, u, colmajor=True)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    solver.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = solver.collect_kernel_ms()[-steps:]
+    solver.enable_timing(False)
+    info = solver.info()
+    iters = float(np.minimum(info.iter, st.max_iter).mean())
+    bytes_per_qp = solver.algorithmic_bytes_per_qp()
+    rec = {}
+    if csr is not None:
+        bytes_per_qp = int(8 * (n * n + n + 2 * m) + 12 * nnz_avg + 4 * (m + 1) + 8 * (n + m) + 40)
+        # what the no-check kernel needs: the lower triangle of P only (the full P is read by the residual checks alone)
+        rec["needed_bytes_per_qp"] = int(8 * (n * (n + 1) // 2 + n + 2 * m) + 12 * nnz_avg + 4 * (m + 1) + 8 * (n + m) + 40)
+    kavg = float(np.mean(kernel_ms))
+    achieved = bytes_per_qp * B / (kavg * 1e-3) / 1e9
+    rec.update({
+        "workload": "%s: %d x (n=%d, m=%d) %s, %s" % (name, B, n, m, "CSR A" if csr is not None else "dense", mode),
+        "ms_per_step": elapsed / steps * 1e3, "kernel_ms_avg": kavg, "value": B * steps / elapsed, "unit": "QP/s",
+        "admm_iters_per_qp": iters, "kernel": solver.kernel_name(), "steps": steps,
+        "algorithmic_bytes_per_qp": bytes_per_qp, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+        "traffic": pmc_traffic(solver.kernel_name(), n, m, B, mode),
+    })
+    if "needed_bytes_per_qp" in rec:
+        rec["frac_needed"] = rec["needed_bytes_per_qp"] * B / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if oracle_k > 0:
+        k = min(B, oracle_k)
+        if csr is not None:
+            Ah = A_dense[:k].cpu().numpy()
+        else:
+            Ah = A_cm[:k].cpu().numpy().transpose(0, 2, 1)
+        t0 = time.perf_counter()
+        xo, yo, zo, io = oracle.solve_batch(P[:k].cpu().numpy().transpose(0, 2, 1), q[:k].cpu().numpy(), Ah, l[:k].cpu().numpy(),
+                                            u[:k].cpu().numpy(), settings=oracle_settings(st), nthreads=oracle.max_threads(), dtype=np.float64)
+        dt = time.perf_counter() - t0
+        xg, yg, zg, ig = solver.solution()
+
+        def rel(a, b):
+            den = np.maximum(np.max(np.abs(b), axis=1), 1e-300)
+            return float(np.max(np.max(np.abs(a - b), axis=1) / den))
+
+        rec["parity"] = {"oracle_sample": k, "max_rel_err_x": rel(xg[:k], xo), "max_rel_err_y": rel(yg[:k], yo),
+                         "status_equal": bool((ig.status[:k] == io["status"]).all()), "iter_equal": bool((ig.iter[:k] == io["iter"]).all()),
+                         "cpu_qp_per_s": k / max(dt, 1e-9), "cpu_cores": oracle.max_threads()}
+    solver.close()
+    return rec
+
+
+def extra_configs(dev, c3_data):
+    """The BASELINE configs besides the headline, each as a short measured line: configs[1] (C2), configs[2] under the reference's
+    default settings and under the SQP driver's settings, the whole 65,536 batch of configs[2] in one launch, configs[4] (C5, CSR A).
+    (configs[3], the SQP outer loop, is a host driver written in C++: tests/cpp/sqp_batch_test.cpp; configs[0] is the CPU plumbing case.)"""
+    import torch
+
+    from sqp_solver_amd.problems import random_qp_batch_torch
+
+    out = {}
+    out["c3_default"] = extra_line("configs[2] shard", 50, 100, c3_data[0].shape[0], "default", c3_data, dev, steps=10)
+    out["c3_sqp"] = extra_line("configs[2] shard", 50, 100, c3_data[0].shape[0], "sqp", c3_data, dev, steps=10)
+    d = random_qp_batch_torch(4096, 20, 40, seed=20250228 + 2, dtype=torch.float64, device=dev)
+    out["c2"] = extra_line("configs[1]", 20, 40, 4096, "fixed", d, dev, steps=20, oracle_k=256)
+    del d
+    d = random_qp_batch_torch(65536, 50, 100, seed=20250228 + 3, dtype=torch.float64, device=dev)
+    out["c3_whole_65536"] = extra_line("configs[2] whole batch, one launch", 50, 100, 65536, "fixed", d, dev, steps=3, warmup=1)
+    del d
+    torch.cuda.empty_cache()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_csr
+
+    P, q, rp, ci, v, l, u, A_dense, nnz_avg = bench_csr.make(8192, 200, 400, 0.05, 20250228 + 5, dev)
+    out["c5"] = extra_line("configs[4]", 200, 400, 8192, "fixed", (P, q, None, l, u), dev, steps=3, warmup=1, csr=(rp, ci, v),
+                           nnz_avg=nnz_avg, oracle_k=64, A_dense=A_dense)
+    return out
 
 
 def main():
@@ -140,12 +264,7 @@ def main():
 
     solver = QPSolverBatch(n, m, B, dtype=ndt, device=local_rank, force_generic=args.force_generic, f32_arith=args.f32_arith)
     st = solver.settings
-    if args.mode == "fixed":
-        st.max_iter = args.iters
-        st.check_termination = 0
-    elif args.mode == "sqp":  # SQP constructor, src/sqp.cpp:15-23
-        st.warm_start, st.check_termination, st.eps_abs, st.eps_rel = 1, 10, 1e-4, 1e-4
-        st.max_iter, st.adaptive_rho, st.adaptive_rho_interval, st.alpha = 100, 1, 50, 1.6
+    apply_mode(st, args.mode, args.iters)
     solver.set_stream(torch.cuda.current_stream().cuda_stream)
 
     # device views of the resident results for the gather
@@ -196,6 +315,39 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # N > 1 diagnostics (outside the timed region): what a step costs without the gather, what a gather costs on its own, the
+    # kernel time of every rank, how many ranks RCCL sees — so that a scaling run that disappoints can be read
+    multi = None
+    if use_dist:
+        dsteps = max(2, min(args.steps, 5))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(dsteps):
+            step()
+        torch.cuda.synchronize()
+        solve_ms = (time.perf_counter() - t0) / dsteps * 1e3
+        gather_ms = None
+        if gather_bufs is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(dsteps):
+                gather_bufs.gather()
+                gather_bufs.flush()
+                torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - t0) / dsteps * 1e3
+        kavg = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        per = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([kavg, solve_ms, gather_ms if gather_ms is not None else float("nan")], dtype=torch.float64, device=dev))
+        multi = {
+            "rccl_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+            "kernel_ms_avg_per_rank": [float(p[0]) for p in per],
+            "solve_ms_per_rank": [float(p[1]) for p in per],            # a step without the gather (wall, synchronised)
+            "gather_ms_sync_per_rank": [float(p[2]) for p in per],      # one gather on its own, joined before the next (not overlapped)
+            "record_bytes_per_rank": int(B * (8 * (n + max(m, 1)) + 40)),
+        }
 
     # total ADMM iterations of the last step (info.iter counts max_iter+1 when exhausted, qp.cpp:147-150)
     info = solver.info()
@@ -263,6 +415,7 @@ def main():
                 "parallelism": "batch-sharded x%d" % world,
                 "gather": bool(gather_bufs is not None),
             },
+            **({"multi_gpu": multi} if multi is not None else {}),
             "admm_iters_per_sec": admm_iters_per_sec,
             "solved_fraction": solved_total / float(total_batch),
             "roofline": {
@@ -288,6 +441,13 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, solver, P[:k], q[:k], A_cm, l[:k], u[:k], st, ndt)
             else:
                 out["cpu_baseline"] = cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt)
+        # the other BASELINE configs in the same driver-run line (default workload only: the headline stays what it is)
+        default_headline = (args.workload == "c3" and (n, m, B) == (50, 100, 8192) and args.mode == "fixed" and args.iters == 200 and
+                            args.dtype == "f64" and not strong and not args.force_generic)
+        if world == 1 and not use_dist and not args.no_extra and default_headline:
+            t0 = time.perf_counter()
+            out["extra"] = extra_configs(dev, (P, q, A_cm, l, u))
+            out["extra"]["seconds"] = time.perf_counter() - t0
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
@@ -299,6 +459,24 @@ def main():
             assert torch.equal(xs[:B], gather_bufs.local[0]) and torch.equal(ys[:B], gather_bufs.local[1]) and \
                 torch.equal(infos[:B], gather_bufs.local[2]), "gather mismatch"
             assert xs.shape[0] == total_batch and gather_bufs.rows == [shard_bounds(total_batch, world, r)[1] - shard_bounds(total_batch, world, r)[0] for r in range(world)]
+            # ... and the records of EVERY rank's shard equal a re-solve, on this rank, of sampled QPs of that shard (its inputs are
+            # regenerated here from the rank's seed): a gather that delivers the wrong rank's or a stale buffer fails this
+            if csr is None:
+                off = 0
+                for r in range(world):
+                    Br = gather_bufs.rows[r]
+                    if Br > 0:
+                        Pr, qr, Ar, lr_, ur = random_qp_batch_torch(Br, n, m, seed=20250228 + 3 + 1000 * r, dtype=tdt, device=dev)
+                        idx = torch.linspace(0, Br - 1, steps=min(32, Br), device=dev).long()
+                        chk = QPSolverBatch(n, m, int(idx.numel()), dtype=ndt, device=local_rank, force_generic=args.force_generic, f32_arith=args.f32_arith)
+                        apply_mode(chk.settings, args.mode, args.iters)
+                        chk.setup_solve(Pr[idx].contiguous(), qr[idx].contiguous(), Ar[idx].contiguous(), lr_[idx].contiguous(), ur[idx].contiguous(), colmajor=True)
+                        xc, yc, _, _ = chk.solution()
+                        chk.close()
+                        gx, gy = xs[off + idx].cpu().numpy(), ys[off + idx].cpu().numpy()
+                        assert np.array_equal(gx, xc) and np.array_equal(gy[:, :m], yc[:, :m]), "rank %d: gathered records differ from a re-solve of its shard" % r
+                        del Pr, qr, Ar, lr_, ur
+                    off += Br
         dist.barrier()
         dist.destroy_process_group()
     return out
@@ -338,11 +516,7 @@ def cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt):
     import oracle
 
     B, n, m = P.shape[0], args.n, args.m
-    ost = oracle.default_settings(
-        rho=st.rho, sigma=st.sigma, alpha=st.alpha, eps_rel=st.eps_rel, eps_abs=st.eps_abs,
-        max_iter=st.max_iter, check_termination=st.check_termination, warm_start=st.warm_start,
-        adaptive_rho=st.adaptive_rho, adaptive_rho_tolerance=st.adaptive_rho_tolerance,
-        adaptive_rho_interval=st.adaptive_rho_interval)
+    ost = oracle_settings(st)
     cores = oracle.max_threads()
 
     def host(k):

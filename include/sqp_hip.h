@@ -43,9 +43,14 @@
  *   - all calls are asynchronous on the solver's stream except where noted.
  *   - return value: 0 = ok, <0 = API misuse or HIP error (message via sqph_last_error).
  *     Per-QP numerical status is in sqph_info::status, exactly as in the reference.
- *   - P and A given to sqph_solve must be the ones given to the preceding
- *     sqph_setup / sqph_update_qp; q, l, u may differ (the reference re-reads them from
- *     solve()'s argument, src/qp.cpp:89,100,112).
+ *   - q, l, u given to sqph_solve may differ from those of the preceding sqph_setup /
+ *     sqph_update_qp (the reference re-reads them from solve()'s argument, src/qp.cpp:89,
+ *     100,112).  P may differ as well while the factor is the resident one (after
+ *     sqph_setup / sqph_update_qp, or on a SQPH_FLAG_KEEP_FACTOR handle) and rho is not
+ *     adapted: as in the reference it then enters the residuals only (src/qp.cpp:324,360;
+ *     the factor is setup()'s).  A must be the matrix of the preceding set-up: the iteration
+ *     runs on B = A W', rebuilt from the call's A (the reference reads solve()'s A for the
+ *     residuals alone).
  */
 #ifndef SQP_HIP_H
 #define SQP_HIP_H

@@ -2,6 +2,10 @@
 // sqp::sqp_settings_t, sqp::Info with the reference's names, members and Eigen types (sqp.hpp:13-38, 62-140), so that callers of
 // SQP::solve() compile unchanged.  The outer loop is the batched driver of include/sqp_hip/sqp.hpp run with ONE instance (the
 // same statements as src/sqp.cpp; its QP subproblems go to the GPU through libsqp_hip); many instances at once: sqp::raw::BatchSQP.
+//
+// The declarations of sqp_settings_t, Info, NonLinearProblem and SQP's public members (names, defaults and their doc comments) restate
+// the interface of msplr/sqp_solver's include/solvers/sqp.hpp — Copyright (c) 2019 Michael Spieler, MIT License — because source
+// compatibility with its callers is the contract of this header; the implementation behind them is this repository's own.
 #pragma once
 #define SQP_HIP_SQP_DROPIN 1
 #include <cstdio>

@@ -16,8 +16,10 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <exception>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -128,9 +130,21 @@ class HostPool {
         n_ = n;
         next_.store(0, std::memory_order_relaxed);
         pending_.store((int)workers_.size(), std::memory_order_relaxed);
+        failed_.store(false, std::memory_order_relaxed);
         gen_.fetch_add(1, std::memory_order_release);
         work();
-        while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
+        // (a worker may be inside its 100 us idle sleep: spin briefly, then give the core away instead of burning it)
+        for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; spins++) {
+            if (spins < 20000) cpu_relax();
+            else std::this_thread::yield();
+        }
+        // an exception thrown by a callback on any thread (the user's NLP methods run here) surfaces from this call, like in the
+        // serial driver — the first one wins, the other chunks of the job are skipped
+        if (failed_.load(std::memory_order_acquire)) {
+            std::exception_ptr e = error_;
+            error_ = nullptr;
+            std::rethrow_exception(e);
+        }
     }
 
    private:
@@ -144,7 +158,14 @@ class HostPool {
         for (;;) {
             const int lo = next_.fetch_add(CHUNK, std::memory_order_relaxed);
             if (lo >= n_) break;
-            (*job_)(lo, lo + CHUNK < n_ ? lo + CHUNK : n_);
+            if (failed_.load(std::memory_order_relaxed)) continue;  // drain the remaining chunks without running them
+            try {
+                (*job_)(lo, lo + CHUNK < n_ ? lo + CHUNK : n_);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(err_mu_);
+                if (!error_) error_ = std::current_exception();
+                failed_.store(true, std::memory_order_release);
+            }
         }
     }
     void worker(unsigned last) {
@@ -164,7 +185,9 @@ class HostPool {
     std::vector<std::thread> workers_;
     std::atomic<unsigned> gen_{0};
     std::atomic<int> next_{0}, pending_{0};
-    std::atomic<bool> stop_{false};
+    std::atomic<bool> stop_{false}, failed_{false};
+    std::mutex err_mu_;
+    std::exception_ptr error_;
     const std::function<void(int, int)> *job_ = nullptr;
     int n_ = 0;
 };

@@ -30,7 +30,7 @@ void qpo_default_settings(qpo_settings *s) {
 
 int qpo_max_threads(void) {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    return omp_get_num_procs();  /* (not omp_get_max_threads: a solve with an explicit thread count lowers that for good) */
 #else
     return 1;
 #endif

@@ -9,6 +9,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.environ.get("SQPH_LIB") or os.path.join(LIBDIR, "libsqp_hip.so")  # SQPH_LIB: A/B-test another build
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+# extra compiler flags from the environment, e.g. SQPH_HIPCC_FLAGS=-DSQPH_LANE_NO_FMA for users who want the one-QP-per-lane kernel's
+# unfused multiply / add back (it tracks the reference's unfused CPU arithmetic almost bit for bit: admm_lane_kernel.h)
+FLAGS += os.environ.get("SQPH_HIPCC_FLAGS", "").split()
 
 
 def sources():
@@ -64,7 +67,7 @@ def build_f32_tiles_experiment(verbose=False):
     cmd = [HIPCC] + FLAGS + ["-DSQPH_SLIM", "-DSQPH_SLIM_C2", "-DSQPH_F32_TILE_STORAGE", "-o", out] + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    subprocess.check_call(cmd)  # (compiler output is shown: a failure of this build must be diagnosable)
     return out
 
 

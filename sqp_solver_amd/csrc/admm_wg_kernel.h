@@ -958,6 +958,9 @@ struct WgKernel {
         constexpr int TX = STACK ? TXS : TW;  // tile rows of the iteration's second tile
         static_assert(!F32 || L::F32_FITS, "float views must fit the regions of the double layout");
         static_assert(!(F32 && STACK) || R * (TR + TXS) * L::Cf <= 2 * L::STAGE_Y, "stacked float partial sums fit the z~ staging region");
+        // the stacked fp64 operator stages R (TR + TXS) rows of partial sums from O_STAGE_Y on: past STAGE_Y they run over the gap and the
+        // O_STX region (unused in the stacked mode: its x~ partial sums continue the z~ array) — but never into the owners' constants
+        static_assert(!STACK || F32 || L::O_STAGE_Y + R * (TR + TXS) * L::Cp <= L::O_QV, "stacked partial sums end before the owners' constants");
         float *lf = reinterpret_cast<float *>(lds);
         const int t = threadIdx.x;
         const int r = t % R, c = t / R;
@@ -2004,6 +2007,11 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_nocheck_kernel(KArgs<dou
     WgKernel<TIN, NW, R, C, TR, TC, TW>::template run<false>(a, lds);
 }
 
+// waves per SIMD of the no-check instantiation where it can hold more than the shape's checking kernel: the C2 shape (one wave per QP)
+// fits four per SIMD without the check block — all 4,096 QPs of BASELINE configs[1] resident at once instead of 3,072 (0.345 -> 0.317 ms;
+// the checking kernel spills at that bound and stays at three: 0.78 against 0.84 ms under the reference's default settings)
+constexpr int wg_nocheck_wpe(int NW, int R, int C, int TR, int TC, int W) { return (NW == 1 && R == 8 && C == 8 && TR == 5 && TC == 3) ? 4 : W; }
+
 // the stacked operator (WgKernel::run<CHECKS, false, STACK = true>) for problems with m <= R (TR + TW - 1) - C TC (WgKernel::SOFF); instantiated in
 // wg_stack.hip only
 template <typename TIN, int NW, int R, int C, int TR, int TC, int TW, int WPE>
@@ -2068,7 +2076,8 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 // problems with many more constraints than variables (m <= 224 with n <= 16 / 32 / 56): measured 4,096 x (10,150) 1.43 ms against
 // 7.73 ms in the 16 x 16 / 13 x 7 shape it fell into before, 4,096 x (50,150) 2.94 against 8.68 ms; the 64 x 8 grids (8 waves) carry
 // m <= 448 with n <= 32 / 56: 2,048 x (50,400) 3.98 ms against 45.5 ms in the generic kernel; the 16 x 16 grids with 2 / 4 / 8 tile rows
-// serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x)
+// serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x; their 112 x 112
+// factor scratch takes > 80 KB of LDS, i.e. one workgroup per CU: WPE 1 is what they get, and what the register allocator is told)
 // (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
 #ifdef SQPH_SLIM
 #ifdef SQPH_SLIM_C2  // ... plus the C2 shape
@@ -2088,9 +2097,9 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
     X(4, 32, 8, 7, 2, 1, 4)      \
     X(4, 32, 8, 7, 4, 1, 3)      \
     X(4, 32, 8, 7, 7, 2, 2)      \
-    X(4, 16, 16, 2, 7, 7, 2)     \
-    X(4, 16, 16, 4, 7, 7, 2)     \
-    X(4, 16, 16, 8, 7, 7, 2)     \
+    X(4, 16, 16, 2, 7, 7, 1)     \
+    X(4, 16, 16, 4, 7, 7, 1)     \
+    X(4, 16, 16, 8, 7, 7, 1)     \
     X(4, 16, 16, 13, 7, 7, 1)    \
     X(8, 64, 8, 7, 4, 1, 2)      \
     X(8, 64, 8, 7, 7, 1, 2)

@@ -3,7 +3,15 @@
 // There is deliberately NO CPU execution path in this library.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types only: the library itself is opened with dlopen on the first cross-device gather
+// RCCL: types only — the library itself is opened with dlopen on the first cross-device gather, so an installation without the
+// RCCL headers still compiles this file (the few types the dlopen'd entry points need are restated below)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclFloat64 = 8 } ncclDataType_t;
+#endif
 
 #include <cmath>
 #include <cstdio>
@@ -564,8 +572,9 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     const bool fused = (mode & (MODE_SETUP | MODE_UPDATE)) && (mode & MODE_SOLVE);
     if (fused && !(s->flags & SQPH_FLAG_KEEP_FACTOR)) a.mode |= MODE_NO_FACTOR_STORE;
     const bool solve_only = !(mode & (MODE_SETUP | MODE_UPDATE));
-    auto for_family = [&](char fam) {  // mode bits for a launch by kernel family `fam`
-        int mbits = a.mode & ~(MODE_REFACTOR | (fam == 'g' ? MODE_NO_FACTOR_STORE : 0));
+    const int mode_in = a.mode;
+    auto for_family = [&](char fam) {  // mode bits for a launch by kernel family `fam`: always derived from the call's own mode
+        int mbits = mode_in & ~(MODE_REFACTOR | (fam == 'g' ? MODE_NO_FACTOR_STORE : 0));
         if (solve_only && (!s->factor_resident || s->factor_family != fam)) mbits |= MODE_REFACTOR;
         if ((mbits & MODE_SAME_MATRICES) && (!s->factor_resident || s->factor_family != fam)) mbits &= ~MODE_SAME_MATRICES;
         return mbits;
@@ -576,7 +585,6 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
             s->factor_family = fam;
         }
     };
-    const int mode_in = a.mode;
     a.P = (const TIN *)P; a.q = (const TIN *)q; a.A = (const TIN *)A; a.l = (const TIN *)l; a.u = (const TIN *)u;
     a.sP = sP; a.sq = sq; a.sA = sA; a.sl = sl; a.su = su;
     a.x = (T *)s->x; a.z = (T *)s->z; a.y = (T *)s->y; a.rho_vec = (T *)s->rho_vec; a.ctype = s->ctype;
@@ -703,7 +711,6 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
             SQPH_HIP(s, hipMalloc(&s->At, bytes));
         }
         a.At = (T *)s->At;
-        a.mode = mode_in;
         a.mode = for_family('g');
         const int big = s->n > s->m ? s->n : s->m;
 #ifdef SQPH_EXPERIMENTS
@@ -1097,6 +1104,7 @@ int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int cou
     const size_t n = g->n, m = g->m, c = (size_t)count;
     const bool cross = src->device != g->device;
     bool via_rccl = false;
+    const char *rccl_err = nullptr;
     if (!(g->flags & SQPH_GATHER_NO_RCCL) && (cross || (g->flags & SQPH_GATHER_RCCL_ALWAYS))) {
         RcclApi &R = rccl();
         std::lock_guard<std::mutex> lk(R.mu);
@@ -1112,41 +1120,56 @@ int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int cou
             xfer(src->info, g->info + offset, c * sizeof(sqph_info), ncclInt8);
             const ncclResult_t re = R.GroupEnd();
             if (r == ncclSuccess) r = re;
-            if (r != ncclSuccess) SQPH_FAIL(src, SQPH_ERR_HIP, "sqph_gather_post: RCCL: %s", R.GetErrorString(r));
+            // an error after a partly issued group: the send / receive kernels that were enqueued still have to be waited for —
+            // the events below are recorded either way, the error is returned after them
+            if (r != ncclSuccess) rccl_err = R.GetErrorString(r);
             via_rccl = true;
         }
     }
-    hipEvent_t ev, ev_root = nullptr;
+    // (any failure from here on still hands the events already created to the gather: nothing leaks, nothing enqueued goes unwaited)
+    hipEvent_t ev = nullptr, ev_root = nullptr;
+    const auto hand_over = [&]() {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->transport = via_rccl ? "rccl" : "peer-copy";  // written by one host thread per shard: under the gather's mutex
+        if (ev) {
+            g->pending.push_back(ev);
+            g->pending_dev.push_back(src->device);
+        }
+        if (ev_root) {
+            g->pending.push_back(ev_root);
+            g->pending_dev.push_back(g->device);
+        }
+    };
+#define SQPH_HIP_POST(call)                                                                                   \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            hand_over();                                                                                      \
+            SQPH_FAIL(src, SQPH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                      \
+        }                                                                                                     \
+    } while (0)
     if (via_rccl) {
-        g->transport = "rccl";
         DeviceGuard dr(g->device);
-        SQPH_HIP(src, hipEventCreateWithFlags(&ev_root, hipEventDisableTiming));
-        SQPH_HIP(src, hipEventRecord(ev_root, g->stream));
+        SQPH_HIP_POST(hipEventCreateWithFlags(&ev_root, hipEventDisableTiming));
+        SQPH_HIP_POST(hipEventRecord(ev_root, g->stream));
     }
     DeviceGuard dg(src->device);
     if (!via_rccl) {
-        g->transport = "peer-copy";
         if (cross) {
             int can = 0;
             (void)hipDeviceCanAccessPeer(&can, src->device, g->device);
             if (can) (void)hipDeviceEnablePeerAccess(g->device, 0);  // idempotent (an "already enabled" error is cleared below)
             (void)hipGetLastError();
         }
-        SQPH_HIP(src, hipMemcpyPeerAsync(g->x + (size_t)offset * n, g->device, src->x, src->device, c * n * sizeof(double), src->stream));
-        if (m) SQPH_HIP(src, hipMemcpyPeerAsync(g->y + (size_t)offset * m, g->device, src->y, src->device, c * m * sizeof(double), src->stream));
-        SQPH_HIP(src, hipMemcpyPeerAsync(g->info + offset, g->device, src->info, src->device, c * sizeof(sqph_info), src->stream));
+        SQPH_HIP_POST(hipMemcpyPeerAsync(g->x + (size_t)offset * n, g->device, src->x, src->device, c * n * sizeof(double), src->stream));
+        if (m) SQPH_HIP_POST(hipMemcpyPeerAsync(g->y + (size_t)offset * m, g->device, src->y, src->device, c * m * sizeof(double), src->stream));
+        SQPH_HIP_POST(hipMemcpyPeerAsync(g->info + offset, g->device, src->info, src->device, c * sizeof(sqph_info), src->stream));
     }
-    SQPH_HIP(src, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    SQPH_HIP(src, hipEventRecord(ev, src->stream));
-    {
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->pending.push_back(ev);
-        g->pending_dev.push_back(src->device);
-        if (ev_root) {
-            g->pending.push_back(ev_root);
-            g->pending_dev.push_back(g->device);
-        }
-    }
+    SQPH_HIP_POST(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    SQPH_HIP_POST(hipEventRecord(ev, src->stream));
+#undef SQPH_HIP_POST
+    hand_over();
+    if (rccl_err) SQPH_FAIL(src, SQPH_ERR_HIP, "sqph_gather_post: RCCL: %s", rccl_err);
     return SQPH_OK;
 }
 

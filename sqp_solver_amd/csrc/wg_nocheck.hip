@@ -31,8 +31,8 @@ template <typename TIN>
 int wg_nocheck_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name, int skip) {
 #define SQPH_WG_CASE(NW_, R_, C_, TR_, TC_, TW_, W_)                                                                                     \
     if (a.m <= R_ * TR_ && a.n <= C_ * TC_ && skip-- <= 0) {                                                                             \
-        SQPH_OCC((admm_wg_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>), 64 * NW_);          \
-        hipLaunchKernelGGL((admm_wg_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
+        SQPH_OCC((admm_wg_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, wg_nocheck_wpe(NW_, R_, C_, TR_, TC_, W_)>), 64 * NW_);          \
+        hipLaunchKernelGGL((admm_wg_nocheck_kernel<TIN, NW_, R_, C_, TR_, TC_, TW_, wg_nocheck_wpe(NW_, R_, C_, TR_, TC_, W_)>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
         *name = "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_ "_w" #W_;                                                                    \
         return hipGetLastError() == hipSuccess ? 1 : -1;                                                                                 \
     }

@@ -383,6 +383,29 @@ def warm_start_and_resolve(make, n=8, m=12, batch=4, **kw):
     assert relerr(x, np.array(xs)) < TOL_F64 and relerr(y, np.array(ys)) < TOL_F64
 
 
+def solve_with_other_P(make, n=8, m=12, batch=4, **kw):
+    """setup(qp); solve(qp2) with another P: the reference factors setup()'s matrices and reads solve()'s P for the residuals only
+    (src/qp.cpp:324,360 against :11-44) — same here while the factor is the resident one (sqph_setup leaves it resident; no
+    adaptive rho: a refactorisation would read the call's P, the reference's update_KKT_rho keeps the old block)."""
+    P, q, A, l, u = random_qp_batch(batch, n, m, seed=23)
+    P2 = 1.3 * P + 0.05 * np.eye(n)[None]
+    s = make(n, m, batch, **kw)
+    s.settings.max_iter = 150
+    s.setup(P, q, A, l, u)
+    s.solve(P2, q, A, l, u)
+    x, y, z, info = s.solution()
+    for b in range(batch):
+        o = oracle.QPSolver()
+        o.settings.max_iter = 150
+        o.setup(P[b], q[b], A[b], l[b], u[b])
+        o.solve(P2[b], q[b], A[b], l[b], u[b])
+        assert o.info.status == info.status[b] and o.info.iter == info.iter[b], (b, o.info.status, info.status[b], o.info.iter, info.iter[b])
+        assert relerr(x[b:b + 1], o.primal_solution()[None]) < TOL_F64 and relerr(y[b:b + 1], o.dual_solution()[None]) < TOL_F64
+        assert abs(o.info.res_dual - info.res_dual[b]) <= 1e-6 * max(abs(o.info.res_dual), 1e-9) + 1e-9
+    # ... and the residual really was the one of P2 (with P the dual residual of the same iterate is another number)
+    assert np.max(np.abs(info.res_dual)) > 0
+
+
 def fused_then_solve(make, n=8, m=12, batch=4, adaptive=True, **kw):
     """setup_solve() (fused: the factor is not written to the workspace unless keep_factor) followed by solve() with new
     q, l, u — the second call rebuilds the factor (or finds it resident): same results as setup(); solve(); solve()."""

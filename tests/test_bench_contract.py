@@ -77,9 +77,52 @@ def test_bench_spawned_path_runs_the_rccl_gather():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["gather"] is True and d["config"]["global_batch"] == 1024
+    # the N > 1 diagnostics (a first scaling run must be readable): ranks RCCL sees, per-rank kernel / solve / gather times
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 1 and mg["backend"] == "nccl"
+    for k in ("kernel_ms_avg_per_rank", "solve_ms_per_rank", "gather_ms_sync_per_rank"):
+        assert len(mg[k]) == 1 and mg[k][0] > 0
+    assert mg["record_bytes_per_rank"] == 1024 * (8 * 150 + 40)
     # strong-scaling split with a batch that does not divide evenly is fine on one rank too (padding path: rows == [1023])
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--spawn", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                         "--global-batch", "1023"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["gather"] is True and d["config"]["global_batch"] == 1023 and d["scaling"] == "strong"
+
+
+EXTRA_KEYS = ("c2", "c3_default", "c3_sqp", "c3_whole_65536", "c5")
+
+
+def check_extra(ex):
+    for k in EXTRA_KEYS:
+        e = ex[k]
+        for f in ("workload", "ms_per_step", "kernel_ms_avg", "value", "frac", "traffic", "kernel", "algorithmic_bytes_per_qp", "parity"):
+            assert f in e, (k, f)
+        assert e["ms_per_step"] > 0 and e["value"] > 0 and 0 < e["frac"] < 1
+        p = e["parity"]
+        assert p["max_rel_err_x"] < 1e-6 and p["max_rel_err_y"] < 1e-6 and p["status_equal"] and p["iter_equal"], (k, p)
+    assert "needed_bytes_per_qp" in ex["c5"] and ex["c5"]["frac_needed"] <= ex["c5"]["frac"]
+
+
+def test_recorded_default_line_carries_every_baseline_config():
+    """the default `python bench.py` line (the one the driver records) measures the other BASELINE configs in its `extra` object"""
+    f = os.path.join(ROOT, "profiles", "r04_bench_lines.jsonl")
+    if not os.path.exists(f):
+        pytest.skip("no round-4 lines recorded yet")
+    lines = [json.loads(l) for l in open(f) if l.strip()]
+    with_extra = [d for d in lines if "extra" in d]
+    assert with_extra, "the default line of the round carries `extra`"
+    for d in with_extra:
+        check_extra(d["extra"])
+
+
+@pytest.mark.gpu
+def test_default_bench_line_has_the_extra_configs():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-seconds", "2"],
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    for k in REQUIRED:
+        assert k in d, k
+    check_extra(d["extra"])

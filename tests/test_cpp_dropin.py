@@ -48,6 +48,26 @@ HOST_ONLY = ["ref_bfgs_test"]  # no QP solve inside: runs without a device
 KNOWN_FAILURES = {"ref_sqp_test_autodiff": ["SQPAutoDiff.TestRosenbrock"], "refsrc_sqp_test_autodiff": ["SQPAutoDiff.TestRosenbrock"]}
 
 
+MANIFEST = os.path.join(CPP, "REF_MANIFEST")  # tracked: the binaries tests/cpp/_ref/ must hold on a GPU box (written where they are built)
+
+
+def _write_manifest():
+    with open(MANIFEST, "w") as f:
+        f.write("# binaries built from the reference's own sources (tests/test_cpp_dropin.py); they travel untracked in tests/cpp/_ref/.\n")
+        f.write("# A GPU box on which one of them is missing FAILS test_cpp_dropin's GPU tests instead of skipping them.\n")
+        for k in list(REF) + list(REFSRC):
+            f.write(k + ".bin\n")
+
+
+def _require_manifest_binaries(names):
+    """every binary the tracked manifest promises is there — a missing push must not quietly shrink the evidence"""
+    if not os.path.exists(MANIFEST):
+        return
+    want = [l.strip() for l in open(MANIFEST) if l.strip() and not l.startswith("#")]
+    missing = [w for w in want if w[:-4] in names and not os.path.exists(os.path.join(REFDIR, w))]
+    assert not missing, "tests/cpp/_ref/ lacks %s (listed in tests/cpp/REF_MANIFEST): run __graft_entry__.build() where /root/reference exists" % missing
+
+
 def _link_args(depth):
     _capi.load()
     lib = _capi.lib_path()
@@ -76,6 +96,7 @@ def build_reference_tests():
         cmd += [os.path.join(REFERENCE, s) for s in srcs] + _link_args(3)
         subprocess.check_call(cmd)
         out.append(exe)
+    _write_manifest()
     return out
 
 
@@ -142,8 +163,9 @@ def test_eigen_mode_facade_on_the_gpu():
 @pytest.mark.gpu
 def test_reference_gtest_files_pass_against_the_facade():
     exes = build_reference_tests()
+    _require_manifest_binaries(REF)
     if not exes:
-        pytest.skip("tests/cpp/_ref/*.bin not built (needs /root/reference at build time)")
+        pytest.skip("tests/cpp/_ref/*.bin not built (needs /root/reference at build time) and no manifest promises them")
     for exe in exes:
         p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
         print(p.stdout)
@@ -169,8 +191,9 @@ def test_reference_sqp_source_over_the_facade_equals_the_dropin_class_bit_for_bi
     must pass.  Any difference is a bug in one of the two outer loops."""
     build_reference_tests()
     exes = build_reference_sqp_source()
+    _require_manifest_binaries(REFSRC)
     if not exes:
-        pytest.skip("tests/cpp/_ref/refsrc_*.bin not built (needs /root/reference at build time)")
+        pytest.skip("tests/cpp/_ref/refsrc_*.bin not built (needs /root/reference at build time) and no manifest promises them")
     for exe in exes:
         name = os.path.basename(exe)[:-4]
         twin = os.path.join(REFDIR, name.replace("refsrc_", "ref_") + ".bin")

@@ -79,6 +79,7 @@ def test_state_paths(make):
 def test_fused_call_then_solve(n, m, make):
     """a fused setup_solve keeps no factor by default; the following solve() rebuilds it (every kernel family)"""
     cases.fused_then_solve(make, n=n, m=m, batch=5)
+    cases.solve_with_other_P(make, n=n, m=m, batch=5)  # solve(qp) with another P than setup(qp) (src/qp.cpp:324,360)
 
 
 @pytest.mark.parametrize("n,m", [(2, 3), (4, 6), (8, 12), (20, 40), (50, 100), (100, 200)])

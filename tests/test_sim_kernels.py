@@ -186,6 +186,7 @@ def test_wg_tall_shapes(n, m):
 def test_fused_call_then_solve(make, n, m):
     """factor residency policy (capi.hip, mirrored by simlib): fused setup_solve without / with keep_factor, then solve()"""
     cases.fused_then_solve(make, n=n, m=m, batch=2)
+    cases.solve_with_other_P(make, n=n, m=m, batch=2)  # solve(qp) with another P than setup(qp): residuals from the call's P
 
 
 # ---------------------------------------------------------------- one QP per lane (tiny problems)
