@@ -15,9 +15,19 @@ inline int lane_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, cons
 #ifdef SQPH_EXPERIMENTS  // environment knobs exist in experiment builds only (tools/slim_build.sh), never in the shipped library
     static const bool off = getenv("SQPH_NO_LANE") != nullptr;
     if (off) return 0;
+    static const bool no_quad = getenv("SQPH_NO_QUAD") != nullptr;
+#else
+    constexpr bool no_quad = false;
 #endif
 #define SQPH_LANE_CASE(N_, M_, E_)                                                                                    \
     if (SQPH_LANE_MATCH(a, N_, M_, E_)) {                                                                             \
+        if constexpr (M_ <= 4 && sizeof(TA) == 8) {   /* small batch: four lanes per QP (admm_lane_kernel.h, LPQ = 4) */ \
+            if (a.batch <= SQPH_QUAD_MAX_BATCH && !no_quad) {                                                          \
+                hipLaunchKernelGGL((admm_lane_kernel<TA, TIN, N_, M_, E_, 4>), dim3((a.batch + 15) / 16), dim3(64), 0, stream, a); \
+                *name = (E_) ? "quad_" #N_ "x" #M_ "_exact" : "quad_" #N_ "x" #M_;                                       \
+                return hipGetLastError() == hipSuccess ? 1 : -1;                                                      \
+            }                                                                                                         \
+        }                                                                                                             \
         hipLaunchKernelGGL((admm_lane_kernel<TA, TIN, N_, M_, E_>), dim3((a.batch + 63) / 64), dim3(64), 0, stream, a);   \
         *name = sizeof(TA) == 4 ? ((E_) ? "lane_" #N_ "x" #M_ "_exact_f32" : "lane_" #N_ "x" #M_ "_f32")                \
                                 : ((E_) ? "lane_" #N_ "x" #M_ "_exact" : "lane_" #N_ "x" #M_);                          \

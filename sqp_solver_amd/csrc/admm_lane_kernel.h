@@ -13,6 +13,7 @@
 #pragma once
 #include "block_ops.h"
 #include "kargs.h"
+#include "wave_ops.h"
 
 namespace sqph {
 
@@ -31,16 +32,71 @@ __device__ __forceinline__ float lane_fma(float a, float b, float c) { return __
 #define LFMA(a, b, c) ((a) * (b) + (c))
 #endif
 
+// An ADMM iteration of a QP this small is ONE chain of dependent fp64 operations (w -> A'w -> W -> W' -> A x~ -> relax -> clip -> y), and a
+// lone wavefront pays ~25 cycles per link (measured, tools/xp/quad_lat.sh): the three helpers below are the same formulas with fewer
+// links (round 4: 20 -> 17 per iteration).  -DSQPH_LANE_NO_FMA keeps the statement order of rounds 1-2.
+// w = R (z - R^-1 y), the rhs tail of qp.cpp:275 pre-multiplied by R:  rho z - y in one fused operation
+template <typename T>
+__device__ __forceinline__ T lane_w(T rho, T rinv, T y, T z) {
+#ifndef SQPH_LANE_NO_FMA
+    (void)rinv;
+    return lane_fma(rho, z, -y);
+#else
+    return rho * (z - rinv * y);
+#endif
+}
+// z = min(max(zr + R^-1 y, l), u) (cwiseMax(l) then cwiseMin(u), qp.cpp:278-281), y += R (zr - z) (qp.cpp:103).  lmin = min(l, u):
+// what "max with l, then min with u" returns below l — with it the two comparisons no longer depend on each other (identical results,
+// NaN included)
+template <typename T>
+__device__ __forceinline__ void lane_tail(T zr, T rho, T rinv, T l, T lmin, T u, T &y, T &z) {
+    const T zn0 = LFMA(rinv, y, zr);
+#ifndef SQPH_LANE_NO_FMA
+    const T hi = zn0 > u ? u : zn0;
+    const T zn = zn0 < l ? lmin : hi;
+    y = lane_fma(rho, zr - zn, y);  // (not (y + rho zr) - rho z: a row that never binds must keep y == 0 exactly)
+#else
+    T zn = zn0 < l ? l : zn0;
+    zn = zn > u ? u : zn;
+    (void)lmin;
+    y = y + rho * (zr - zn);
+#endif
+    z = zn;
+}
+
 
 // EXACT: n == NMAX and m == MMAX are compile-time constants (every bound check folds away; the SQP driver's shapes);
 // otherwise the arrays are padded to NMAX x MMAX and the run-time n, m guard every row and column.
 // TA = arithmetic type: double (default: fp64 whatever the interface Scalar is) or float (SQPH_FLAG_F32_ARITH with a float
 // interface: a true single-precision solve — iterates, factor and residuals in fp32; the resident state arrays stay fp64 and are
 // converted at the kernel's boundary).
-template <typename TA, typename TIN, int NMAX, int MMAX, bool EXACT>
+// LPQ = lanes per QP: 1 (throughput: 64 QPs per wavefront), or 4 — the QUAD variant for small batches (the SQP driver's 1,024
+// instances are 16 wavefronts on a chip of 1,024 SIMDs; round 4, asked for by the round-3 review on the premise that a call takes
+// as long as the instruction stream of ONE lane's iterations, ~110 instructions per ADMM iteration — see SQPH_QUAD_MAX_BATCH below for
+// what the measurement said).  The four lanes of a quad hold
+// the same QP and run set-up, factorisation and the residual checks redundantly; in the iteration lane k of the quad owns constraint
+// row k (m <= 4): it forms w_k, its row's contribution to A'w (summed over the quad by two DPP quad_perm exchanges per entry) and its
+// row of z~, z, y — ~45 instructions per iteration.  Lane 0 of the quad writes the results.
+template <typename TA, typename TIN, int NMAX, int MMAX, bool EXACT, int LPQ = 1>
 struct LaneKernel {
     using T = TA;
     static constexpr int MM = MMAX > 0 ? MMAX : 1;
+    static_assert(LPQ == 1 || (LPQ == 4 && MMAX <= 4), "the quad variant gives every constraint row a lane");
+    // element k of a small register array by a chain of selects (k is a lane index)
+    template <int N>
+    static __device__ __forceinline__ T pick(const T (&v)[N], int k, T pad) {
+        T r = pad;
+#pragma unroll
+        for (int i = 0; i < N; i++) r = (k == i) ? v[i] : r;
+        return r;
+    }
+    // every lane of the quad gets the m-vector whose element k lane k holds
+    static __device__ __forceinline__ void quad_gather(T vk, T (&v)[MM]) {
+        if constexpr (MM > 0) v[0] = quad_bcast<0>(vk);
+        if constexpr (MM > 1) v[1] = quad_bcast<1>(vk);
+        if constexpr (MM > 2) v[2] = quad_bcast<2>(vk);
+        if constexpr (MM > 3) v[3] = quad_bcast<3>(vk);
+    }
 
     // S = P_sym + sigma I + A' diag(rho) A ; Jacobi scaling ; forward elimination of [S~ | I] ; W = D^-1/2 L^-1 D_J^-1/2.
     // false on a non-positive / non-finite pivot (this QP only).
@@ -126,7 +182,9 @@ struct LaneKernel {
     }
 
     static __device__ __forceinline__ void run(const KArgs<double, TIN> &a) {
-        const int qp = blockIdx.x * blockDim.x + threadIdx.x;
+        const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+        const int qp = gt / LPQ, kq = gt % LPQ;  // QP and (quad variant) my lane of its quad
+        const bool writer = LPQ == 1 || kq == 0;
         if (qp >= a.batch) return;
         const int n = EXACT ? NMAX : a.n, m = EXACT ? MMAX : a.m;
         const TIN *gP = a.P + (long)qp * a.sP;
@@ -152,7 +210,7 @@ struct LaneKernel {
 
         const T INF = T(1) / T(0);
         T P[NMAX][NMAX], A[MM][NMAX], W[NMAX][NMAX];
-        T q[NMAX], x[NMAX], l[MM], u[MM], z[MM], y[MM], rho[MM], rinv[MM];
+        T q[NMAX], x[NMAX], l[MM], u[MM], lmin[MM], z[MM], y[MM], rho[MM], rinv[MM];
         int ct[MM];
 #pragma unroll
         for (int j = 0; j < NMAX; j++) {
@@ -167,6 +225,7 @@ struct LaneKernel {
         for (int i = 0; i < MMAX; i++) {
             l[i] = i < m ? (T)gl[i] : -INF;
             u[i] = i < m ? (T)gu[i] : INF;
+            lmin[i] = l[i] > u[i] ? u[i] : l[i];
             z[i] = y[i] = 0;
             rho[i] = rinv[i] = T(1);
             ct[i] = SQPH_INEQUALITY_CONSTRAINT;
@@ -196,8 +255,16 @@ struct LaneKernel {
                     rho[i] = rho_for_type<T>(c, rho_s, a_rho_min, a_eqf);
                     rinv[i] = T(1) / rho[i];
                     if (rho_unchanged && !((double)rho[i] == srho[i])) rho_unchanged = false;
-                    sct[i] = c;
-                    srho[i] = (double)rho[i];
+                }
+            }
+            if constexpr (LPQ > 1) quad_sync();  // every lane of the quad has compared before lane 0 overwrites
+            if (writer) {
+#pragma unroll
+                for (int i = 0; i < MMAX; i++) {
+                    if (i < m) {
+                        sct[i] = ct[i];
+                        srho[i] = (double)rho[i];
+                    }
                 }
             }
             info.rho_updates += 1;
@@ -247,7 +314,7 @@ struct LaneKernel {
         for (;;) {
             if (need_factor) {
                 const bool ok = factor(Pl, A, rho, n, m, sigma, W);
-                if (!(mode & MODE_NO_FACTOR_STORE)) {
+                if (!(mode & MODE_NO_FACTOR_STORE) && writer) {
 #pragma unroll
                     for (int i = 0; i < NMAX; i++)
 #pragma unroll
@@ -276,18 +343,57 @@ struct LaneKernel {
                     for (int i = 0; i < MMAX; i++) z[i] = y[i] = 0;
                 }
             }
+            // quad variant: my constraint row (lanes beyond m carry a padding row: A = 0, rho = 1, no bounds)
+            T Ak[NMAX], rk = T(1), rik = T(1), lk = -INF, lmk = -INF, uk = INF, zk = 0, yk = 0;
+            if constexpr (LPQ > 1) {
+#pragma unroll
+                for (int j = 0; j < NMAX; j++) {
+                    T col[MM];
+#pragma unroll
+                    for (int i = 0; i < MM; i++) col[i] = A[i][j];
+                    Ak[j] = pick<MM>(col, kq, T(0));
+                }
+                rk = pick<MM>(rho, kq, T(1));
+                rik = pick<MM>(rinv, kq, T(1));
+                lk = pick<MM>(l, kq, -INF);
+                lmk = pick<MM>(lmin, kq, -INF);
+                uk = pick<MM>(u, kq, INF);
+                zk = pick<MM>(z, kq, T(0));
+                yk = pick<MM>(y, kq, T(0));
+            }
             for (; iter <= a.max_iter; iter++) {
                 T b[NMAX], t[NMAX], xt[NMAX];
+                if constexpr (LPQ > 1) {
+                    const T w = lane_w<T>(rk, rik, yk, zk);
 #pragma unroll
-                for (int j = 0; j < NMAX; j++) b[j] = 0;
+                    for (int j = 0; j < NMAX; j++) {
+                        T cj = Ak[j] * w;
+                        cj += quad_xor<1>(cj);
+                        cj += quad_xor<2>(cj);
+                        b[j] = LFMA(sigma, x[j], -q[j]) + cj;
+                    }
+                } else {
+                // b = sigma x - q + A'w as two interleaved accumulation chains (even rows onto sigma x - q, odd rows apart)
+                T b1[NMAX];
 #pragma unroll
-                for (int i = 0; i < MMAX; i++) {
-                    const T w = rho[i] * LFMA(-rinv[i], y[i], z[i]);  // rhs tail of qp.cpp:275 pre-multiplied by R
-#pragma unroll
-                    for (int j = 0; j < NMAX; j++) b[j] = LFMA(A[i][j], w, b[j]);
+                for (int j = 0; j < NMAX; j++) {
+                    b[j] = LFMA(sigma, x[j], -q[j]);
+                    b1[j] = 0;
                 }
 #pragma unroll
-                for (int j = 0; j < NMAX; j++) b[j] = LFMA(sigma, x[j], -q[j]) + b[j];
+                for (int i = 0; i < MMAX; i++) {
+                    const T w = lane_w<T>(rho[i], rinv[i], y[i], z[i]);
+#pragma unroll
+                    for (int j = 0; j < NMAX; j++) {
+                        if (i & 1) b1[j] = (i == 1) ? A[i][j] * w : LFMA(A[i][j], w, b1[j]);
+                        else b[j] = LFMA(A[i][j], w, b[j]);
+                    }
+                }
+                if constexpr (MMAX > 1) {
+#pragma unroll
+                    for (int j = 0; j < NMAX; j++) b[j] = b[j] + b1[j];
+                }
+                }
 #pragma unroll
                 for (int i = 0; i < NMAX; i++) {
                     T s = 0;
@@ -304,17 +410,21 @@ struct LaneKernel {
                 }
 #pragma unroll
                 for (int j = 0; j < NMAX; j++) x[j] = LFMA(alpha, xt[j], oma * x[j]);
+                if constexpr (LPQ > 1) {
+                    T zt = 0;
+#pragma unroll
+                    for (int j = 0; j < NMAX; j++) zt = LFMA(Ak[j], xt[j], zt);
+                    const T zr = LFMA(alpha, zt, oma * zk);
+                    lane_tail<T>(zr, rk, rik, lk, lmk, uk, yk, zk);
+                } else {
 #pragma unroll
                 for (int i = 0; i < MMAX; i++) {
                     T zt = 0;
 #pragma unroll
                     for (int j = 0; j < NMAX; j++) zt = LFMA(A[i][j], xt[j], zt);
                     const T zr = LFMA(alpha, zt, oma * z[i]);
-                    T zn = LFMA(rinv[i], y[i], zr);
-                    zn = zn < l[i] ? l[i] : zn;  // cwiseMax(l) then cwiseMin(u), qp.cpp:278-281
-                    zn = zn > u[i] ? u[i] : zn;
-                    y[i] = LFMA(rho[i], zr - zn, y[i]);
-                    z[i] = zn;
+                    lane_tail<T>(zr, rho[i], rinv[i], l[i], lmin[i], u[i], y[i], z[i]);
+                }
                 }
                 bool check = false, adapt = false;
                 if (--next_check == 0) {
@@ -326,6 +436,10 @@ struct LaneKernel {
                     next_adapt = a.adaptive_rho_interval;
                 }
                 if (check || adapt) {
+                    if constexpr (LPQ > 1) {  // the checks run on the whole vectors, in every lane of the quad
+                        quad_gather(zk, z);
+                        quad_gather(yk, y);
+                    }
                     // update_state + residuals, qp.cpp:316-331, 353-361
                     T v[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -357,7 +471,7 @@ struct LaneKernel {
                     const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
                     info.res_prim = (double)v[2];
                     info.res_dual = (double)v[6];
-                    if (check && a.trace && qp == a.trace_qp) {  // print_status, qp.cpp:373-383 (recorded; the host prints)
+                    if (check && a.trace && qp == a.trace_qp && writer) {  // print_status, qp.cpp:373-383 (recorded; the host prints)
                         T obj = 0;
 #pragma unroll
                         for (int j = 0; j < NMAX; j++) {
@@ -403,12 +517,17 @@ struct LaneKernel {
                     }
                 }
             }
+            if constexpr (LPQ > 1) {  // (after a check the vectors are current already; after an exhausted loop they are not)
+                quad_gather(zk, z);
+                quad_gather(yk, y);
+            }
             if (!need_factor) break;
         }
         if (solving) {
             if (iter > a.max_iter) info.status = SQPH_MAX_ITER_EXCEEDED;
             info.iter = iter;
         }
+        if (!writer) return;
         if (state_dirty) {
 #pragma unroll
             for (int j = 0; j < NMAX; j++)
@@ -426,10 +545,16 @@ struct LaneKernel {
     }
 };
 
-template <typename TA, typename TIN, int NMAX, int MMAX, bool EXACT>
+template <typename TA, typename TIN, int NMAX, int MMAX, bool EXACT, int LPQ = 1>
 __global__ __launch_bounds__(64) void admm_lane_kernel(KArgs<double, TIN> a) {
-    LaneKernel<TA, TIN, NMAX, MMAX, EXACT>::run(a);
+    LaneKernel<TA, TIN, NMAX, MMAX, EXACT, LPQ>::run(a);
 }
+// batches up to this size take the quad variant where the shape has one (m <= 4).  Measured on the MI355X (tools/xp/quad_lat.sh,
+// gpurun_out/r04_quad_lat.txt; (2,3), device-resident): 1,024 QPs x 200 iterations 43 us against 47 us for one QP per lane, the SQP
+// driver's settings 47 against 52 us — an ADMM iteration of a QP this small is a chain of ~20 DEPENDENT fp64 operations (~25 cycles
+// each for a lone wavefront), not an instruction-issue problem, so spreading the rows over lanes shortens it only by the length of
+// the A'w accumulation; from ~4,096 QPs on the extra wavefronts cost more than that (16,384: 0.357 against 0.279 ms, default settings)
+#define SQPH_QUAD_MAX_BATCH 2048
 
 // shapes compiled into the library: {NMAX, MMAX, EXACT}; first match wins (exact: n == NMAX && m == MMAX; else n <= NMAX && m <= MMAX).
 // The exact ones are the shapes of the reference's SQP test problems (tests/sqp_test.cpp, tests/sqp_test_autodiff.cpp).
@@ -441,15 +566,22 @@ __global__ __launch_bounds__(64) void admm_lane_kernel(KArgs<double, TIN> a) {
     X(2, 2, true)           \
     X(3, 3, true)           \
     X(2, 1, true)           \
+    X(4, 4, false)          \
     X(4, 6, false)
 #endif
 #define SQPH_LANE_MATCH(a, N_, M_, E_) ((E_) ? ((a).n == N_ && (a).m == M_) : ((a).n <= N_ && (a).m <= M_))
 
 #ifdef SQPH_SIM
 template <typename TIN, typename TA = double>
-inline int sim_run_lane(const KArgs<double, TIN> &a) {
+inline int sim_run_lane(const KArgs<double, TIN> &a, bool quad = false) {
 #define SQPH_SIM_CASE(N_, M_, E_)                                                                          \
     if (SQPH_LANE_MATCH(a, N_, M_, E_)) {                                                                  \
+        if constexpr (M_ <= 4 && sizeof(TA) == 8) {                                                        \
+            if (quad) {                                                                                    \
+                ::sqph_sim::launch(admm_lane_kernel<TA, TIN, N_, M_, E_, 4>, dim3((a.batch + 15) / 16), dim3(64), 0, a); \
+                return 0;                                                                                  \
+            }                                                                                              \
+        }                                                                                                  \
         ::sqph_sim::launch(admm_lane_kernel<TA, TIN, N_, M_, E_>, dim3((a.batch + 63) / 64), dim3(64), 0, a);  \
         return 0;                                                                                          \
     }

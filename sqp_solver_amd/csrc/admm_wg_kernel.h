@@ -232,7 +232,11 @@ struct WgLayout {
     static constexpr bool P_STAGED = NW > 0 && O_PST + NP * NP <= O_QV;
     // fp32-product variant: the same regions viewed as floats (float offset = 2 x the double offset), rows padded to 16 bytes
     static constexpr int r4(int x) { return (x + 3) & ~3; }
-    static constexpr int TRf = r4(TR), TWf = r4(TW), TCf = r4(TC);  // gather strides (floats)
+    // gather strides (floats).  The R lanes of a column group read their rows with one ds_read_b128 each: a stride of an EVEN number of
+    // 16-byte units puts lanes r and r + 8 on the same banks (TR = 7: 8 floats, two-way on every operand read), an odd number spreads
+    // the 16 lanes over all 64
+    static constexpr int odd16(int x) { return ((x / 4) % 2 == 0) ? x + 4 : x; }
+    static constexpr int TRf = odd16(r4(TR)), TWf = odd16(r4(TW)), TCf = r4(TC);
     static constexpr int Rf = r4(R) + 4, Cf = r4(C) + 4;           // staging strides (floats)
     static constexpr int TC2 = (TC + 1) / 2;                       // column pairs of a tile row
     static constexpr bool F32_FITS = R * TRf <= 2 * R * TRp && R * TWf <= 2 * R * TWp && C * TCf <= 2 * C * TCp && NP * Rf <= 2 * STAGE_X &&

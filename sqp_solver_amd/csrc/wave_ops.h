@@ -248,4 +248,48 @@ __device__ __forceinline__ double fmac_bcast16(double acc, double x, double y) {
 #endif
 }
 
+
+// ---- four lanes per QP (the quad variant of the one-QP-per-lane kernel, admm_lane_kernel.h): exchanges inside an aligned quad by DPP
+// quad_perm — quads of a wavefront may have diverged (different iteration counts), the lanes of one quad never do
+template <int MASK, typename T>
+__device__ __forceinline__ T quad_xor(T v) {  // value of lane (l ^ MASK) of my quad, MASK = 1 or 2
+    static_assert(MASK == 1 || MASK == 2, "stays inside the quad");
+#ifdef SQPH_SIM
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    const uint64_t r = ::sqph_sim::group_exchange<4>(bits, (int)(threadIdx.x & 3) ^ MASK);
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
+#else
+    return xchg<MASK>(v);
+#endif
+}
+template <int I, typename T>
+__device__ __forceinline__ T quad_bcast(T v) {  // value of lane I of my quad
+#ifdef SQPH_SIM
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    const uint64_t r = ::sqph_sim::group_exchange<4>(bits, I);
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
+#else
+    constexpr int CTRL = I | (I << 2) | (I << 4) | (I << 6);  // quad_perm:[I,I,I,I]
+    if constexpr (sizeof(T) == 8) {
+        double d = (double)v;
+        const int lo = dpp_mov_i32<CTRL>(__double2loint(d)), hi = dpp_mov_i32<CTRL>(__double2hiint(d));
+        return (T)__hiloint2double(hi, lo);
+    } else {
+        return (T)__int_as_float(dpp_mov_i32<CTRL>(__float_as_int((float)v)));
+    }
+#endif
+}
+// the lanes of a quad run in lockstep on the device; the emulator's fibers do not — a rendezvous there, nothing here
+__device__ __forceinline__ void quad_sync() {
+#ifdef SQPH_SIM
+    ::sqph_sim::group_sync<4>();
+#endif
+}
+
 }  // namespace sqph

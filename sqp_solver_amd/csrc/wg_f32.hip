@@ -21,11 +21,11 @@ int wgf_try_launch(const KArgs<double, float> &a, hipStream_t stream, const char
         if (stack && checks)                                                                                                                \
             hipLaunchKernelGGL((admm_wgf_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_, CAN_STACK>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
         else if (stack)                                                                                                                     \
-            hipLaunchKernelGGL((admm_wgf_nocheck_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_, CAN_STACK>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
+            hipLaunchKernelGGL((admm_wgf_nocheck_kernel<float, NW_, R_, C_, TR_, TC_, TW_, wg_nocheck_wpe(NW_, R_, C_, TR_, TC_, W_), CAN_STACK>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
         else if (checks)                                                                                                                    \
             hipLaunchKernelGGL((admm_wgf_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a);       \
         else                                                                                                                                \
-            hipLaunchKernelGGL((admm_wgf_nocheck_kernel<float, NW_, R_, C_, TR_, TC_, TW_, W_>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
+            hipLaunchKernelGGL((admm_wgf_nocheck_kernel<float, NW_, R_, C_, TR_, TC_, TW_, wg_nocheck_wpe(NW_, R_, C_, TR_, TC_, W_)>), dim3(a.batch), dim3(64 * NW_), 0, stream, a); \
         *name = stack ? "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_ "s_w" #W_ "_f32" : "wg" #NW_ "_" #R_ "x" #C_ "_" #TR_ "x" #TC_ "_w" #W_ "_f32"; \
         return hipGetLastError() == hipSuccess ? 1 : -1;                                                                                    \
     }

@@ -39,7 +39,7 @@ struct Lane {
     ucontext_t ctx;
     std::vector<unsigned char> stack;
     bool done = false;
-    int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier, 3 / 4 barrier of an aligned 16- / 32-lane group
+    int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier, 3 / 4 / 5 barrier of an aligned 16- / 32- / 4-lane group
 };
 
 struct Block {
@@ -132,8 +132,8 @@ inline void run_block(unsigned nthreads, size_t smem_bytes, const std::function<
                 }
             }
             // 16- and 32-lane groups (kernels that run several independent QPs per wave; the groups may diverge)
-            for (unsigned gs = 16; gs <= 32; gs *= 2) {
-                const int kind = gs == 16 ? 3 : 4;
+            for (unsigned gs = 4; gs <= 32; gs = gs == 4 ? 16 : gs * 2) {
+                const int kind = gs == 16 ? 3 : gs == 32 ? 4 : 5;
                 for (unsigned g = 0; g * gs < nthreads; g++) {
                     bool all_grp = true, any = false;
                     for (unsigned t = g * gs; t < nthreads && t < (g + 1) * gs; t++) {
@@ -209,8 +209,8 @@ inline void poison_static_lds(void *p, size_t bytes) {
 // the same inside an aligned group of 16 lanes (groups of one wave may have diverged)
 template <int GS>
 inline void group_sync() {
-    static_assert(GS == 16 || GS == 32, "group size");
-    yield_wait(GS == 16 ? 3 : 4);
+    static_assert(GS == 4 || GS == 16 || GS == 32, "group size");
+    yield_wait(GS == 16 ? 3 : GS == 32 ? 4 : 5);
 }
 template <int GS>
 inline uint64_t group_exchange(uint64_t v, int src_lane_in_group) {

@@ -89,6 +89,7 @@ int sim_run(const SimArgs *s, int variant, int dtype, int nt) {
     if (variant == 0) return dtype == SQPH_F32 ? run_generic<float>(*s, nt) : run_generic<double>(*s, nt);
     if (variant == 4) return dtype == SQPH_F32 ? sqph::sim_run_g16<float>(convert<float>(*s)) : sqph::sim_run_g16<double>(convert<double>(*s));
     if (variant == 7) return dtype == SQPH_F32 ? sqph::sim_run_lane<float, float>(convert<float>(*s)) : -1;
+    if (variant == 13) return dtype == SQPH_F32 ? sqph::sim_run_lane<float>(convert<float>(*s), true) : sqph::sim_run_lane<double>(convert<double>(*s), true);  // four lanes per QP
     if (variant == 6) return dtype == SQPH_F32 ? sqph::sim_run_lane<float>(convert<float>(*s)) : sqph::sim_run_lane<double>(convert<double>(*s));
     if (variant == 2) return dtype == SQPH_F32 ? sqph::sim_run_wg<float>(convert<float>(*s)) : sqph::sim_run_wg<double>(convert<double>(*s));
     return -1;

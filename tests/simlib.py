@@ -16,6 +16,7 @@ GENERIC, WG, CSR, G16, LANE, LANE_F32 = 0, 2, 3, 4, 6, 7
 GENERIC_F32_ARITH = 9  # measurement only: the generic kernel in fp32 arithmetic (fp32 state arrays)
 WG_STACK = 12  # register-tiled kernel on the stacked operator (m <= 104 at the C3 shape)
 CSR_DENSE = 11  # the sparse kernel's dense-A mode (A streamed from global memory, W in the CU's registers)
+LANE_QUAD = 13  # the one-QP-per-lane kernel's quad variant (four lanes per QP, m <= 4: small batches)
 WG_F32 = 10  # register-tiled kernels with fp32 products (SQPH_FLAG_F32_ARITH), float interface only
 
 

@@ -294,11 +294,13 @@ def test_full_size_properties_c5():
 
 
 def test_small_shapes_take_the_lane_and_four_per_wave_kernels():
-    """n <= 4 / m <= 6 (the SQP driver's subproblems): one QP per lane; up to n = 12 / m = 24: four QPs per wavefront;
-    a large odd batch against the oracle"""
+    """n <= 4 / m <= 6 (the SQP driver's subproblems): one QP per lane — four lanes per QP (the quad variant, m <= 4) up to 2,048
+    QPs (the SQP driver's batch sizes); up to n = 12 / m = 24: four
+    QPs per wavefront; large odd batches against the oracle"""
     from sqp_solver_amd.problems import random_qp_batch
 
-    for (n, m, B, kern) in ((2, 3, 4099, "lane_2x3_exact"), (4, 6, 3001, "lane_4x6"), (3, 3, 1500, "lane_3x3_exact"), (4, 5, 700, "lane_4x6"), (8, 12, 2051, "g16_"), (12, 24, 1027, "g16_")):
+    for (n, m, B, kern) in ((2, 3, 1999, "quad_2x3_exact"), (2, 3, 4099, "lane_2x3_exact"), (4, 6, 3001, "lane_4x6"), (3, 3, 1500, "quad_3x3_exact"),
+                           (3, 3, 2100, "lane_3x3_exact"), (4, 4, 333, "quad_4x4"), (3, 2, 2500, "lane_4x4"), (4, 5, 700, "lane_4x6"), (8, 12, 2051, "g16_"), (12, 24, 1027, "g16_")):
         P, q, A, l, u = random_qp_batch(B, n, m, seed=31)
         s = make_gpu(n, m, B)
         s.setup_solve(P, q, A, l, u)
@@ -435,6 +437,12 @@ def test_lane_kernel_paths():
     cases.fused_then_solve(make_gpu, n=4, m=5, batch=3)
     s = make_gpu(2, 3, 4)
     s.setup_solve(*cases.simple(4))
+    assert s.kernel_name() == "quad_2x3_exact"  # (small batch: four lanes per QP)
+    # the same paths on batches beyond the quad variant's limit (one QP per lane)
+    cases.parity_fixed_iters(make_gpu, 2, 3, 2100, iters=100, dual_floor=True)
+    cases.parity_termination(make_gpu, 2, 3, 2100, sqp_settings=True, diagnostics="stable")
+    s = make_gpu(2, 3, 2100)
+    s.setup_solve(*cases.random_qp_batch(2100, 2, 3, seed=2))
     assert s.kernel_name() == "lane_2x3_exact"
 
 

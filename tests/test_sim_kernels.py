@@ -223,6 +223,34 @@ def test_lane_parity_alpha_float_termination_and_state_paths():
         cases.stress_parity(make_lane, 4, 6, 8, kind, iters=120)
 
 
+def make_quad(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.LANE_QUAD, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
+
+
+@pytest.mark.parametrize("case", [c for c in cases.REFERENCE_CASES if c.__name__ != "ref_legacy_TestConstraint"], ids=lambda f: f.__name__)
+def test_quad_reference_cases(case):
+    case(make_quad)
+
+
+def test_quad_variant_of_the_lane_kernel():
+    """LaneKernel<..., LPQ = 4>: four lanes per QP (m <= 4), quads of a wavefront diverging freely — fixed iterations at the exact
+    shapes and a padded one, termination in the three settings (iteration counts differ between the quads of a wave), state paths"""
+    for (n, m, b) in ((2, 3, 37), (2, 2, 20), (3, 3, 18), (2, 1, 5), (4, 4, 9), (3, 2, 7)):
+        cases.parity_fixed_iters(make_quad, n, m, b, iters=120)
+    cases.parity_fixed_iters(make_quad, 2, 3, 8, iters=100, alpha=1.6)
+    cases.parity_fixed_iters(make_quad, 2, 3, 8, iters=100, dtype=np.float32)
+    for kw in (dict(), dict(adaptive=True), dict(sqp_settings=True)):
+        cases.parity_termination(make_quad, 2, 3, 40, diagnostics=True if not kw else "stable", **kw)
+        cases.parity_termination(make_quad, 3, 3, 24, diagnostics=True if not kw else "stable", **kw)
+    cases.warm_start_and_resolve(make_quad, n=3, m=3)
+    cases.set_state_warm_start(make_quad, n=3, m=4)
+    cases.uninitialized_and_numerical_issues(make_quad, n=3, m=3)
+    cases.shared_matrices(make_quad, n=4, m=4)
+    cases.fused_then_solve(make_quad, n=3, m=3, batch=3)
+    cases.soc_factor_reuse(make_quad, n=2, m=3, batch=6)
+    cases.solve_with_other_P(make_quad, n=2, m=3, batch=5)
+
+
 def make_lane_f32(n, m, batch, dtype=np.float32, legacy_cold_start=False, **kw):
     return simlib.SimSolverBatch(n, m, batch, dtype=np.float32, variant=simlib.LANE_F32, legacy_cold_start=legacy_cold_start)
 
