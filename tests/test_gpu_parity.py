@@ -70,6 +70,8 @@ def test_state_paths(make):
     cases.warm_start_and_resolve(make)
     cases.set_state_warm_start(make)
     cases.uninitialized_and_numerical_issues(make)
+    for (n, m) in ((2, 3), (8, 12), (20, 40), (50, 100), (56, 112), (100, 200)):  # every kernel family's factorisation, the MFMA set-up among them
+        cases.failing_pivots(make, n=n, m=m, batch=5)
     cases.shared_matrices(make)
     cases.edge_shapes(make)
 
@@ -342,16 +344,18 @@ def test_true_fp32_variant():
 def test_fp32_product_variant_of_the_register_tiled_kernels():
     """SQPH_FLAG_F32_ARITH at the BASELINE dense shapes (reference src/qp.cpp:385-386 and
     tests/qp_solver_test.cpp:58-69): tiles, operands and partial sums of the two iteration stages in fp32 (wg_f32.hip), the
-    factorisation, the iterates and the residual checks in fp64.  Tolerance as in tests/test_sim_kernels.py: x within TOL_F32 of
-    the float oracle; x, y, z no further from the fp64 solution than max(4x the float oracle, 1e-3).  Default termination against
+    factorisation, the iterates and the residual checks in fp64.  Stated accuracy, WITHOUT a floor (round 4; measured on the MI355X,
+    tools/xp/f32_err.py: x 0.7-1.7x, z 0.5-1.8x, y 2.7-4.6x the float oracle's error against the fp64 solution): x and z no further
+    from the fp64 solution than 2.5x the reference's QPSolver<float>, y no further than 6x — i.e. this variant is as accurate as the
+    reference's float path on the primal side and ~4x less accurate on the dual.  Default termination against
     the FP64 oracle: status equal, iteration counts equal on >= 90 % of the batch, solutions of those within 1e-4."""
     from sqp_solver_amd.problems import random_qp_batch
 
     mk = lambda n, m, b, **kw: make_gpu(n, m, b, dtype=np.float32, f32_arith=True, keep_factor=kw.get("keep_factor", False))  # noqa: E731
     worst = {}
     for (n, m, b, kern) in ((20, 40, 512, "wg1_8x8_5x3_w3_f32"), (50, 100, 256, "wg2_16x8_7x7s_w2_f32"), (30, 60, 64, "wg2_16x8_7x7s_w2_f32"), (56, 112, 32, "wg2_16x8_7x7_w2_f32")):
-        ex, ey, ez = cases.parity_fixed_iters(mk, n, m, b, iters=200, dtype=np.float32, f32_floor=1e-3)
-        assert ex < 5e-5 and ey < 1e-3, (n, m, ex, ey)
+        ex, ey, ez = cases.parity_fixed_iters(mk, n, m, b, iters=200, dtype=np.float32, f32_floor=0.0, f32_ratio=(2.5, 6.0, 2.5))
+        assert ex < 2e-5 and ey < 1e-3, (n, m, ex, ey)
         worst[(n, m)] = (ex, ey)
         P, q, A, l, u = random_qp_batch(b, n, m, seed=3, dtype=np.float32)
         s = mk(n, m, b)

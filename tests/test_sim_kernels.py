@@ -290,6 +290,9 @@ def test_wg_stacked_operator():
     cases.fused_then_solve(make_wg_stack, n=50, m=100, batch=2)
     cases.warm_start_and_resolve(make_wg_stack, n=40, m=77)
     cases.soc_factor_reuse(make_wg_stack, n=50, m=100, batch=2)
+    cases.failing_pivots(make_wg_stack, n=50, m=100, batch=4)  # the MFMA set-up: the pivot flag of a diagonal block, NaN through the block products
+    cases.failing_pivots(make_wg, n=8, m=12, batch=4)
+    cases.failing_pivots(make_wg, n=20, m=40, batch=4)
 
 
 def make_csr_dense(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
@@ -316,15 +319,16 @@ def make_wg_f32(n, m, batch, dtype=np.float32, legacy_cold_start=False, **kw):
 def test_wg_fp32_product_variant():
     """SQPH_FLAG_F32_ARITH at the BASELINE dense shapes (reference src/qp.cpp:385-386): B / W' tiles, operand
     vectors and partial sums of the two iteration stages in fp32 (v_pk_fma_f32), factorisation / iterates / residual checks in
-    fp64.  Stated tolerance (cases.parity_fixed_iters): x within TOL_F32 = 5e-3 of the reference's QPSolver<float> (float oracle);
-    x, y, z no further from the fp64 solution of the same float-valued problem than max(4x the float oracle's error, 1e-3);
-    measured 6e-7..2e-6 (x) and 9e-5..2e-4 (y) against 1e-6 / 2e-5..4e-5 for the float oracle.  Default termination: status equal,
+    fp64.  Stated accuracy, without a floor (cases.parity_fixed_iters): x within TOL_F32 = 5e-3 of the reference's QPSolver<float>
+    (float oracle); against the fp64 solution of the same float-valued problem x and z no further than 3x the float oracle's error
+    (or 5e-6, ~40 fp32 ulps: a maximum over 3-12 QPs is noisy), y no further than 8x with no floor on these small batches (the GPU test states 2.5x / 6x on batches of 32-512: tests/test_gpu_parity.py).
+    Default termination: status equal,
     iteration counts equal to the FP64 oracle's on at least 3 of 4 QPs (the stop test sits on an fp32-noisy residual)."""
     from sqp_solver_amd.problems import random_qp_batch
 
     for (n, m, b) in ((20, 40, 12), (50, 100, 6), (30, 60, 4), (56, 112, 3)):
-        ex, ey, ez = cases.parity_fixed_iters(make_wg_f32, n, m, b, iters=150, dtype=np.float32, f32_floor=1e-3)
-        assert ex < 5e-5 and ey < 1e-3, (n, m, ex, ey)
+        ex, ey, ez = cases.parity_fixed_iters(make_wg_f32, n, m, b, iters=150, dtype=np.float32, f32_floor=(5e-6, 0.0, 5e-6), f32_ratio=(3.0, 8.0, 3.0))
+        assert ex < 2e-5 and ey < 1e-3, (n, m, ex, ey)
     for (n, m, b) in ((20, 40, 12), (50, 100, 6)):
         P, q, A, l, u = random_qp_batch(b, n, m, seed=3, dtype=np.float32)
         s = make_wg_f32(n, m, b)
