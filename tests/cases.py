@@ -619,8 +619,7 @@ def uninitialized_and_numerical_issues(make, n=4, m=5, batch=3, **kw):
 
 def failing_pivots(make, n=8, m=12, batch=4, **kw):
     """a factorisation that fails AFTER the diagonal test: QP 1 has an indefinite S with a positive diagonal (documented difference:
-    the Schur form needs S positive definite — NUMERICAL_ISSUES here, include/sqp_hip.h), QP 2 a NaN below the diagonal of P (the
-    reference's LDLT fails as well); the other QPs of the batch are solved as if alone."""
+    the Schur form needs S positive definite — NUMERICAL_ISSUES here, include/sqp_hip.h), QP 2 a NaN below the diagonal of P; the other QPs of the batch are solved as if alone."""
     P, q, A, l, u = random_qp_batch(batch, n, m, seed=6)
     Pb = P.copy()
     big = 50.0 * (1.0 + np.abs(A[1]).sum(axis=0).max())  # beyond anything A'RA adds to the 2 x 2 block
@@ -633,9 +632,8 @@ def failing_pivots(make, n=8, m=12, batch=4, **kw):
     x, y, z, info = s.solution()
     assert info.status[1] == NUMERICAL_ISSUES and info.iter[1] == 0, (info.status, info.iter)
     assert info.status[2] == NUMERICAL_ISSUES and info.iter[2] == 0, (info.status, info.iter)
-    o = oracle.QPSolver()
-    o.setup(Pb[2], q[2], A[2], l[2], u[2])
-    assert o.info.status == NUMERICAL_ISSUES
+    # (the reference's LDLT reports a NaN below the diagonal only when it happens to land on a pivot test — Eigen's info() is about
+    # zero pivots — and iterates on NaNs otherwise; the device flags the QP in every case, which is the stricter reading)
     for b in [b for b in range(batch) if b not in (1, 2)]:
         ob = oracle.QPSolver()
         ob.settings.max_iter, ob.settings.check_termination = 30, 0
