@@ -183,8 +183,12 @@ struct WgLayout {
     static constexpr int NR = R * TW;  // padded n (rows of W)
     static_assert(NW == 0 || (NP <= NT && NR >= NP && NR <= NT && MP <= NT), "owners: lane t owns n-element t and m-element t");
     static constexpr int ev(int x) { return (x + 1) & ~1; }
-    static constexpr int TRp = ev(TR) + 2;  // row-gather stride per r    (w, y)
-    static constexpr int TWp = ev(TW) + 2;  // W-row gather stride per r  (y1)
+    // gather strides per r: an odd number of 16-byte units, so that the ds_read_b128 of the R lanes of a column group fall on distinct bank
+    // quads (an even number puts lanes r and r + 8 — or r + 4 with R = 8 — on the same ones: C2's TR = 5 at stride 8 read every operand
+    // at half rate, tools/xp/lds_model_wg.py)
+    static constexpr int gstride(int x) { return (ev(x) / 2) % 2 ? ev(x) : ev(x) + 2; }
+    static constexpr int TRp = gstride(TR);  // row-gather stride per r    (w, y)
+    static constexpr int TWp = gstride(TW);  // W-row gather stride per r  (y1)
     static constexpr int TCp = ev(TC);      // column-gather stride per c (b, x~, x)
     static constexpr int Rp = R + 2;        // staging stride per output for reductions over r
     static constexpr int Cp = C + 2;        // staging stride per output for reductions over c
@@ -195,7 +199,13 @@ struct WgLayout {
     static constexpr int O_WROW = O_COLV2 + C * TCp;       // [R][TWp]  n-vector in W-row-gather order    (y1)
     static constexpr int O_STAGE = ev(O_WROW + R * TWp);   // staging X: partials reduced over r  [NP][Rp]
     static constexpr int mx(int a, int b) { return a > b ? a : b; }
-    static constexpr int STAGE_X = NP * Rp;
+    // rows of staging X per column group: TC, or 4 where R = 8 and TC = 3 — a ds_write_b64 is served 16 lanes at a time, two column
+    // groups of 8 lanes then, whose rows must start 16 banks apart: 4 rows of Rp = 10 doubles do, 3 rows do not (C2: every stage-1 store
+    // was two-way conflicted)
+    static constexpr int XR = (R == 8 && TC == 3) ? 4 : TC;
+    static constexpr int xrow(int c, int k) { return XR * c + k; }          // row of tile column k of lane group c
+    static constexpr int xslot(int j) { return XR * (j % C) + j / C; }     // row of matrix column j
+    static constexpr int STAGE_X = C * XR * Rp;
     static constexpr int O_STAGE_Y = O_STAGE + STAGE_X;    // staging Y: partials reduced over c  [max(NR,MP)][Cp]
     static constexpr int STAGE_Y = mx(NR, MP) * Cp;
     // set-up scratch, aliasing the staging areas:  rho[MP] | rowbuf[NP+2] | sj[NP] | As[R][SSTR] | Wl[NP][SSTR]
@@ -319,7 +329,7 @@ struct WgKernel {
             for (int k = 0; k < TC; k++) pb[k] = wg_fma(at[s][k], w[s], pb[k]);
         T *st = lds + L::O_STAGE;
 #pragma unroll
-        for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = pb[k];
+        for (int k = 0; k < TC; k++) st[L::xrow(c, k) * L::Rp + r] = pb[k];
     }
     // A x : partial over my columns for my TR rows; staged for a reduction over c
     static __device__ __forceinline__ void stage_A(const T (&at)[TR][TC], const T (&x)[TC], T *lds, int r, int c) {
@@ -359,7 +369,7 @@ struct WgKernel {
             for (int k = 0; k < TC; k++) px[k] = wg_fma(wt[u][k], y[u], px[k]);
         T *st = lds + L::O_STAGE;
 #pragma unroll
-        for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = px[k];
+        for (int k = 0; k < TC; k++) st[L::xrow(c, k) * L::Rp + r] = px[k];
     }
     // The iteration's two stages with the W' tile (vt[u][k] = W[TC c + k][R u + r]): both products of a stage share the
     // reduction direction, so stage 1 stages ONE set of partial sums (W u and B'w accumulate into the same registers)
@@ -387,7 +397,7 @@ struct WgKernel {
                 if (!xzero<TX, STACK>(u, k)) pb[k] = wg_fma(vt[u][k], ur[u], pb[k]);
         T *st = lds + L::O_STAGE;
 #pragma unroll
-        for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rp + r] = pb[k];
+        for (int k = 0; k < TC; k++) st[L::xrow(c, k) * L::Rp + r] = pb[k];
     }
     //   stage 2:  z~[R s + r] = sum_k B[.][TC c + k] y1[TC c + k] ,  x~[R u + r] = sum_k W[TC c + k][.] y1[TC c + k]   (both over c)
     // STACK: the x~ partial sums continue the z~ array (one stacked (m+n)-vector of outputs, see run())
@@ -493,7 +503,7 @@ struct WgKernel {
     static __device__ __forceinline__ T reducef_over_c(const float *lf, int t) { return (T)wgf_sum<C>(lf + 2 * L::O_STAGE_Y + t * L::Cf); }
 
     // owner-side reductions (lane t owns output t)
-    static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? L::cslot(t) : 0) * L::Rp); }  // t = column index
+    static __device__ __forceinline__ T reduce_over_r(const T *lds, int t) { return wg_sum<R>(lds + L::O_STAGE + (t < L::NP ? L::xslot(t) : 0) * L::Rp); }  // t = column index
     static __device__ __forceinline__ T reduce_over_c(const T *lds, int t) { return wg_sum<C>(lds + L::O_STAGE_Y + t * L::Cp); }
 
     // ------------------------------------------------------------------ tile loads
@@ -680,7 +690,7 @@ struct WgKernel {
                     pz[s] = wg_fma(a0[s], xk, pz[s]);
                     pb = wg_fma(a0[s], y[s], pb);
                 }
-                stx[(TC * c + k) * L::Rp + r] = pb;
+                stx[L::xrow(c, k) * L::Rp + r] = pb;
             }
             if (k + 1 < TC) {
                 const T xk = xv[k + 1];
@@ -690,7 +700,7 @@ struct WgKernel {
                     pz[s] = wg_fma(a1[s], xk, pz[s]);
                     pb = wg_fma(a1[s], y[s], pb);
                 }
-                stx[(TC * c + k + 1) * L::Rp + r] = pb;
+                stx[L::xrow(c, k + 1) * L::Rp + r] = pb;
             }
         }
         T *sty = lds + L::O_STAGE_Y;
@@ -736,7 +746,7 @@ struct WgKernel {
     // read is coalesced — the factor's own access P[min(i,j) n + max(i,j)] (lower triangle only, qp.cpp:159-189) is a stride-n
     // gather for half of the tile (measured: ~20 k of the set-up's 191 k cycles waiting for it).  Returns false (nothing issued)
     // when the block is not 16-byte aligned; the factor then reads P from global memory as before.
-    static constexpr bool P_STAGED = MSET || L::P_STAGED;
+    static constexpr bool P_STAGED = MSET ? MS::PST : L::P_STAGED;
     static constexpr int O_PST = MSET ? MS::O_SB : L::O_PST;
     static __device__ __forceinline__ bool stage_P_async(const TIN *__restrict__ gP, int n, T *lds, int t) {
 #ifdef SQPH_NO_P_STAGE  // A/B experiment builds only
@@ -1137,7 +1147,7 @@ struct WgKernel {
                 load_A_tile(gA_f, n_f, m_f, r_f, c_f, at);  // the only read of A from global memory per factorisation
                 SQPH_STICK(0)
                 bool ok;
-                if constexpr (MSET) ok = MS::template factor<TIN, MS::O_SB, true>(gP_f, at, n_f, m_f, sigma, lds, t_f, p_staged SQPH_STICK_PASS);
+                if constexpr (MSET) ok = MS::template factor<TIN, MS::O_SB, MS::PST>(gP_f, at, n_f, m_f, sigma, lds, t_f, p_staged SQPH_STICK_PASS);
                 else ok = factor(gP_f, at, n_f, m_f, sigma, lds, t_f, r_f, c_f, wt, p_staged SQPH_STICK_PASS);
                 SQPH_STICK(4)
                 // the factor is kept for later solve() calls unless the host asked for a fused setup+solve without it
@@ -1286,8 +1296,11 @@ struct WgKernel {
                         // two lanes per output: lane r < TC sums partials 0..7, lane r + 8 partials 8..15 of output TC c + r, one DPP
                         // rotation inside the 16-lane row combines them — half the LDS reads and adds in the wave's instruction
                         // stream and a shorter chain (C3 shard fixed-200 2.49 -> 2.42 ms)
-                        const int o = r & 7, hh = r >> 3;
-                        const int sj = TC * c + o, j = L::col(c, o);  // slot and column of the output
+                        // (which lane of a pair takes which half alternates with r / 4 and c: the 16-lane groups a ds_read_b128 is served
+                        // in — lanes {0-3, 12-15, 20-27}, ... — then hold 14 different bank quads; with hh = r / 8 every read was two-way
+                        // conflicted, 11.4 % of the kernel's LDS cycles: tools/xp/lds_model_wg.py)
+                        const int o = r & 7, hh = F32 ? (r >> 3) : (((r >> 3) ^ (r >> 2) ^ c) & 1);
+                        const int sj = F32 ? TC * c + o : L::xrow(c, o), j = L::col(c, o);  // staging row and column of the output
                         if constexpr (F32) {
                             float part = (o < TC) ? wgf_sum<8>(lf + 2 * L::O_STAGE + sj * L::Rf + 8 * hh) : 0.0f;
                             part += xchg16<8>(part);
@@ -1299,7 +1312,7 @@ struct WgKernel {
                         }
                     } else
                     if (r < TC) {
-                        const int sj = TC * c + r, j = L::col(c, r);  // slot and column of the output
+                        const int sj = F32 ? TC * c + r : L::xrow(c, r), j = L::col(c, r);  // staging row and column of the output
                         if constexpr (F32) putf_colv2(lf, j, j < n ? wgf_sum<R>(lf + 2 * L::O_STAGE + sj * L::Rf) : 0.0f);
                         else put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + sj * L::Rp) : T(0));
                     }
@@ -1872,7 +1885,7 @@ struct WgKernel {
 #pragma unroll
                     for (int k = 0; k < NON; k++) {
                         const int j = t + GL * k;
-                        ATy[k] = j < n ? wg_sum<R>(lds + L::O_STAGE + L::cslot(j) * L::Rp) : T(0);
+                        ATy[k] = j < n ? wg_sum<R>(lds + L::O_STAGE + L::xslot(j) * L::Rp) : T(0);
                     }
                     wsync();
                     {
@@ -2014,7 +2027,9 @@ __global__ __launch_bounds__(64 * NW, WPE) void admm_wg_nocheck_kernel(KArgs<dou
 // waves per SIMD of the no-check instantiation where it can hold more than the shape's checking kernel: the C2 shape (one wave per QP)
 // fits four per SIMD without the check block — all 4,096 QPs of BASELINE configs[1] resident at once instead of 3,072 (0.345 -> 0.317 ms;
 // the checking kernel spills at that bound and stays at three: 0.78 against 0.84 ms under the reference's default settings)
-constexpr int wg_nocheck_wpe(int NW, int R, int C, int TR, int TC, int W) { return (NW == 1 && R == 8 && C == 8 && TR == 5 && TC == 3) ? 4 : W; }
+constexpr int wg_nocheck_wpe(int NW, int R, int C, int TR, int TC, int W) {
+    return (NW == 1 && R == 8 && C == 8 && TR == 5 && TC == 3) ? 4 : (NW == 4 && R == 16 && C == 16 && TR == 8 && TC == 4) ? 3 : W;
+}
 
 // the stacked operator (WgKernel::run<CHECKS, false, STACK = true>) for problems with m <= R (TR + TW - 1) - C TC (WgKernel::SOFF); instantiated in
 // wg_stack.hip only
@@ -2086,6 +2101,8 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 #ifdef SQPH_SLIM
 #ifdef SQPH_SLIM_C2  // ... plus the C2 shape
 #define SQPH_WG_SHAPES(X) X(1, 8, 8, 5, 3, 3, 3) X(2, 16, 8, 7, 7, 4, 2)
+#elif defined(SQPH_SLIM_W4)  // ... plus the four-wave 16 x 16 shape
+#define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2) X(4, 16, 16, 8, 4, 4, 2)
 #else
 #define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2)
 #endif

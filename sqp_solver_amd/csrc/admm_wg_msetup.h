@@ -39,8 +39,15 @@ struct MSetup {
     static constexpr int O_XS = L::ev(O_FLAG + 8);    // [NB][16][17]  a block of 16 rows of A by 16-column blocks; the L panel in the factorisation
     static constexpr int O_SB = O_XS + NB * BS;       // [NBLK][16][17] S, then L / E, finally W;  P is staged here first (natural n x n)
     static constexpr int O_TB = O_SB + NBLK * BS;     // [2][16][17]   the unscaled inverses of the current and the next diagonal block
-    static constexpr int END = L::mx(O_TB + 2 * BS, O_SB + L::NP * L::NP);
+    // P is staged (LDS-DMA) where its n x n block fits behind O_SB; where only the blocks fit (the four-wave 16 x 16 grid with n <= 64)
+    // the P phase reads it from global memory
+    static constexpr bool PST = O_SB + L::NP * L::NP <= L::O_QV;
+    static constexpr int END = L::mx(O_TB + 2 * BS, PST ? O_SB + L::NP * L::NP : 0);
+#ifdef SQPH_XP_NO_MSET4  // (experiment builds: the scalar set-up for the four-wave grid)
+    static constexpr bool ENABLED = NW == 2 && R == 16 && C == 4 * NW && L::NP <= 64 && END <= L::O_QV && (O_SB % 2) == 0;
+#else
     static constexpr bool ENABLED = NW >= 1 && R == 16 && C == 4 * NW && L::NP <= 64 && END <= L::O_QV && (O_SB % 2) == 0;
+#endif
 
     static __device__ __forceinline__ int blk(int I, int K) { return I * (I + 1) / 2 + K; }
     // wavefront index as a scalar (the compiler cannot tell that t >> 6 is uniform: without this every per-wave decision below

@@ -293,6 +293,7 @@ def test_wg_stacked_operator():
     cases.failing_pivots(make_wg_stack, n=50, m=100, batch=4)  # the MFMA set-up: the pivot flag of a diagonal block, NaN through the block products
     cases.failing_pivots(make_wg, n=8, m=12, batch=4)
     cases.failing_pivots(make_wg, n=20, m=40, batch=4)
+    cases.failing_pivots(make_wg, n=60, m=120, batch=3)  # the MFMA set-up of the four-wave grid (P read from global memory)
 
 
 def make_csr_dense(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):

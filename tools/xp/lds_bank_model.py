@@ -16,6 +16,10 @@ def cost(kind, addr):
         groups, mod, width = G_32, 64, 2
     elif kind == "read_b128":
         groups, mod, width = G_B128, 64, 4
+    elif kind == "write_b32":
+        groups, mod, width = G_32, 32, 1
+    elif kind == "read_b32":
+        groups, mod, width = G_32, 32, 1
     elif kind == "write_b64":
         groups, mod, width = G_16, 32, 2
     elif kind == "write_b128":
@@ -36,7 +40,7 @@ def cost(kind, addr):
 
 
 def ideal(kind):
-    return {"read_b64": 2, "read_b128": 4, "write_b64": 4, "write_b128": 8}[kind]
+    return {"read_b64": 2, "read_b128": 4, "write_b64": 4, "write_b128": 8, "write_b32": 2, "read_b32": 2}[kind]
 
 
 def cost_write2_b64(addr0, addr1):
