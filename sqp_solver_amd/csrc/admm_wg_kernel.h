@@ -249,7 +249,17 @@ struct WgLayout {
     static constexpr int TRf = odd16(r4(TR)), TWf = odd16(r4(TW)), TCf = r4(TC);
     static constexpr int Rf = r4(R) + 4, Cf = r4(C) + 4;           // staging strides (floats)
     static constexpr int TC2 = (TC + 1) / 2;                       // column pairs of a tile row
-    static constexpr bool F32_FITS = R * TRf <= 2 * R * TRp && R * TWf <= 2 * R * TWp && C * TCf <= 2 * C * TCp && NP * Rf <= 2 * STAGE_X &&
+    // rows of the float staging X.  The C3 grid (R = 16, C = 8, TC = 7): a ds_write_b32 is served 32 lanes at a time — the 16 lanes of an
+    // even column group and of the odd one next to it, whose rows must start 16 banks apart (rows 4 mod 8 apart at Rf = 20) — and the two
+    // ds_read_b128 of the y1 reduction 16 lanes at a time, 14 of them active, which need 14 different bank quads: the rows of an odd group
+    // follow the even group's seven in the order 3 4 5 6 - 0 1 2 (one row unused), and which lane of a pair sums which half of a row is
+    // y1_half_f().  Before: every store of the two stages and every read of the reduction two-way conflicted, 30 % of the kernel's LDS
+    // cycles (tools/xp/lds_model_wgf.py)
+    static constexpr bool XF_ROT = R == 16 && C == 8 && TC == 7;
+    static constexpr int xrowf(int c, int k) { return XF_ROT ? 15 * (c >> 1) + ((c & 1) ? 7 + ((k + 5) & 7) : k) : TC * c + k; }
+    static constexpr int y1_half_f(int r, int c) { return XF_ROT ? ((r >> 3) ^ ((((c & 1) ? 0x0f : 0x50) >> (r & 7)) & 1)) : (r >> 3); }
+    static constexpr int XROWSF = XF_ROT ? 15 * (C / 2) : NP;
+    static constexpr bool F32_FITS = R * TRf <= 2 * R * TRp && R * TWf <= 2 * R * TWp && C * TCf <= 2 * C * TCp && XROWSF * Rf <= 2 * STAGE_X &&
                                      mx(NR, MP) * Cf <= 2 * STAGE_Y && NR * Cf <= 2 * NR * Cp;
     // column distribution (cyclic over c): tile column k of lane group c is matrix column col(c, k); cslot(j) = its slot index
     static constexpr int col(int c, int k) { return C * k + c; }
@@ -470,7 +480,7 @@ struct WgKernel {
         }
         float *st = lf + 2 * L::O_STAGE;
 #pragma unroll
-        for (int k = 0; k < TC; k++) st[(TC * c + k) * L::Rf + r] = pb[k / 2][k & 1];
+        for (int k = 0; k < TC; k++) st[L::xrowf(c, k) * L::Rf + r] = pb[k / 2][k & 1];
     }
     template <int TX, bool STACK = false>
     static __device__ __forceinline__ void stage2_f(const sqph_f2 (&bt)[TR][L::TC2], const sqph_f2 (&vt)[TX][L::TC2], const float (&y1)[TC],
@@ -483,12 +493,15 @@ struct WgKernel {
         }
         float *sty = lf + 2 * L::O_STAGE_Y;
         float *stx = lf + (STACK ? 2 * L::O_STAGE_Y + R * TR * L::Cf : 2 * L::O_STX);
+        // position inside a row rotated by 2 (r / 8): the row stride is a multiple of 4 floats, so lanes r and r + 8 of a store would share
+        // banks; the owner sums the whole row, so the order is free
+        const int pos = R >= 16 ? ((c + 2 * (r >> 3)) & (C - 1)) : c;
 #pragma unroll
         for (int s = 0; s < TR; s++) {
             sqph_f2 acc = {0.0f, 0.0f};
 #pragma unroll
             for (int kp = 0; kp < L::TC2; kp++) acc = wgf_fma2(bt[s][kp], yp[kp], acc);
-            sty[(R * s + r) * L::Cf + c] = acc[0] + acc[1];
+            sty[(R * s + r) * L::Cf + pos] = acc[0] + acc[1];
         }
 #pragma unroll
         for (int u = 0; u < TX; u++) {
@@ -496,7 +509,7 @@ struct WgKernel {
 #pragma unroll
             for (int kp = 0; kp < L::TC2; kp++)
                 if (!xzero2<TX, STACK>(u, kp)) acc = wgf_fma2(vt[u][kp], yp[kp], acc);
-            stx[(R * u + r) * L::Cf + c] = acc[0] + acc[1];
+            stx[(R * u + r) * L::Cf + pos] = acc[0] + acc[1];
         }
     }
     static __device__ __forceinline__ T reducef_xt(const float *lf, int i) { return (T)wgf_sum<C>(lf + 2 * L::O_STX + i * L::Cf); }
@@ -1299,8 +1312,8 @@ struct WgKernel {
                         // (which lane of a pair takes which half alternates with r / 4 and c: the 16-lane groups a ds_read_b128 is served
                         // in — lanes {0-3, 12-15, 20-27}, ... — then hold 14 different bank quads; with hh = r / 8 every read was two-way
                         // conflicted, 11.4 % of the kernel's LDS cycles: tools/xp/lds_model_wg.py)
-                        const int o = r & 7, hh = F32 ? (r >> 3) : (((r >> 3) ^ (r >> 2) ^ c) & 1);
-                        const int sj = F32 ? TC * c + o : L::xrow(c, o), j = L::col(c, o);  // staging row and column of the output
+                        const int o = r & 7, hh = F32 ? L::y1_half_f(r, c) : (((r >> 3) ^ (r >> 2) ^ c) & 1);
+                        const int sj = F32 ? L::xrowf(c, o) : L::xrow(c, o), j = L::col(c, o);  // staging row and column of the output
                         if constexpr (F32) {
                             float part = (o < TC) ? wgf_sum<8>(lf + 2 * L::O_STAGE + sj * L::Rf + 8 * hh) : 0.0f;
                             part += xchg16<8>(part);
@@ -1312,7 +1325,7 @@ struct WgKernel {
                         }
                     } else
                     if (r < TC) {
-                        const int sj = F32 ? TC * c + r : L::xrow(c, r), j = L::col(c, r);  // staging row and column of the output
+                        const int sj = F32 ? L::xrowf(c, r) : L::xrow(c, r), j = L::col(c, r);  // staging row and column of the output
                         if constexpr (F32) putf_colv2(lf, j, j < n ? wgf_sum<R>(lf + 2 * L::O_STAGE + sj * L::Rf) : 0.0f);
                         else put_colv2(lds, j, j < n ? wg_sum<R>(lds + L::O_STAGE + sj * L::Rp) : T(0));
                     }
