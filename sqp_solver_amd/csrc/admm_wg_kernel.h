@@ -223,14 +223,23 @@ struct WgLayout {
     static constexpr int CH = (C + 1) / 2;  // W is staged half of its columns (CH column groups) at a time
     // P staged in LDS behind As while S = A'RA is accumulated (LDS-DMA issued ahead of the A tile's loads, see stage_P_async)
     static constexpr int O_PST = ev(O_AS + R * SSTR);
-    static constexpr int SETUP = O_WL + CH * TC * WSTR;
+    static constexpr int SETUP = O_AS + R * SSTR;  // (rounds 1-3 staged W behind As during the factorisation; the lower-triangle factor of round 4 does not)
     static constexpr int O_RED = O_STAGE + MP + 2 * NP + 16;  // workgroup max scratch (residual checks)
     static constexpr int STAGE = mx(STAGE_X + STAGE_Y, MP + 2 * NP + 16 + 8 * NW);
     // x~ partials of stage 2 ([R u + r][Cp]): a region of their own — stage 2 of a fast wave must not overwrite the stage-1
     // partials a slower wave of the workgroup is still reducing (there is no workgroup barrier between the two stages)
     // (the aliased region below the owners' constants is also made large enough to stage all of W for the W -> W' transposition)
-    static constexpr int O_AS2 = NP * WSTR;  // build_B: one block of R rows of A behind the staged W
-    static constexpr int O_STX = ev(mx(mx(O_STAGE + STAGE, SETUP), O_AS2 + R * SSTR - NR * Cp));
+    // The staged transposed copy of W (build_B_inplace, load_vt_lds): row j holds column j of W.  Padded form: NP rows of WSTR.  The
+    // 16 x 16 grids with 7 x 7 tiles (n <= 112) pack it — row j = C kj + cj keeps the entries W[C k + c][j] of the tile columns k >= kj
+    // only (the others are zero in every lane), k-major: wf_row(j) + C (k - kj) + c — 7,168 instead of 14,336 doubles, which is what
+    // lets two of these workgroups share a CU (they ran one wave per SIMD until round 4)
+    static constexpr bool WPACK = NW > 0 && R == 16 && C == 16 && TC == 7 && TW == 7;
+    static constexpr int wf_len(int kj) { return C * (TC - kj); }                                   // entries of a row of column block kj
+    static constexpr int wf_blk(int kj) { return C * C * (kj * TC - kj * (kj - 1) / 2); }           // first row of column block kj
+    static constexpr int WF_SIZE = WPACK ? wf_blk(TC) : NP * WSTR;
+    static constexpr int O_AS2 = WF_SIZE;  // build_B: one block of R rows of A behind the staged W
+    // (the set-up scratch and build_B's staging end below the owners' constants; the x~ staging region may lie inside them)
+    static constexpr int O_STX = ev(mx(O_STAGE + STAGE, mx(SETUP, O_AS2 + R * SSTR) - NR * Cp));
     // per-element constants of the owners (q, l, u): LDS instead of VGPRs, after everything the set-up may alias
     static constexpr int O_QV = ev(O_STX + NR * Cp);
     static constexpr int O_LOV = O_QV + NP;
@@ -574,6 +583,14 @@ struct WgKernel {
         // through As one block of R rows at a time (natural column order: As[r][j]); nothing goes through global memory.
         T *Wf = lds, *As = lds + L::O_AS2;
         wsync();  // the factorisation's scratch in this region is dead
+        if constexpr (L::WPACK) {
+            static_assert(!STACK, "the packed copy serves the padded operator");
+            // row j = C k + c (column block k, my column group), entry i = R u + r = C u + r of it: kept for u >= k only
+#pragma unroll
+            for (int u = 0; u < TW; u++)
+#pragma unroll
+                for (int k = 0; k <= u && k < TC; k++) Wf[L::wf_blk(k) + c * L::wf_len(k) + C * (u - k) + r] = wt[u][k];
+        } else {
 #pragma unroll
         for (int u = 0; u < TW; u++) {
             const int i = R * u + r;
@@ -581,6 +598,7 @@ struct WgKernel {
 #pragma unroll
                 for (int k = 0; k < TC; k++) Wf[L::col(c, k) * L::WSTR + L::slot(i)] = wt[u][k];
             }
+        }
         }
 #pragma unroll
         for (int s = 0; s < TR; s++) {
@@ -595,6 +613,18 @@ struct WgKernel {
             for (int kj = 0; kj < TC; kj++) {
                 const int cjn = n - C * kj < C ? n - C * kj : C;  // columns of this block inside the matrix (block-uniform)
                 const T *ap = As + r * L::SSTR + C * kj;
+                if constexpr (L::WPACK) {
+                    const T *wp = Wf + L::wf_blk(kj) + c;
+#pragma unroll 2
+                    for (int cj = 0; cj < cjn; cj++) {
+                        const T av = ap[cj];
+                        T wv[TC];
+#pragma unroll
+                        for (int k = kj; k < TC; k++) wv[k] = wp[cj * L::wf_len(kj) + C * (k - kj)];
+#pragma unroll
+                        for (int k = kj; k < TC; k++) acc[k] = wg_fma(av, wv[k], acc[k]);
+                    }
+                } else {
                 const T *wp = Wf + (C * kj) * L::WSTR + L::SLOT * c;
 #pragma unroll 2
                 for (int cj = 0; cj < cjn; cj++) {
@@ -603,6 +633,7 @@ struct WgKernel {
                     wg_read<L::SLOT>(wp + cj * L::WSTR, wv);  // the reads of the entries below kj are dead code
 #pragma unroll
                     for (int k = kj; k < TC; k++) acc[k] = wg_fma(av, wv[k], acc[k]);
+                }
                 }
             }
 #pragma unroll
@@ -627,6 +658,17 @@ struct WgKernel {
     // Entries that are structurally zero (L::vt_zero) are never read by the stages: left at zero here.
     static __device__ __forceinline__ void load_vt_lds(T *lds, int n, int r, int c, T (&vt)[TW][TC]) {
         wsync();
+        if constexpr (L::WPACK) {
+            // vt[u][k] = W[C k + c][R u + r]: row j = C u + r of the packed copy (column block u, R = C), entry C k + c of it, k >= u
+#pragma unroll
+            for (int u = 0; u < TW; u++)
+#pragma unroll
+                for (int k = 0; k < TC; k++) {
+                    T v = T(0);
+                    if (k >= u) v = lds[L::wf_blk(u) + r * L::wf_len(u) + C * (k - u) + c];
+                    vt[u][k] = (k >= u && R * u + r < n && L::col(c, k) < n) ? SQPH_TILE_QUANT(v) : T(0);
+                }
+        } else {
 #pragma unroll
         for (int u = 0; u < TW; u++) {
             const int jp = R * u + r;
@@ -634,6 +676,7 @@ struct WgKernel {
             wg_read<L::SLOT>(lds + (jp < L::NP ? jp : 0) * L::WSTR + L::SLOT * c, tmp);
 #pragma unroll
             for (int k = 0; k < TC; k++) vt[u][k] = (!L::vt_zero(u, k) && jp < n && L::col(c, k) < n) ? SQPH_TILE_QUANT(tmp[k]) : T(0);
+        }
         }
         wsync();
     }
@@ -2108,12 +2151,17 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 // problems with many more constraints than variables (m <= 224 with n <= 16 / 32 / 56): measured 4,096 x (10,150) 1.43 ms against
 // 7.73 ms in the 16 x 16 / 13 x 7 shape it fell into before, 4,096 x (50,150) 2.94 against 8.68 ms; the 64 x 8 grids (8 waves) carry
 // m <= 448 with n <= 32 / 56: 2,048 x (50,400) 3.98 ms against 45.5 ms in the generic kernel; the 16 x 16 grids with 2 / 4 / 8 tile rows
-// serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x; their 112 x 112
-// factor scratch takes > 80 KB of LDS, i.e. one workgroup per CU: WPE 1 is what they get, and what the register allocator is told)
+// serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x).  Until round 4
+// their staged copy of W (112 rows of 128 doubles) took 115 KB of LDS, i.e. one workgroup per CU, one wave per SIMD; packed to its lower
+// tile-triangle (WgLayout::WPACK) the four 16 x 16 / 7 x 7 shapes take 74-78 KB: two workgroups per CU, WPE 2 — 2,048 x (100,100)
+// 2.92 -> 1.86 ms, (100,30) 2.11 -> 1.29.  The 13-row shape stays at WPE 1: bound to 256 registers (it uses the AGPRs as spill space
+// at one wave per SIMD) it spills into the loop, 2,048 x (100,200) 4.05 -> 8.4 ms)
 // (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
 #ifdef SQPH_SLIM
 #ifdef SQPH_SLIM_C2  // ... plus the C2 shape
 #define SQPH_WG_SHAPES(X) X(1, 8, 8, 5, 3, 3, 3) X(2, 16, 8, 7, 7, 4, 2)
+#elif defined(SQPH_SLIM_SHAPES)  // ... or a list given on the command line: -D'SQPH_SLIM_SHAPES(X)=X(4,32,8,7,4,1,3) X(...)'
+#define SQPH_WG_SHAPES(X) SQPH_SLIM_SHAPES(X)
 #elif defined(SQPH_SLIM_W4)  // ... plus the four-wave 16 x 16 shape
 #define SQPH_WG_SHAPES(X) X(2, 16, 8, 7, 7, 4, 2) X(4, 16, 16, 8, 4, 4, 2)
 #else
@@ -2131,9 +2179,9 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
     X(4, 32, 8, 7, 2, 1, 4)      \
     X(4, 32, 8, 7, 4, 1, 3)      \
     X(4, 32, 8, 7, 7, 2, 2)      \
-    X(4, 16, 16, 2, 7, 7, 1)     \
-    X(4, 16, 16, 4, 7, 7, 1)     \
-    X(4, 16, 16, 8, 7, 7, 1)     \
+    X(4, 16, 16, 2, 7, 7, 2)     \
+    X(4, 16, 16, 4, 7, 7, 2)     \
+    X(4, 16, 16, 8, 7, 7, 2)     \
     X(4, 16, 16, 13, 7, 7, 1)    \
     X(8, 64, 8, 7, 4, 1, 2)      \
     X(8, 64, 8, 7, 7, 1, 2)
