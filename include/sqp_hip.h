@@ -250,7 +250,7 @@ int sqph_gather_fetch(sqph_gather *g, int dtype, void *x, void *y, sqph_info *in
 /* Wait for every posted copy and expose the device buffers (valid until sqph_gather_destroy). */
 int sqph_gather_device_ptrs(sqph_gather *g, void **x, void **y, sqph_info **info);
 
-/* Name of the kernel variant the last launch used ("generic_w1", "tile_13x7", ...). */
+/* Name of the kernel variant the last launch used ("generic_w1", "wg2_16x8_7x7s_w2", "lane_2x3_exact", "csr_t7", ...). */
 const char *sqph_kernel_name(const sqph_solver *s);
 /* Last launch duration helpers: records HIP events around every launch when enabled. */
 int sqph_enable_timing(sqph_solver *s, int on);

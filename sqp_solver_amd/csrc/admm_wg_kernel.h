@@ -2154,8 +2154,10 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 // serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x).  Until round 4
 // their staged copy of W (112 rows of 128 doubles) took 115 KB of LDS, i.e. one workgroup per CU, one wave per SIMD; packed to its lower
 // tile-triangle (WgLayout::WPACK) the four 16 x 16 / 7 x 7 shapes take 74-78 KB: two workgroups per CU, WPE 2 — 2,048 x (100,100)
-// 2.92 -> 1.86 ms, (100,30) 2.11 -> 1.29.  The 13-row shape stays at WPE 1: bound to 256 registers (it uses the AGPRs as spill space
-// at one wave per SIMD) it spills into the loop, 2,048 x (100,200) 4.05 -> 8.4 ms)
+// 2.92 -> 1.86 ms, (100,30) 2.11 -> 1.29.  m <= 224 with 56 < n <= 112 takes a 32 x 16 grid of eight waves (7 x 7 + 4 x 7 doubles of
+// tiles per lane, two waves per SIMD) since round 4: the four-wave 16 x 16 grid with 13 x 7 + 7 x 7 doubles per lane that served it
+// ran one wave per SIMD with the AGPRs as spill space (bound to 256 registers it spilled into the loop, 4.05 -> 8.4 ms):
+// 2,048 x (100,200) 4.01 -> 3.65 ms, under the default settings 4.33 -> 3.06)
 // (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
 #ifdef SQPH_SLIM
 #ifdef SQPH_SLIM_C2  // ... plus the C2 shape
@@ -2182,7 +2184,7 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
     X(4, 16, 16, 2, 7, 7, 2)     \
     X(4, 16, 16, 4, 7, 7, 2)     \
     X(4, 16, 16, 8, 7, 7, 2)     \
-    X(4, 16, 16, 13, 7, 7, 1)    \
+    X(8, 32, 16, 7, 7, 4, 2)     \
     X(8, 64, 8, 7, 4, 1, 2)      \
     X(8, 64, 8, 7, 7, 1, 2)
 

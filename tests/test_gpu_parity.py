@@ -97,12 +97,14 @@ def test_setup_solve_reuse_after_failed_setup(n, m):
 
 
 def test_four_wave_shapes():
-    """m <= 208, n <= 112: four wavefronts per QP (13 x 7 + 7 x 7 doubles of tiles per lane, one wave per SIMD)"""
+    """m <= 224, 56 < n <= 112: the 32 x 16 lane grid, eight wavefronts per QP (7 x 7 + 4 x 7 doubles of tiles per lane)"""
     s = make_gpu(100, 200, 2)
     s.setup_solve(*[a[:2] for a in cases.random_qp_batch(2, 100, 200, seed=3)])
-    assert s.kernel_name().startswith("wg4_16x16_13x7"), s.kernel_name()
+    assert s.kernel_name().startswith("wg8_32x16_7x7"), s.kernel_name()
     cases.parity_fixed_iters(make_gpu, 100, 200, 8, iters=60)
     cases.parity_fixed_iters(make_gpu, 112, 208, 4, iters=40)
+    cases.parity_fixed_iters(make_gpu, 112, 224, 3, iters=40)
+    cases.failing_pivots(make_gpu, n=100, m=200, batch=3)
     cases.parity_termination(make_gpu, 90, 180, 6, adaptive=True)
 
 

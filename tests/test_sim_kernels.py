@@ -154,7 +154,7 @@ def test_g16_state_paths():
 
 
 def test_wg_four_wave_large_tile_shape():
-    """the m <= 208, n <= 112 shape (4 waves, 13 x 7 tiles) under the emulator"""
+    """the m <= 224, 56 < n <= 112 shape (32 x 16 lanes, eight waves) under the emulator"""
     cases.parity_fixed_iters(lambda n, m, b, **kw: simlib.SimSolverBatch(n, m, b, variant=simlib.WG), 70, 150, 1, iters=25)
 
 
