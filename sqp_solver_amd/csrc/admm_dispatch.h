@@ -89,7 +89,7 @@ inline int wg_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const 
     constexpr bool no_stack = false;
 #endif
     // problems whose first fitting shape is the two-wave 16 x 8 grid and whose m leaves room for W' inside ten stacked tile rows (wg_stack.hip)
-    if (!no_stack && skip == 0 && !always_checks && !(a.m <= 64 && a.n <= 32)) {
+    if (!no_stack && skip == 0 && !always_checks && !(a.m <= 128 && a.n <= 32)) {  // (n <= 32: the one-wave grids and the 16 x 8 / 8 x 4 grid come first)
         const int rc = wgs_try_launch<TIN>(a, stream, name);
         if (rc != 0) return rc;
     }

@@ -2158,6 +2158,9 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 // tiles per lane, two waves per SIMD) since round 4: the four-wave 16 x 16 grid with 13 x 7 + 7 x 7 doubles per lane that served it
 // ran one wave per SIMD with the AGPRs as spill space (bound to 256 registers it spilled into the loop, 4.05 -> 8.4 ms):
 // 2,048 x (100,200) 4.01 -> 3.65 ms, under the default settings 4.33 -> 3.06)
+// n <= 32 with 64 < m <= 128 has a 16 x 8 grid of its own since round 4 (8 x 4 + 2 x 4 doubles of tiles per lane, three waves per SIMD,
+// MFMA set-up): until then it ran in the C3 grid padded to 56 columns or, beyond m = 112, in the four-wave 16 x 16 grid —
+// 4,096 x (24,96) 1.11 -> 0.75 ms, 4,096 x (32,128) ~1.5 -> 0.79 ms (tools/xp/shape_sweep.py found the gap)
 // (SQPH_SLIM: experiment builds with the C3 shape only — seconds instead of minutes to compile; never shipped)
 #ifdef SQPH_SLIM
 #ifdef SQPH_SLIM_C2  // ... plus the C2 shape
@@ -2176,6 +2179,7 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
     X(1, 8, 8, 3, 2, 2, 4)       \
     X(1, 8, 8, 5, 3, 3, 3)       \
     X(1, 8, 8, 8, 4, 4, 2)       \
+    X(2, 16, 8, 8, 4, 2, 3)      \
     X(2, 16, 8, 7, 7, 4, 2)      \
     X(4, 16, 16, 8, 4, 4, 2)     \
     X(4, 32, 8, 7, 2, 1, 4)      \

@@ -635,7 +635,7 @@ def test_api_sequence_fuzz_csr(n, m, batch):
     print(n, m, sorted(seen))
 
 
-@pytest.mark.parametrize("n,m", [(4, 4), (8, 12), (12, 24), (16, 24), (24, 40), (32, 64), (56, 112), (64, 128), (16, 224), (32, 224), (56, 224), (112, 32), (112, 64), (112, 128), (112, 208), (32, 448),
+@pytest.mark.parametrize("n,m", [(4, 4), (8, 12), (12, 24), (16, 24), (24, 40), (32, 64), (24, 96), (32, 128), (56, 112), (64, 128), (16, 224), (32, 224), (56, 224), (112, 32), (112, 64), (112, 128), (112, 208), (32, 448),
                                  (56, 448), (113, 209), (57, 449)])
 def test_api_sequence_fuzz_at_kernel_shape_limits(n, m):
     """the largest (n, m) each compiled kernel shape takes (and one beyond the last: the fallback), through the random call sequences"""

@@ -61,7 +61,7 @@ def test_wg_reference_cases(case):
     case(make_wg)
 
 
-@pytest.mark.parametrize("n,m", [(2, 3), (5, 7), (16, 24), (20, 40), (32, 64), (50, 100), (56, 112), (64, 128), (33, 9), (64, 120)])
+@pytest.mark.parametrize("n,m", [(2, 3), (5, 7), (16, 24), (20, 40), (32, 64), (24, 96), (32, 128), (50, 100), (56, 112), (64, 128), (33, 9), (64, 120)])
 def test_wg_parity_fixed(n, m):
     cases.parity_fixed_iters(make_wg, n, m, 2, iters=60 if n > 32 else 150)
 
