@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch, bench
 from sqp_solver_amd import QPSolverBatch
 from sqp_solver_amd.problems import random_qp_batch_torch
-n, m, B = 50, 100, 8192
+n, m, B = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (50, 100, 8192)
 P, q, A, l, u = random_qp_batch_torch(B, n, m, seed=0, dtype=torch.float64, device=torch.device("cuda:0"))
 for mode in ("default", "sqp"):
     s = QPSolverBatch(n, m, B)
