@@ -108,6 +108,17 @@ def test_four_wave_shapes():
     cases.parity_termination(make_gpu, 90, 180, 6, adaptive=True)
 
 
+def test_grid_selection():
+    """the lane grid each shape region takes (first fit in SQPH_WG_SHAPES; the stacked operator where m leaves room for W')"""
+    for (n, m, name) in ((20, 40, "wg1_8x8_5x3"), (24, 96, "wg2_16x8_8x4_w3"), (32, 128, "wg2_16x8_8x4_w3"), (50, 100, "wg2_16x8_7x7s"), (56, 112, "wg2_16x8_7x7_"),
+                         (60, 120, "wg4_16x16_8x4"), (100, 30, "wg4_16x16_2x7_w2"), (100, 100, "wg4_16x16_8x7_w2"), (100, 200, "wg8_32x16_7x7"), (50, 200, "wg4_32x8_7x7"),
+                         (50, 400, "wg8_64x8_7x7"), (130, 150, "cud_t7")):
+        s = make_gpu(n, m, 2)
+        s.settings.max_iter, s.settings.check_termination = 5, 0
+        s.setup_solve(*[a[:2] for a in cases.random_qp_batch(2, n, m, seed=3)])
+        assert s.kernel_name().startswith(name), (n, m, s.kernel_name())
+
+
 def test_dense_shapes_beyond_the_register_tiled_kernels():
     """112 < n <= 224 (or m beyond the tiled shapes' rows), m <= 512: the CU-wide kernel in its dense-A mode (csr_dense.hip: W in the
     CU's registers, A streamed from global memory twice per iteration) — fixed iterations, termination with adaptive rho, the
