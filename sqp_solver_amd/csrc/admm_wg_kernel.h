@@ -232,21 +232,30 @@ struct WgLayout {
     // The staged transposed copy of W (build_B_inplace, load_vt_lds): row j holds column j of W.  Padded form: NP rows of WSTR.  The
     // 16 x 16 grids with 7 x 7 tiles (n <= 112) pack it — row j = C kj + cj keeps the entries W[C k + c][j] of the tile columns k >= kj
     // only (the others are zero in every lane), k-major: wf_row(j) + C (k - kj) + c — 7,168 instead of 14,336 doubles, which is what
-    // lets two of these workgroups share a CU (they ran one wave per SIMD until round 4)
+    // lets two of these workgroups share a CU (they ran one wave per SIMD until round 4).  (Since the end of round 4 these grids take
+    // the MFMA set-up — MSX below — whose blocks serve build_B and the W' tile; this form is what they fall back to without it.)
     static constexpr bool WPACK = NW > 0 && R == 16 && C == 16 && TC == 7 && TW == 7;
     static constexpr int wf_len(int kj) { return C * (TC - kj); }                                   // entries of a row of column block kj
     static constexpr int wf_blk(int kj) { return C * C * (kj * TC - kj * (kj - 1) / 2); }           // first row of column block kj
     static constexpr int WF_SIZE = WPACK ? wf_blk(TC) : NP * WSTR;
     static constexpr int O_AS2 = WF_SIZE;  // build_B: one block of R rows of A behind the staged W
+    // The 16 x 16 / 7 x 7 grids with m <= 128 run their set-up on the MFMA (admm_wg_msetup.h) with seven block columns in unpadded,
+    // swizzled 16 x 16 blocks: rho / diagonal / flags, 7 staging blocks, 28 lower blocks, 2 diagonal-block buffers
+#ifdef SQPH_NO_MSX  // A/B experiment builds: these grids with the scalar set-up and the packed staged copy of W (WPACK)
+    static constexpr bool MSX = false;
+#else
+    static constexpr bool MSX = NW == 4 && R == 16 && C == 16 && TC == 7 && TW == 7 && TR <= 8;
+#endif
+    static constexpr int MSX_END = ev(MP + 16 * 7 + 8) + (7 + 28 + 2) * 256;
     // (the set-up scratch and build_B's staging end below the owners' constants; the x~ staging region may lie inside them)
-    static constexpr int O_STX = ev(mx(O_STAGE + STAGE, mx(SETUP, O_AS2 + R * SSTR) - NR * Cp));
+    static constexpr int O_STX = ev(mx(O_STAGE + STAGE, (MSX ? MSX_END : mx(SETUP, O_AS2 + R * SSTR)) - NR * Cp));
     // per-element constants of the owners (q, l, u): LDS instead of VGPRs, after everything the set-up may alias
     static constexpr int O_QV = ev(O_STX + NR * Cp);
     static constexpr int O_LOV = O_QV + NP;
     static constexpr int O_UPV = O_LOV + MP;
     static constexpr int O_RINV = O_UPV + MP;  // 1/rho of the owned constraint (changes only at a refactorisation)
     static constexpr int TOTAL = ev(O_RINV + MP);
-    static_assert(O_AS2 + R * SSTR <= O_QV, "build_B stages all of W and a block of A rows in [0, O_QV)");
+    static_assert(MSX || O_AS2 + R * SSTR <= O_QV, "build_B stages all of W and a block of A rows in [0, O_QV)");
     // the workgroup kernels whose scratch has room for an n x n block of doubles take P through LDS
     static constexpr bool P_STAGED = NW > 0 && O_PST + NP * NP <= O_QV;
     // fp32-product variant: the same regions viewed as floats (float offset = 2 x the double offset), rows padded to 16 bytes
@@ -2154,7 +2163,8 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 // serve 56 < n <= 112 with m <= 32 / 64 / 128 (fewer products per iteration than the 13-row shape: 1.95x / 1.7x / 1.36x).  Until round 4
 // their staged copy of W (112 rows of 128 doubles) took 115 KB of LDS, i.e. one workgroup per CU, one wave per SIMD; packed to its lower
 // tile-triangle (WgLayout::WPACK) the four 16 x 16 / 7 x 7 shapes take 74-78 KB: two workgroups per CU, WPE 2 — 2,048 x (100,100)
-// 2.92 -> 1.86 ms, (100,30) 2.11 -> 1.29.  m <= 224 with 56 < n <= 112 takes a 32 x 16 grid of eight waves (7 x 7 + 4 x 7 doubles of
+// 2.92 -> 1.86 ms, (100,30) 2.11 -> 1.29 — and 1.58 / 1.14 ms with the MFMA set-up in swizzled blocks that replaced the packed copy at
+// the end of the round (WgLayout::MSX, admm_wg_msetup.h: 81.7 KB, still two per CU).  m <= 224 with 56 < n <= 112 takes a 32 x 16 grid of eight waves (7 x 7 + 4 x 7 doubles of
 // tiles per lane, two waves per SIMD) since round 4: the four-wave 16 x 16 grid with 13 x 7 + 7 x 7 doubles per lane that served it
 // ran one wave per SIMD with the AGPRs as spill space (bound to 256 registers it spilled into the loop, 4.05 -> 8.4 ms):
 // 2,048 x (100,200) 4.01 -> 3.65 ms, under the default settings 4.33 -> 3.06)

@@ -11,8 +11,8 @@
 // the elimination into ceil(n/16) block steps: a 16 x 16 diagonal block is eliminated inside one wavefront (every lane a column,
 // pivot row and multipliers by DPP row broadcast: no LDS, no barrier), everything off the diagonal is 16 x 16 x 16 block products.
 //
-// Layouts.  A 16 x 16 block is stored row-major with rows padded to 17 doubles (BS = 272): the four access patterns below are
-// (nearly) bank-conflict free with it.  Lower blocks (I >= K) only, block (I, K) at index I (I + 1) / 2 + K.
+// Layouts.  A 16 x 16 block is stored row-major with rows padded to 17 doubles (BS = 272; unpadded and XOR-swizzled where NB > 4, see
+// SWZ): the four access patterns below are (nearly) bank-conflict free with it.  Lower blocks (I >= K) only, block (I, K) at index I (I + 1) / 2 + K.
 //     opN(blk, kq): element (lr, 4 kq + lq)   — A-operand X[i][k];  B-operand of X Y' (Y[j][k])
 //     opT(blk, kq): element (4 kq + lq, lr)   — B-operand of X Y  (Y[k][j]);  A-operand of X' Y
 //     D layout    : lane holds (lq + 4 e, lr), e < 4            with lr = lane & 15, lq = lane >> 4
@@ -29,7 +29,13 @@ struct MSetup {
     static constexpr int NT = L::NT;
     static constexpr int NB = (L::NP + 15) / 16;      // 16-column blocks of an n x n matrix
     static constexpr int NBLK = NB * (NB + 1) / 2;    // lower blocks
-    static constexpr int BS = 16 * 17;                // doubles per block
+    // seven block columns (56 < n <= 112, the 16 x 16 / 7 x 7 grids): the 28 + 7 + 2 padded blocks would take 10,064 doubles and one of
+    // the two workgroups a CU holds; there the rows are 16 doubles and column j of row i sits at j ^ i (the same four access patterns
+    // are conflict-free: a group of lanes reads one or two rows, the XOR permutes inside a row and rows of different parity lie in
+    // different bank halves) — a few address instructions more per access, 9,720 doubles
+    static constexpr bool SWZ = NB > 4;
+    static constexpr int BS = SWZ ? 256 : 16 * 17;    // doubles per block
+    static __device__ __forceinline__ int ix(int i, int j) { return SWZ ? i * 16 + (j ^ i) : i * 17 + j; }  // element (i, j) of a block
     static constexpr int NQ = (NBLK + (NW > 0 ? NW : 1) - 1) / (NW > 0 ? NW : 1);  // S blocks accumulated per wavefront
     static constexpr int NJQ = (TC + 3) / 4;          // 4-column groups of the B tile = accumulators of build_B
     // LDS map (doubles), all of it inside the set-up scratch [0, L::O_QV)
@@ -46,8 +52,9 @@ struct MSetup {
 #ifdef SQPH_XP_NO_MSET4  // (experiment builds: the scalar set-up for the four-wave grid)
     static constexpr bool ENABLED = NW == 2 && R == 16 && C == 4 * NW && L::NP <= 64 && END <= L::O_QV && (O_SB % 2) == 0;
 #else
-    static constexpr bool ENABLED = NW >= 1 && R == 16 && C == 4 * NW && L::NP <= 64 && END <= L::O_QV && (O_SB % 2) == 0;
+    static constexpr bool ENABLED = NW >= 1 && R == 16 && C == 4 * NW && (L::NP <= 64 || L::MSX) && END <= L::O_QV && (O_SB % 2) == 0;
 #endif
+    static_assert(!L::MSX || ENABLED, "WgLayout sized the set-up scratch of this grid for the MFMA set-up");
 
     static __device__ __forceinline__ int blk(int I, int K) { return I * (I + 1) / 2 + K; }
     // wavefront index as a scalar (the compiler cannot tell that t >> 6 is uniform: without this every per-wave decision below
@@ -82,20 +89,20 @@ struct MSetup {
         return y;
 #endif
     }
-    static __device__ __forceinline__ T opN(const T *b, int kq, int lr, int lq) { return b[lr * 17 + 4 * kq + lq]; }
-    static __device__ __forceinline__ T opT(const T *b, int kq, int lr, int lq) { return b[(4 * kq + lq) * 17 + lr]; }
+    static __device__ __forceinline__ T opN(const T *b, int kq, int lr, int lq) { return b[ix(lr, 4 * kq + lq)]; }
+    static __device__ __forceinline__ T opT(const T *b, int kq, int lr, int lq) { return b[ix(4 * kq + lq, lr)]; }
     static __device__ __forceinline__ void ldD(const T *b, int lr, int lq, sqph_acc4 &a) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) a.v[e] = b[(lq + 4 * e) * 17 + lr];
+        for (int e = 0; e < 4; e++) a.v[e] = b[ix(lq + 4 * e, lr)];
     }
     static __device__ __forceinline__ void stD(T *b, int lr, int lq, const sqph_acc4 &a) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) b[(lq + 4 * e) * 17 + lr] = a.v[e];
+        for (int e = 0; e < 4; e++) b[ix(lq + 4 * e, lr)] = a.v[e];
     }
     // element (i, j) of the lower triangular W held in SB (zero above the diagonal and beyond n)
     static __device__ __forceinline__ T Wget(const T *SB, int i, int j, int n) {
         const bool in = i < n && j < n && (i >> 4) >= (j >> 4);
-        const int a = blk(i >> 4, in ? (j >> 4) : 0) * BS + (i & 15) * 17 + (j & 15);
+        const int a = blk(i >> 4, in ? (j >> 4) : 0) * BS + ix(i & 15, j & 15);
         const T v = SB[in ? a : 0];
         return in ? v : T(0);
     }
@@ -225,7 +232,7 @@ struct MSetup {
         const int j = l & 15;
         T M[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) M[i] = Sjj[i * 17 + j];
+        for (int i = 0; i < 16; i++) M[i] = Sjj[ix(i, j)];
         T mypiv = T(1);
         bool bad = false;
         gj_steps<0>(M, j, mypiv, bad);
@@ -234,8 +241,8 @@ struct MSetup {
         const T dj = djp[j];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            TB[i * 17 + j] = M[i];         // unscaled: operand of this step's panel products
-            Sjj[i * 17 + j] = M[i] * dj;   // W_JJ = Winv_JJ D_J^-1/2 (columns)
+            TB[ix(i, j)] = M[i];           // unscaled: operand of this step's panel products
+            Sjj[ix(i, j)] = M[i] * dj;     // W_JJ = Winv_JJ D_J^-1/2 (columns)
         }
         if (bad) flag[1] = T(1);
     }
@@ -269,14 +276,14 @@ struct MSetup {
         const T *xa[NQ], *xb[NQ];  // my element of the k-step's first row in the A-operand / B-operand column block of accumulator q
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            xa[q] = XS + bI[q] * BS + lq * 17 + lr;
-            xb[q] = XS + bJ[q] * BS + lq * 17 + lr;
+            xa[q] = XS + bI[q] * BS + (SWZ ? 0 : lq * 17 + lr);  // (swizzled blocks: the element is found per k-step)
+            xb[q] = XS + bJ[q] * BS + (SWZ ? 0 : lq * 17 + lr);
         }
         T *xw[TC];  // where my TC entries of a tile row go in the staged block
 #pragma unroll
         for (int k = 0; k < TC; k++) {
             const int j = L::col(c, k);
-            xw[k] = XS + (j >> 4) * BS + r * 17 + (j & 15);
+            xw[k] = XS + (j >> 4) * BS + ix(r, j & 15);
         }
         constexpr bool ALLV = NBLK % NW == 0;  // every wavefront has NQ blocks: no per-block test
 #pragma unroll
@@ -293,8 +300,8 @@ struct MSetup {
                     T av[NQ], bw[NQ];
 #pragma unroll
                     for (int q = 0; q < NQ; q++) {
-                        av[q] = xa[q][4 * kq * 17];
-                        bw[q] = xb[q][4 * kq * 17];
+                        av[q] = xa[q][SWZ ? ix(lq + 4 * kq, lr) : 4 * kq * 17];
+                        bw[q] = xb[q][SWZ ? ix(lq + 4 * kq, lr) : 4 * kq * 17];
                     }
                     const T rk = rho_l[R * s + 4 * kq + lq];
 #pragma unroll
@@ -371,7 +378,7 @@ struct MSetup {
                 const T dc = sj[16 * bJ[q] + lr];
                 T *b = SB + (wave + NW * q) * BS;
 #pragma unroll
-                for (int e = 0; e < 4; e++) b[(lq + 4 * e) * 17 + lr] = acc[q].v[e] * sj[16 * bI[q] + lq + 4 * e] * dc;
+                for (int e = 0; e < 4; e++) b[ix(lq + 4 * e, lr)] = acc[q].v[e] * sj[16 * bI[q] + lq + 4 * e] * dc;
             }
         }
         SQPH_STICK(2)
@@ -495,9 +502,10 @@ struct MSetup {
             const bool in = 4 * q + (lr >> 2) < TC && cw < n;
 #pragma unroll
             for (int jb = 0; jb < NB; jb++)
-                wa[q][jb] = (in && (cw >> 4) >= jb) ? SB + blk(cw >> 4, jb) * BS + (cw & 15) * 17 + lq : zrow + lq;
+                wa[q][jb] = (in && (cw >> 4) >= jb) ? SB + blk(cw >> 4, jb) * BS + (SWZ ? (cw & 15) * 16 : (cw & 15) * 17 + lq) : zrow + (SWZ ? 0 : lq);
         }
-        const T *xv = XS + lr * 17 + lq;
+        const int cwlo = (C * (lr >> 2) + 4 * wave + (lr & 3)) & 15;  // my W row inside its block (the same for every q: C is a multiple of 16 or the rows of a q differ by C * 4)
+        const T *xv = XS + (SWZ ? 0 : lr * 17 + lq);
 #pragma unroll
         for (int s = 0; s < TR; s++) {
             if (R * s < m) {
@@ -505,7 +513,7 @@ struct MSetup {
 #pragma unroll
                 for (int k = 0; k < TC; k++) {
                     const int j = L::col(c, k);
-                    XS[(j >> 4) * BS + r * 17 + (j & 15)] = at[s][k];
+                    XS[(j >> 4) * BS + ix(r, j & 15)] = at[s][k];
                 }
                 __syncthreads();
 #pragma unroll
@@ -519,8 +527,8 @@ struct MSetup {
 #pragma unroll
                     for (int ks = 0; ks < KEND / 4; ks++) {
                         if (4 * ks < kend) {
-                            wv[ks] = wa[q][ks >> 2][(4 * ks) & 15];
-                            av[ks] = xv[(ks >> 2) * BS + ((4 * ks) & 15)];
+                            wv[ks] = wa[q][ks >> 2][SWZ ? ((((4 * ks) & 15) + lq) ^ cwlo) : ((4 * ks) & 15)];
+                            av[ks] = xv[(ks >> 2) * BS + (SWZ ? ix(lr, ((4 * ks) & 15) + lq) : ((4 * ks) & 15))];
                         }
                     }
 #pragma unroll
@@ -574,7 +582,7 @@ struct MSetup {
             while ((I + 1) * (I + 2) / 2 <= b) I++;
             const int K = b - I * (I + 1) / 2;
             const int i = 16 * I + ii, j = 16 * K + jj;
-            SB[b * BS + ii * 17 + jj] = (i < n && j < n && i >= j) ? gW[(long)j * n + i] : T(0);
+            SB[b * BS + ix(ii, jj)] = (i < n && j < n && i >= j) ? gW[(long)j * n + i] : T(0);
         }
     }
 };

@@ -70,14 +70,14 @@ def test_state_paths(make):
     cases.warm_start_and_resolve(make)
     cases.set_state_warm_start(make)
     cases.uninitialized_and_numerical_issues(make)
-    for (n, m) in ((2, 3), (8, 12), (20, 40), (50, 100), (56, 112), (60, 120), (64, 128), (100, 200)):  # every kernel family's factorisation, the MFMA set-up among them
+    for (n, m) in ((2, 3), (8, 12), (20, 40), (50, 100), (56, 112), (60, 120), (64, 128), (100, 100), (112, 128), (100, 200)):  # every kernel family's factorisation, the MFMA set-up among them (4, 4 and 7 block columns)
         cases.failing_pivots(make, n=n, m=m, batch=5)
     cases.shared_matrices(make)
     cases.edge_shapes(make)
 
 
 @pytest.mark.parametrize("make", MAKERS, ids=IDS)
-@pytest.mark.parametrize("n,m", [(2, 3), (8, 12), (20, 40), (50, 100), (60, 120), (100, 200)])
+@pytest.mark.parametrize("n,m", [(2, 3), (8, 12), (20, 40), (50, 100), (60, 120), (100, 100), (100, 200)])
 def test_fused_call_then_solve(n, m, make):
     """a fused setup_solve keeps no factor by default; the following solve() rebuilds it (every kernel family)"""
     cases.fused_then_solve(make, n=n, m=m, batch=5)

@@ -294,6 +294,7 @@ def test_wg_stacked_operator():
     cases.failing_pivots(make_wg, n=8, m=12, batch=4)
     cases.failing_pivots(make_wg, n=20, m=40, batch=4)
     cases.failing_pivots(make_wg, n=60, m=120, batch=3)  # the MFMA set-up of the four-wave grid (P read from global memory)
+    cases.failing_pivots(make_wg, n=90, m=60, batch=3)  # ... with seven block columns in swizzled blocks (56 < n <= 112)
 
 
 def make_csr_dense(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
