@@ -247,6 +247,8 @@ struct WgLayout {
     static constexpr bool MSX = NW == 4 && R == 16 && C == 16 && TC == 7 && TW == 7 && TR <= 8;
 #endif
     static constexpr int MSX_END = ev(MP + 16 * 7 + 8) + (7 + 28 + 2) * 256;
+    // the 32 x 16 grid of eight waves (m <= 224, n <= 112) takes the MFMA set-up too: its LDS has the room (one workgroup per CU anyway)
+    static constexpr bool MSR = NW == 8 && R == 32 && C == 16 && TC == 7 && TW == 4;
     // (the set-up scratch and build_B's staging end below the owners' constants; the x~ staging region may lie inside them)
     static constexpr int O_STX = ev(mx(O_STAGE + STAGE, (MSX ? MSX_END : mx(SETUP, O_AS2 + R * SSTR)) - NR * Cp));
     // per-element constants of the owners (q, l, u): LDS instead of VGPRs, after everything the set-up may alias
@@ -2167,7 +2169,7 @@ __global__ __launch_bounds__(64, WPE) void admm_g16_kernel(KArgs<double, TIN> a)
 // the end of the round (WgLayout::MSX, admm_wg_msetup.h: 81.7 KB, still two per CU).  m <= 224 with 56 < n <= 112 takes a 32 x 16 grid of eight waves (7 x 7 + 4 x 7 doubles of
 // tiles per lane, two waves per SIMD) since round 4: the four-wave 16 x 16 grid with 13 x 7 + 7 x 7 doubles per lane that served it
 // ran one wave per SIMD with the AGPRs as spill space (bound to 256 registers it spilled into the loop, 4.05 -> 8.4 ms):
-// 2,048 x (100,200) 4.01 -> 3.65 ms, under the default settings 4.33 -> 3.06)
+// 2,048 x (100,200) 4.01 -> 3.65 ms, under the default settings 4.33 -> 3.06; 3.01 / 2.61 ms with the MFMA set-up, WgLayout::MSR)
 // n <= 32 with 64 < m <= 128 has a 16 x 8 grid of its own since round 4 (8 x 4 + 2 x 4 doubles of tiles per lane, three waves per SIMD,
 // MFMA set-up): until then it ran in the C3 grid padded to 56 columns or, beyond m = 112, in the four-wave 16 x 16 grid —
 // 4,096 x (24,96) 1.11 -> 0.75 ms, 4,096 x (32,128) ~1.5 -> 0.79 ms (tools/xp/shape_sweep.py found the gap)

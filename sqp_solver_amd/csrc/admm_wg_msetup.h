@@ -48,12 +48,17 @@ struct MSetup {
     // P is staged (LDS-DMA) where its n x n block fits behind O_SB; where only the blocks fit (the four-wave 16 x 16 grid with n <= 64)
     // the P phase reads it from global memory
     static constexpr bool PST = O_SB + L::NP * L::NP <= L::O_QV;
-    static constexpr int END = L::mx(O_TB + 2 * BS, PST ? O_SB + L::NP * L::NP : 0);
+    // 32-row grids (RH = 2 half-blocks of 16 rows per tile row): the D layout of B' = W A' is not the register tile there, the result
+    // blocks go through LDS (build_B_rows), one block per 16 columns of B
+    static constexpr int RH = R / 16;
+    static constexpr int O_DS = O_TB + 2 * BS;
+    static constexpr int END = L::mx(O_DS + (RH > 1 ? NB * BS : 0), PST ? O_SB + L::NP * L::NP : 0);
 #ifdef SQPH_XP_NO_MSET4  // (experiment builds: the scalar set-up for the four-wave grid)
     static constexpr bool ENABLED = NW == 2 && R == 16 && C == 4 * NW && L::NP <= 64 && END <= L::O_QV && (O_SB % 2) == 0;
 #else
-    static constexpr bool ENABLED = NW >= 1 && R == 16 && C == 4 * NW && (L::NP <= 64 || L::MSX) && END <= L::O_QV && (O_SB % 2) == 0;
+    static constexpr bool ENABLED = NW >= 1 && ((R == 16 && C == 4 * NW && (L::NP <= 64 || L::MSX)) || L::MSR) && END <= L::O_QV && (O_SB % 2) == 0;
 #endif
+    static_assert(!L::MSR || ENABLED, "the 32 x 16 grid's set-up scratch has room for the MFMA set-up");
     static_assert(!L::MSX || ENABLED, "WgLayout sized the set-up scratch of this grid for the MFMA set-up");
 
     static __device__ __forceinline__ int blk(int I, int K) { return I * (I + 1) / 2 + K; }
@@ -283,15 +288,18 @@ struct MSetup {
 #pragma unroll
         for (int k = 0; k < TC; k++) {
             const int j = L::col(c, k);
-            xw[k] = XS + (j >> 4) * BS + ix(r, j & 15);
+            xw[k] = XS + (j >> 4) * BS + ix(r & 15, j & 15);
         }
         constexpr bool ALLV = NBLK % NW == 0;  // every wavefront has NQ blocks: no per-block test
 #pragma unroll
-        for (int s = 0; s < TR; s++) {
-            if (R * s < m) {
+        for (int sh = 0; sh < TR * RH; sh++) {
+            const int s = sh / RH, h = sh % RH;  // tile row and its 16-row half (RH = 1: the whole tile row)
+            if (R * s + 16 * h < m) {
                 __syncthreads();
+                if (RH == 1 || (r >> 4) == h) {
 #pragma unroll
-                for (int k = 0; k < TC; k++) *xw[k] = at[s][k];
+                    for (int k = 0; k < TC; k++) *xw[k] = at[s][k];
+                }
                 __syncthreads();
                 // all four k-steps of the block, straight-line (rows beyond m are zero rows of the tile with rho = 0): the operands of
                 // a k-step are requested before the products of the one before it wait for theirs
@@ -303,7 +311,7 @@ struct MSetup {
                         av[q] = xa[q][SWZ ? ix(lq + 4 * kq, lr) : 4 * kq * 17];
                         bw[q] = xb[q][SWZ ? ix(lq + 4 * kq, lr) : 4 * kq * 17];
                     }
-                    const T rk = rho_l[R * s + 4 * kq + lq];
+                    const T rk = rho_l[R * s + 16 * h + 4 * kq + lq];
 #pragma unroll
                     for (int q = 0; q < NQ; q++)
                         if (ALLV || bv[q]) mfma16(av[q], bw[q] * rk, acc[q]);
@@ -490,6 +498,45 @@ struct MSetup {
         const int r = t % R, c = t / R;
         T *XS = lds + O_XS;
         const T *SB = lds + O_SB;
+        if constexpr (RH > 1) {
+            // 32-row grids: B' = W A' per 16-row half of a tile row; wavefront w multiplies block row w of W (W rows 16 w ..) into the
+            // staged half-block of A — D[i][j] = B[A row j][W row 16 w + i] — and parks D in LDS, where lane (r, c) of that half picks
+            // up B[R s + r][16 k + c] = D_k[c][r & 15]
+            static_assert(!STACK && C == 16, "one result block per tile column");
+            T *DS = lds + O_DS;
+#pragma unroll
+            for (int sh = 0; sh < TR * RH; sh++) {
+                const int s = sh / RH, h = sh % RH;
+                if (R * s + 16 * h < m) {
+                    __syncthreads();
+                    if ((r >> 4) == h) {
+#pragma unroll
+                        for (int k = 0; k < TC; k++) {
+                            const int j = L::col(c, k);
+                            XS[(j >> 4) * BS + ix(r & 15, j & 15)] = at[s][k];
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll 1
+                    for (int w = wave; w < NB; w += NW) {
+                        sqph_acc4 a = {{0, 0, 0, 0}};
+#pragma unroll 1
+                        for (int jb = 0; jb <= w; jb++) {
+                            const T *Wb = SB + blk(w, jb) * BS, *Ab = XS + jb * BS;
+#pragma unroll
+                            for (int kq = 0; kq < 4; kq++) mfma16(opN(Wb, kq, lr, lq), opN(Ab, kq, lr, lq), a);
+                        }
+                        stD(DS + w * BS, lr, lq, a);
+                    }
+                    __syncthreads();
+                    if ((r >> 4) == h) {
+#pragma unroll
+                        for (int k = 0; k < TC; k++) at[s][k] = SQPH_TILE_QUANT(DS[k * BS + ix(c, r & 15)]);
+                    }
+                }
+            }
+            return;
+        }
         // my element of W in the A-operand of accumulator q and column block jb: W[cw][16 jb + ko + lq] with cw the W row of my D
         // row; where that block lies above the diagonal (or cw is not a column of the problem) the address is that of a zero row
         const T *wa[NJQ][NB];
