@@ -247,10 +247,20 @@ struct WgLayout {
     static constexpr bool MSX = NW == 4 && R == 16 && C == 16 && TC == 7 && TW == 7 && TR <= 8;
 #endif
     static constexpr int MSX_END = ev(MP + 16 * 7 + 8) + (7 + 28 + 2) * 256;
-    // the 32 x 16 grid of eight waves (m <= 224, n <= 112) takes the MFMA set-up too: its LDS has the room (one workgroup per CU anyway)
-    static constexpr bool MSR = NW == 8 && R == 32 && C == 16 && TC == 7 && TW == 4;
+    // the 32 x 16 grid of eight waves (m <= 224, n <= 112) takes the MFMA set-up too: its LDS has the room (one workgroup per CU anyway);
+    // so do the tall grids (32 x 8 with four waves, 64 x 8 with eight: n <= 56), whose blocks may need a little more than the
+    // scalar set-up's scratch (MST_END enters O_QV below)
+#ifdef SQPH_NO_MST  // A/B experiment builds
+    static constexpr bool MST = false;
+#else
+    // (not the 64 x 8 / 7 x 7 grid: with the MFMA code its no-check loop spills, 2,048 x (50,400) 3.61 -> 5.52 ms)
+    static constexpr bool MST = (NW == 4 && R == 32 && C == 8) || (NW == 8 && R == 64 && C == 8 && TC <= 4);
+#endif
+    static constexpr bool MSR = (NW == 8 && R == 32 && C == 16 && TC == 7 && TW == 4) || MST;
+    static constexpr int MST_NB = (NP + 15) / 16;
+    static constexpr int MST_END = ev(MP + 16 * MST_NB + 8 + 2) + (2 * MST_NB + MST_NB * (MST_NB + 1) / 2 + 2) * (MST_NB > 4 ? 256 : 272);
     // (the set-up scratch and build_B's staging end below the owners' constants; the x~ staging region may lie inside them)
-    static constexpr int O_STX = ev(mx(O_STAGE + STAGE, (MSX ? MSX_END : mx(SETUP, O_AS2 + R * SSTR)) - NR * Cp));
+    static constexpr int O_STX = ev(mx(O_STAGE + STAGE, (MSX ? MSX_END : mx(mx(SETUP, O_AS2 + R * SSTR), MST ? MST_END : 0)) - NR * Cp));
     // per-element constants of the owners (q, l, u): LDS instead of VGPRs, after everything the set-up may alias
     static constexpr int O_QV = ev(O_STX + NR * Cp);
     static constexpr int O_LOV = O_QV + NP;

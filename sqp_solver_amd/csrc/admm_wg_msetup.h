@@ -502,7 +502,7 @@ struct MSetup {
             // 32-row grids: B' = W A' per 16-row half of a tile row; wavefront w multiplies block row w of W (W rows 16 w ..) into the
             // staged half-block of A — D[i][j] = B[A row j][W row 16 w + i] — and parks D in LDS, where lane (r, c) of that half picks
             // up B[R s + r][16 k + c] = D_k[c][r & 15]
-            static_assert(!STACK && C == 16, "one result block per tile column");
+            static_assert(!STACK && (C == 16 || C == 8), "tile column k is column 8 (k & 1) + c or c of result block k / 2 or k");
             T *DS = lds + O_DS;
 #pragma unroll
             for (int sh = 0; sh < TR * RH; sh++) {
@@ -531,7 +531,7 @@ struct MSetup {
                     __syncthreads();
                     if ((r >> 4) == h) {
 #pragma unroll
-                        for (int k = 0; k < TC; k++) at[s][k] = SQPH_TILE_QUANT(DS[k * BS + ix(c, r & 15)]);
+                        for (int k = 0; k < TC; k++) at[s][k] = SQPH_TILE_QUANT(DS[(L::col(c, k) >> 4) * BS + ix(L::col(c, k) & 15, r & 15)]);
                     }
                 }
             }
