@@ -12,6 +12,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 # extra compiler flags from the environment, e.g. SQPH_HIPCC_FLAGS=-DSQPH_LANE_NO_FMA for users who want the one-QP-per-lane kernel's
 # unfused multiply / add back (it tracks the reference's unfused CPU arithmetic almost bit for bit: admm_lane_kernel.h)
 FLAGS += os.environ.get("SQPH_HIPCC_FLAGS", "").split()
+# flags of single translation units (csrb.hip says why)
+UNIT_FLAGS = {"csrb.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 
 def sources():
@@ -40,7 +42,7 @@ def build(force=False, verbose=False):
     objs, procs = [], []
     for u in units:
         obj = os.path.join(LIBDIR, u[:-4] + ".o")
-        cmd = [HIPCC] + cflags + ["-c", "-o", obj, os.path.join(CSRC, u)]
+        cmd = [HIPCC] + cflags + UNIT_FLAGS.get(u, []) + ["-c", "-o", obj, os.path.join(CSRC, u)]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

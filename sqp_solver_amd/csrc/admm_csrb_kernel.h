@@ -1,0 +1,1266 @@
+// Sparse-A ADMM kernel, block-row form (BASELINE config 5: n = 200, m = 400, CSR A): ONE 512-lane workgroup (8 wavefronts) per QP.
+//
+// The factor W (S^-1 = W'W, lower triangular, n <= 16 NB) lives in the CU's register file as 16 x 16 blocks in the accumulator
+// layout of v_mfma_f64_16x16x4_f64 (lane l of a wavefront holds rows (l >> 4) + 4 e, e < 4, of column l & 15).  Wavefront w owns
+// the block rows I1 = NB - 1 - w and I0 = w (NB + 1 blocks, 4 doubles per lane each); the last wavefront owns none and
+// eliminates the diagonal blocks.  What this layout buys over the 32 x 32 lane grid of admm_csr_kernel.h:
+//   * the set-up runs on the matrix pipe with the blocks in registers: blocked elimination, only the current panel column / block
+//     row (NB blocks) and two diagonal blocks go through LDS (the 2-D cyclic tile of the other kernel took n pivots of ~80
+//     instructions and a workgroup barrier each);
+//   * y1 = W t is reduced inside the wavefront (a block row's 16 row sums need the 16 lanes of a DPP row: 8 partial sums per lane
+//     through a private LDS slice, no workgroup barrier) and handed to x~ = W' y1 by DPP row broadcast inside the multiply-add;
+//     the column sums of W' y1 are reduced over the four DPP rows by v_permlane32_swap / v_permlane16_swap and cross the
+//     wavefronts as 8 partial sums per column (14 KB instead of 2 x 57 KB of staging per iteration);
+//   * with 256 VGPRs per lane the entries of A a lane sums — its slice of a row for A x~, of a column for A' w — stay in
+//     registers (values and packed 16-bit indices, at most KR per lane and orientation): a sparse product is one LDS gather
+//     per entry instead of an index load and two gathers.
+// Iteration (reference src/qp.cpp:84-103 on the Schur-ordered system; four workgroup barriers):
+//     t = (sigma x - q) + A' w  |  y1 = W t ; x~ partials = W' y1  |  x~, x  |  z~ = A x~ ; z, y ; w = rho z - y
+// Numerics: the formulas of admm_csr_kernel.h / admm_generic.h, fp64 arithmetic, TIN inputs.
+// Requirements checked by the host: n <= 16 NB, m <= 512, CSR rows sorted by column without duplicates, everything within LDS.
+// A QP whose rows (columns) need more than KR entries per lane takes the LDS form of that sparse product (block-uniform branch).
+#pragma once
+#include "admm_csr_kernel.h"
+
+#ifndef SQPH_CSB_KR
+#define SQPH_CSB_KR 14
+#endif
+
+namespace sqph {
+
+template <int NB>
+struct CsbLayout {
+    static constexpr int NT = 512, NW = 8;
+    static constexpr int NP = 16 * NB;
+    static constexpr int BS = 16 * 17;  // a 16 x 16 block, rows padded to 17 doubles (admm_wg_msetup.h: opN / opT / D accesses conflict-free)
+    static constexpr int LDP = NP + 1;  // S panel column stride
+    static constexpr int ev(int x) { return (x + 1) & ~1; }
+    static constexpr int mx(int a, int b) { return a > b ? a : b; }
+    // the work area (offsets in doubles from 0) is shared by: the S panel of the set-up | the elimination's panel / diagonal
+    // buffers | the iteration's staging | the lane maps while they are built
+    static constexpr int W_PANEL = 32 * LDP;
+    static constexpr int O_XS = 0;                  // [NB][BS] step J: L_IJ at I > J, W_JK at K < J
+    static constexpr int O_TB = O_XS + NB * BS;     // [2][BS]  unscaled inverse of the current / next diagonal block
+    static constexpr int O_MD = O_TB + 2 * BS;      // [2][BS]  the diagonal block handed to the eliminating wavefront, W_JJ on return
+    static constexpr int W_ELIM = O_MD + 2 * BS;
+    static constexpr int O_PW = 0;                  // [8 waves][8 values][64 lanes] partial sums of y1 = W t
+    static constexpr int O_XP = O_PW + 8 * 8 * 64;  // [NP][8] partial sums of x~ = W' y1, one per wavefront
+    static constexpr int W_ITER = O_XP + NP * 8;
+    static constexpr int W_MAP = (2 * NT * 2 + (544 + 32) * 4 + 7) / 8;
+    static constexpr int WORK = ev(mx(mx(W_PANEL, W_ELIM), mx(W_ITER, W_MAP)));
+    static constexpr int o_t = WORK;                // t = sigma x - q + A'w, plain-indexed
+    static constexpr int o_xt = o_t + NP;
+    static constexpr int o_ux = o_xt + NP;
+    static constexpr int o_qv = o_ux + NP;
+    static constexpr int o_sj = o_qv + NP;
+    static constexpr int o_flag = o_sj + NP;        // [8]
+    static constexpr int o_red = o_flag + 8;        // [8][8]
+    static constexpr int o_colptr_d = o_red + 64;   // (NP + 1) ints
+    static constexpr int o_ccur_d = o_colptr_d + ev(NP + 2) / 2;
+    static constexpr int o_var = o_ccur_d + NP / 2;
+    static constexpr int o_colptr = 2 * o_colptr_d, o_ccur = 2 * o_ccur_d;  // 32-bit words
+    int o_lo, o_up, o_rinv, o_wv, o_zs, o_ys, o_rho, o_val;  // doubles: l, u, 1/rho, w, z, y, rho [MP each]; CSR values
+    int o_rowptr, o_csc, o_col;                     // 32-bit words
+    size_t bytes;
+    __host__ __device__ static CsbLayout make(int m, int nnz_cap) {
+        CsbLayout L;
+        const int MP = (m + 1) & ~1;
+        int d = o_var;
+        L.o_lo = d; d += MP;
+        L.o_up = d; d += MP;
+        L.o_rinv = d; d += MP;
+        L.o_wv = d; d += MP;
+        L.o_zs = d; d += MP;
+        L.o_ys = d; d += MP;
+        L.o_rho = d; d += MP;
+        L.o_val = d; d += nnz_cap;
+        int w = 2 * d;
+        L.o_csc = w; w += nnz_cap;
+        L.o_rowptr = w; w += m + 1;
+        L.o_col = w; w += (nnz_cap + 1) / 2;
+        L.bytes = (size_t)w * 4 + 16;
+        return L;
+    }
+};
+
+// reduce-scatter steps over the four 16-lane rows of a wavefront: one swap instruction per 32-bit half pairs two values
+//   swap_reduce32(a, b): lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l]
+//   swap_reduce16(a, b): even rows get a[row] + a[row + 1], odd rows get b[row - 1] + b[row]
+__device__ __forceinline__ double swap_reduce32(double a, double b) {
+#ifdef SQPH_SIM
+    const double pa = xchg<32>(a), pb = xchg<32>(b);
+    return ((int)threadIdx.x & 32) ? pb + b : a + pa;
+#else
+    auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+#endif
+}
+__device__ __forceinline__ double swap_reduce16(double a, double b) {
+#ifdef SQPH_SIM
+    const double pa = xchg<16>(a), pb = xchg<16>(b);
+    return ((int)threadIdx.x & 16) ? pb + b : a + pa;
+#else
+    auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+#endif
+}
+// acc + y(lane N .. N + 3 of my 16-lane row) * b[0 .. 3]: four v_fmac_f64 with the row_newbcast control behind ONE pair of wait states
+template <int N>
+__device__ __forceinline__ double fmac4_bcast16(double acc, double y, const sqph_acc4 &b) {
+#ifdef SQPH_SIM
+    acc = __builtin_fma(bcast16<N>(y), b.v[0], acc);
+    acc = __builtin_fma(bcast16<N + 1>(y), b.v[1], acc);
+    acc = __builtin_fma(bcast16<N + 2>(y), b.v[2], acc);
+    acc = __builtin_fma(bcast16<N + 3>(y), b.v[3], acc);
+    return acc;
+#else
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %1, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(y), "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "n"(N), "n"(N + 1), "n"(N + 2), "n"(N + 3));
+    return acc;
+#endif
+}
+
+template <typename TIN, int NB>
+struct CsbKernel {
+    using T = double;
+    using Lay = CsbLayout<NB>;
+    using MS = MSetup<2, 16, 8, 7, 7, 4>;  // the in-wavefront elimination of a 16 x 16 diagonal block (admm_wg_msetup.h: diag_block)
+    static_assert(!MS::SWZ && MS::BS == Lay::BS, "diag_block works on padded blocks");
+    static constexpr int NT = Lay::NT, NW = Lay::NW, NP = Lay::NP, BS = Lay::BS, LDP = Lay::LDP;
+    static constexpr int NH = (NB + 1) / 2;  // wavefronts that own blocks
+    static constexpr int DW = NW - 1;        // the wavefront that eliminates the diagonal blocks
+    static constexpr int KR = SQPH_CSB_KR;   // entries of A per lane and orientation held in registers
+    static_assert(NH <= DW && NB >= 1 && NB <= 14 && (KR % 2) == 0, "block rows pair up on seven wavefronts");
+
+    // block rows and register slots of wavefront W: slots 0 .. I1 hold row I1 = NB - 1 - W, slots I1 + 1 .. I1 + 1 + I0 row I0 = W
+    template <int W>
+    struct Own {
+        static constexpr bool any = W < NH;
+        static constexpr int I1 = NB - 1 - W, I0 = W;
+        static constexpr bool has0 = any && I0 < I1;
+        static constexpr int nslots = any ? (I1 + 1) + (has0 ? I0 + 1 : 0) : 0;
+        static constexpr int row(int s) { return s <= I1 ? I1 : I0; }
+        static constexpr int col(int s) { return s <= I1 ? s : s - I1 - 1; }
+    };
+
+    // the same map with the wavefront index a run-time scalar: the set-up is ONE code path for all wavefronts (seven specialised
+    // copies of the elimination — 14 eight-register accumulator tuples each — were more than the register allocator could hold
+    // together: two of the copies kept their blocks in scratch memory); only the iteration's two dense stages are specialised
+    struct Slot {
+        int I, K;
+        bool valid;
+    };
+    static __device__ __forceinline__ Slot slot_of(int W, int s) {
+        const int I1 = NB - 1 - W, n1 = I1 + 1;
+        const bool has0 = W < I1;
+        Slot d;
+        d.valid = W < NH && (s < n1 || (has0 && s < n1 + W + 1));
+        d.I = s < n1 ? I1 : W;
+        d.K = s < n1 ? s : s - n1;
+        return d;
+    }
+    static __device__ __forceinline__ int wave_of(int t) { return MS::wave_of(t); }
+    template <typename P>
+    static __device__ __forceinline__ const P *uniform_ptr(const P *p) {
+#ifdef SQPH_SIM
+        return p;
+#else
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const P *>(((unsigned long long)hi << 32) | lo);
+#endif
+    }
+    // a use of every block register (no instruction): placed in the loop's sparse phases, whose many loads in flight would otherwise
+    // push the blocks — long live ranges with two uses per iteration, the allocator's favourite victims — out to scratch
+    static __device__ __forceinline__ void pin_blocks(const sqph_acc4 (&B)[NB + 1]) {
+#ifndef SQPH_SIM
+#pragma unroll
+        for (int s = 0; s <= NB; s++) asm volatile("" ::"v"(B[s].v[0]), "v"(B[s].v[1]), "v"(B[s].v[2]), "v"(B[s].v[3]));
+#endif
+    }
+    // a copy the register coalescer cannot see through (an empty asm with a tied operand is joined into one live range again)
+    static __device__ __forceinline__ T split_range(T v) {
+#ifdef SQPH_SIM
+        return v;
+#else
+        T o;
+        asm volatile("v_mov_b64 %0, %1" : "=v"(o) : "v"(v));
+        return o;
+#endif
+    }
+    static __device__ __forceinline__ void wave_fence() { MS::wave_fence(); }
+    static __device__ __forceinline__ T opN(const T *b, int kq, int lr, int lq) { return b[lr * 17 + 4 * kq + lq]; }
+    static __device__ __forceinline__ T opT(const T *b, int kq, int lr, int lq) { return b[(4 * kq + lq) * 17 + lr]; }
+    static __device__ __forceinline__ void ldD(const T *b, int lr, int lq, sqph_acc4 &a) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) a.v[e] = b[(lq + 4 * e) * 17 + lr];
+    }
+    static __device__ __forceinline__ void stD(T *b, int lr, int lq, const sqph_acc4 &a) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) b[(lq + 4 * e) * 17 + lr] = a.v[e];
+    }
+
+    // ---------------------------------------------------------------- sparse data: CSR -> LDS, CSC index, lane maps
+    static constexpr int MAP_VALID = 1 << 15;
+    static __device__ __forceinline__ int lanes_for(int len, int K) {
+        const int need = (len + K - 1) / K;
+        return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 4096;
+    }
+#ifdef SQPH_SIM
+    static inline int shfl_up_i(int v, int d) {
+        const int lane = (int)(threadIdx.x & 63);
+        return (int)(uint32_t)::sqph_sim::wave_exchange((uint64_t)(uint32_t)v, lane >= d ? lane - d : lane);
+    }
+    static inline int shfl_i(int v, int src) { return (int)(uint32_t)::sqph_sim::wave_exchange((uint64_t)(uint32_t)v, src); }
+#else
+    static __device__ __forceinline__ int shfl_up_i(int v, int d) { return __shfl_up(v, d); }
+    static __device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src); }
+#endif
+
+    // CSR of this QP -> LDS, CSC index (row | position-in-CSR) by counting sort, entries of a column ordered by row
+    static __device__ __forceinline__ void load_sparse(const CsrArgs<TIN> &ca, int qp, int n, int m, const Lay &L, unsigned char *smem) {
+        const int t = threadIdx.x;
+        T *lds = reinterpret_cast<T *>(smem);
+        int *li = reinterpret_cast<int *>(smem);
+        int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr, *ccur = li + L.o_ccur;
+        unsigned *csc = reinterpret_cast<unsigned *>(li + L.o_csc);
+        unsigned short *col = reinterpret_cast<unsigned short *>(li + L.o_col);
+        T *val = lds + L.o_val;
+        const int *grp = ca.rowptr + (long long)qp * ca.s_rowptr;
+        const int *gci = ca.colind + (long long)qp * ca.s_colind;
+        const TIN *gv = ca.val + (long long)qp * ca.s_val;
+        for (int i = t; i <= m; i += NT) rowptr[i] = grp[i];
+        for (int j = t; j <= NP; j += NT) colptr[j] = 0;
+        __syncthreads();
+        const int nnz = rowptr[m];
+        for (int e = t; e < nnz; e += NT) {
+            const int j = gci[e];
+            col[e] = (unsigned short)j;
+            val[e] = (T)gv[e];
+            lds_atomic_inc(&colptr[j + 1]);  // integer counts: order-independent
+        }
+        __syncthreads();
+        if (t < 64) {  // exclusive scan of the column counts: wave 0, 4 per lane
+            int v[4], s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = 4 * t + k;
+                v[k] = (j < NP) ? colptr[j + 1] : 0;
+                s += v[k];
+            }
+            int incl = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = shfl_up_i(incl, d);
+                if ((t & 63) >= d) incl += o;
+            }
+            int run = incl - s;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = 4 * t + k;
+                if (j < NP) {
+                    colptr[j + 1] = run + v[k];
+                    ccur[j] = run;
+                }
+                run += v[k];
+            }
+        }
+        __syncthreads();
+        // fill in the order the atomics are served, then make canonical by ranking (the keys of a column are distinct: the final slot
+        // of an entry is the number of smaller keys in its column — one lane per entry)
+        unsigned *tmp = reinterpret_cast<unsigned *>(lds);  // the work area is idle
+        const bool ranked = (size_t)nnz * sizeof(unsigned) <= (size_t)Lay::WORK * sizeof(T);
+        unsigned *fill = ranked ? tmp : csc;
+        for (int i = t; i < m; i += NT) {
+            for (int e = rowptr[i]; e < rowptr[i + 1]; e++) {
+                const int j = col[e];
+                const int slot = lds_atomic_inc(&ccur[j]);
+                fill[slot] = ((unsigned)i << 16) | (unsigned)e;
+            }
+        }
+        __syncthreads();
+        if (ranked) {
+            for (int s0 = t; s0 < nnz; s0 += NT) {
+                const unsigned key = tmp[s0];
+                const int j = col[key & 0xffffu];
+                const int e0 = colptr[j], e1 = colptr[j + 1];
+                int rank = 0;
+                for (int f = e0; f < e1; f++) rank += tmp[f] < key ? 1 : 0;
+                csc[e0 + rank] = key;
+            }
+        } else {
+            for (int j = t; j < n; j += NT) {
+                const int e0 = colptr[j], e1 = colptr[j + 1];
+                for (int e = e0 + 1; e < e1; e++) {
+                    const unsigned key = csc[e];
+                    int f = e - 1;
+                    while (f >= e0 && csc[f] > key) {
+                        csc[f + 1] = csc[f];
+                        f--;
+                    }
+                    csc[f + 1] = key;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // A row (column) of A gets 1, 2, 4 or 8 lanes by its length such that no lane carries more than K entries, K the smallest bound
+    // for which everything fits the NT lanes; groups are laid out by size (aligned for the xor butterfly that adds their partial sums).
+    // Map word (16 bits): element in bits 0-8, part in 9-11, log2(lanes of the element) in 12-13, valid in 15.  Returns K.
+    static __device__ __forceinline__ int build_lane_map(const int *ptr, int count, unsigned short *map, int *hist) {
+        const int t = threadIdx.x;
+        constexpr int NC = 15, HL = 544;  // lengths are <= 512
+        constexpr int KC[NC] = {4, 5, 6, 7, 8, 10, 12, 14, 16, 24, 32, 48, 64, 128, 256};
+        int *need = hist + HL;
+        for (int e = t; e < HL + 16; e += NT) hist[e] = 0;
+        map[t] = 0;
+        __syncthreads();
+        if (t < count) lds_atomic_inc(&hist[ptr[t + 1] - ptr[t]]);
+        __syncthreads();
+        if (t < 64) {
+            int loc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) loc[c] = 0;
+            for (int len = t; len < HL; len += 64) {
+                const int h = hist[len];
+                if (h) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) loc[c] += h * lanes_for(len, KC[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                int v = loc[c];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = shfl_up_i(v, d);
+                    if (t >= d) v += o;
+                }
+                if (t == 63) need[c] = v;
+            }
+        }
+        __syncthreads();
+        int K = KC[NC - 1];
+#pragma unroll
+        for (int c = NC - 1; c >= 0; c--)
+            if (need[c] <= NT) K = KC[c];
+        if (t < 64) {  // wave 0: eight consecutive elements per lane, class offsets by a scan over the 64 lanes
+            int cnt[4] = {0, 0, 0, 0}, cls[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = 8 * t + k;
+                cls[k] = -1;
+                if (i < count) {
+                    const int p = lanes_for(ptr[i + 1] - ptr[i], K);
+                    const int c = p == 1 ? 0 : p == 2 ? 1 : p == 4 ? 2 : 3;
+                    cls[k] = c;
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) cnt[cc] += (cc == c) ? 1 : 0;
+                }
+            }
+            int incl[4], tot[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                int v = cnt[cc];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = shfl_up_i(v, d);
+                    if (t >= d) v += o;
+                }
+                incl[cc] = v;
+                tot[cc] = shfl_i(v, 63);
+            }
+            int base[4];
+            base[3] = 0;
+            base[2] = 8 * tot[3];
+            base[1] = base[2] + 4 * tot[2];
+            base[0] = base[1] + 2 * tot[1];
+            int run[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) run[cc] = incl[cc] - cnt[cc];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int c = cls[k];
+                if (c >= 0) {
+                    int b0 = 0, rn = 0;
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) {
+                        if (cc == c) {
+                            b0 = base[cc];
+                            rn = run[cc];
+                            run[cc] += 1;
+                        }
+                    }
+                    const int p = 1 << c, lane0 = b0 + rn * p;
+                    for (int part = 0; part < p; part++)
+                        map[lane0 + part] = (unsigned short)(MAP_VALID | (c << 12) | (part << 9) | (8 * t + k));
+                }
+            }
+        }
+        __syncthreads();
+        return K;
+    }
+    static __device__ __forceinline__ T group_sum(T s, int lg) {
+        T o = xchg<1>(s);
+        s += lg >= 1 ? o : T(0);
+        o = xchg<2>(s);
+        s += lg >= 2 ? o : T(0);
+        o = xchg<4>(s);
+        s += lg >= 3 ? o : T(0);
+        return s;
+    }
+    // sparse products from LDS (a QP whose map needs more than KR entries per lane): as admm_csr_kernel.h
+    static __device__ __forceinline__ T csr_row_dot_lds(const int *rowptr, const unsigned short *col, const T *val, const T *v, int mp) {
+        T a0 = 0, a1 = 0;
+        const int lg = (mp >> 12) & 3;
+        if (mp & MAP_VALID) {
+            const int i = mp & 511, p = 1 << lg;
+            const int e1 = rowptr[i + 1];
+            int e = rowptr[i] + ((mp >> 9) & 7);
+            for (; e + p < e1; e += 2 * p) {
+                a0 = wg_fma(val[e], v[col[e]], a0);
+                a1 = wg_fma(val[e + p], v[col[e + p]], a1);
+            }
+            if (e < e1) a0 = wg_fma(val[e], v[col[e]], a0);
+        }
+        return group_sum(a0 + a1, lg);
+    }
+    static __device__ __forceinline__ T csc_col_dot_lds(const int *colptr, const unsigned *csc, const T *val, const T *v, int mp) {
+        T a0 = 0, a1 = 0;
+        const int lg = (mp >> 12) & 3;
+        if (mp & MAP_VALID) {
+            const int j = mp & 511, p = 1 << lg;
+            const int e1 = colptr[j + 1];
+            int e = colptr[j] + ((mp >> 9) & 7);
+            for (; e + p < e1; e += 2 * p) {
+                const unsigned p0 = csc[e], p1 = csc[e + p];
+                a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
+                a1 = wg_fma(val[p1 & 0xffffu], v[p1 >> 16], a1);
+            }
+            if (e < e1) {
+                const unsigned p0 = csc[e];
+                a0 = wg_fma(val[p0 & 0xffffu], v[p0 >> 16], a0);
+            }
+        }
+        return group_sum(a0 + a1, lg);
+    }
+    // the same with the lane's entries in registers: sv[k] the values, si[k / 2] two packed 16-bit BYTE offsets into v (slots beyond
+    // the lane's share hold value 0 and offset 0).  Same summation order as the LDS form (even / odd entries, then the group).
+    // The packed words pass through an opaque asm on every call: loop-invariant as they are, the compiler would otherwise keep the
+    // 2 KR unpacked gather addresses in registers across the loop (28 VGPRs that the iterates and part of the slices paid for
+    // with scratch memory).
+    static __device__ __forceinline__ T gather_at(const T *v, int off) {
+        return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(v) + off);
+    }
+    static __device__ __forceinline__ T reg_dot(const T (&sv)[KR], const int (&si)[KR / 2], const T *v, int mp) {
+        T g[KR];
+#pragma unroll
+        for (int k = 0; k < KR; k += 2) {
+            int w = si[k >> 1];
+            SQPH_OPAQUE_V(w);
+            g[k] = gather_at(v, w & 0xffff);
+            g[k + 1] = gather_at(v, (int)((unsigned)w >> 16));
+        }
+        T a0 = 0, a1 = 0;
+#pragma unroll
+        for (int k = 0; k < KR; k += 2) {
+            a0 = wg_fma(sv[k], g[k], a0);
+            a1 = wg_fma(sv[k + 1], g[k + 1], a1);
+        }
+        return group_sum(a0 + a1, (mp >> 12) & 3);
+    }
+    static __device__ __forceinline__ void load_row_regs(const int *rowptr, const unsigned short *col, const T *val, int mp, T (&sv)[KR],
+                                                         int (&si)[KR / 2]) {
+        const bool own = (mp & MAP_VALID) != 0;
+        const int i = mp & 511, p = 1 << ((mp >> 12) & 3);
+        const int e1 = own ? rowptr[i + 1] : 0;
+        const int e0 = own ? rowptr[i] + ((mp >> 9) & 7) : 0;
+#pragma unroll
+        for (int k = 0; k < KR / 2; k++) si[k] = 0;
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const int e = e0 + k * p;
+            const bool in = own && e < e1;
+            sv[k] = in ? val[e] : T(0);
+            si[k >> 1] |= (in ? 8 * (int)col[e] : 0) << (16 * (k & 1));
+        }
+    }
+    static __device__ __forceinline__ void load_col_regs(const int *colptr, const unsigned *csc, const T *val, int mp, T (&sv)[KR],
+                                                         int (&si)[KR / 2]) {
+        const bool own = (mp & MAP_VALID) != 0;
+        const int j = mp & 511, p = 1 << ((mp >> 12) & 3);
+        const int e1 = own ? colptr[j + 1] : 0;
+        const int e0 = own ? colptr[j] + ((mp >> 9) & 7) : 0;
+#pragma unroll
+        for (int k = 0; k < KR / 2; k++) si[k] = 0;
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const int e = e0 + k * p;
+            const bool in = own && e < e1;
+            const unsigned pk = in ? csc[e] : 0u;
+            sv[k] = in ? val[pk & 0xffffu] : T(0);
+            si[k >> 1] |= (int)(8 * (pk >> 16)) << (16 * (k & 1));
+        }
+    }
+
+    // ---------------------------------------------------------------- S = P_sym + sigma I + A' diag(rho) A -> blocks
+    // One 32-column panel at a time in LDS: the 16-lane group g owns column j = 32 p + g — for every CSC entry (i, pos) of that
+    // column, in row order, its lanes add rho_i A_ij * (row i of A) into the panel column (distinct k per lane: rows are
+    // duplicate-free; successive entries are ordered by the wavefront's program order).  Only k >= j is formed (+ the lower triangle
+    // of P: what reaches the reference's factor, Eigen::LDLT<.,Lower>, qp.hpp:129); diagonal blocks are mirrored on pick-up.
+    static __device__ __forceinline__ void pick_up(int W, int p, int n, const T *Sp, int lr, int lq, sqph_acc4 (&B)[NB + 1]) {
+#pragma unroll
+        for (int s = 0; s <= NB; s++) {
+            const Slot d = slot_of(W, s);
+            if (d.valid && (d.K >> 1) == p) {
+                const int kk = d.K & 1;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int il = lq + 4 * e, i = 16 * d.I + il, j = 16 * d.K + lr;
+                    const int hi = il > lr ? il : lr, lo = il > lr ? lr : il;
+                    // a diagonal block is mirrored: (lo, hi) of the lower triangle; elsewhere column lr, row il
+                    const int a = d.I == d.K ? (16 * kk + lo) * LDP + 16 * d.I + hi : (16 * kk + lr) * LDP + i;
+                    const T v = Sp[a];
+                    B[s].v[e] = (i < n && j < n) ? v : (i == j ? T(1) : T(0));  // the padding is an identity block
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ void form_S(const TIN *__restrict__ gP, int n, T sigma, const Lay &L, unsigned char *smem, int t,
+                                                  int wave, sqph_acc4 (&B)[NB + 1]) {
+        const int c16 = t & 15, g = t >> 4, lr = t & 15, lq = (t >> 4) & 3;
+        T *lds = reinterpret_cast<T *>(smem);
+        const int *li = reinterpret_cast<const int *>(smem);
+        const int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr;
+        const unsigned *csc = reinterpret_cast<const unsigned *>(li + L.o_csc);
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(li + L.o_col);
+        const T *val = lds + L.o_val, *rho = lds + L.o_rho;
+        T *Sp = lds;
+#pragma unroll 1
+        for (int p = 0; p < (NB + 1) / 2; p++) {
+            __syncthreads();
+            for (int e = t; e < 32 * LDP; e += NT) Sp[e] = 0;
+            __syncthreads();
+            const int j = 32 * p + g;
+            if (j < n) {
+                // software-pipelined by one entry: the index / coefficient loads of entry e + 1 are issued before the
+                // read-modify-writes of entry e, which the compiler will not move loads across
+                const int e1 = colptr[j + 1];
+                int e = colptr[j];
+                if (e < e1) {
+                    unsigned pk = csc[e];
+                    int i = (int)(pk >> 16);
+                    T coef = rho[i] * val[pk & 0xffffu];
+                    int f0 = rowptr[i], f1 = rowptr[i + 1];
+                    for (; e < e1; e++) {
+                        const unsigned pkn = csc[e + 1 < e1 ? e + 1 : e];
+                        const int in = (int)(pkn >> 16);
+                        const T coefn = rho[in] * val[pkn & 0xffffu];
+                        const int f0n = rowptr[in], f1n = rowptr[in + 1];
+                        for (int f = f0 + c16; f < f1; f += 16) {
+                            const int k = col[f];
+                            if (k >= j) Sp[g * LDP + k] = wg_fma(coef, val[f], Sp[g * LDP + k]);
+                        }
+                        coef = coefn;
+                        f0 = f0n;
+                        f1 = f1n;
+                    }
+                }
+                // + lower triangle of P + sigma I: the group's 16 lanes walk down column j from the diagonal (all loads of a
+                // batch are issued before the first read-modify-write)
+                const TIN *pc = gP + (long)j * n;
+                for (int k0 = j; k0 < n; k0 += 16 * 7) {
+                    T pv[7];
+#pragma unroll
+                    for (int q = 0; q < 7; q++) {
+                        const int k = k0 + c16 + 16 * q;
+                        pv[q] = k < n ? (T)pc[k] : T(0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 7; q++) {
+                        const int k = k0 + c16 + 16 * q;
+                        if (k < n) Sp[g * LDP + k] += pv[q] + (k == j ? sigma : T(0));
+                    }
+                }
+            }
+            __syncthreads();
+            pick_up(wave, p, n, Sp, lr, lq, B);
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- Jacobi scaling + blocked elimination on the matrix pipe
+    // S~ = D_J S D_J = L L' in 16 x 16 blocks, W = L^-1 D_J (admm_wg_msetup.h phase 3, with the blocks in registers).  Step J:
+    //   A: panel L_IJ = M_IJ Winv_JJ' of my rows I > J (through XS[I]: the block is the A-operand of its own product); the owner of
+    //      row J + 1 updates M_J+1,J+1 at once and hands it to the eliminating wavefront; the owner of row J finishes it:
+    //      W_JK = Winv_JJ E_JK (K < J, published in XS[K]), W_JJ from the eliminating wavefront
+    //   B: E_IK -= L_IJ W_JK (K < J), E_IJ = -L_IJ Winv_JJ D_J, M_IK -= L_IJ L_KJ' (J < K <= I) on my rows I > J, both operands
+    //      from LDS, the accumulators in place; meanwhile the last wavefront eliminates M_J+1,J+1 (look-ahead)
+    // E is the unit-block-lower inverse in the making, stored in place of the eliminated blocks.
+    static __device__ __forceinline__ void diag_to_sj(int W, const sqph_acc4 (&B)[NB + 1], T *sj, int lr, int lq) {
+#pragma unroll
+        for (int s = 0; s <= NB; s++) {
+            const Slot d = slot_of(W, s);
+            if (d.valid && d.I == d.K) {
+                const T a0 = B[s].v[0], a1 = B[s].v[1], a2 = B[s].v[2], a3 = B[s].v[3];
+                const T d01 = (lr & 4) ? a1 : a0, d23 = (lr & 4) ? a3 : a2;
+                const T dv = (lr & 8) ? d23 : d01;
+                if ((lr & 3) == lq) sj[16 * d.I + lr] = dv;
+            }
+        }
+    }
+    static __device__ __forceinline__ void scale_blocks(int W, sqph_acc4 (&B)[NB + 1], const T *sj, T *wk, int lr, int lq) {
+#pragma unroll
+        for (int s = 0; s <= NB; s++) {
+            const Slot d = slot_of(W, s);
+            if (d.valid) {
+                const T dc = sj[16 * d.K + lr];
+#pragma unroll
+                for (int e = 0; e < 4; e++) B[s].v[e] = B[s].v[e] * sj[16 * d.I + lq + 4 * e] * dc;
+                if (d.I == 0) stD(wk + Lay::O_MD, lr, lq, B[s]);  // M_00 to the eliminating wavefront
+            }
+        }
+    }
+    static __device__ __forceinline__ void elim_A(int W, int J, sqph_acc4 (&B)[NB + 1], T *wk, int lr, int lq) {
+        T *XS = wk + Lay::O_XS;
+        const T *Wd = wk + Lay::O_TB + (J & 1) * BS;
+#pragma unroll
+        for (int s = 0; s <= NB; s++) {
+            const Slot d = slot_of(W, s);
+            if (!d.valid) continue;
+            if (d.I > J && d.K == J) {
+                T *x = XS + d.I * BS;
+                stD(x, lr, lq, B[s]);
+                wave_fence();
+                sqph_acc4 a = {{0, 0, 0, 0}};
+                T av[4], bv[4];
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) {
+                    av[kq] = opN(x, kq, lr, lq);
+                    bv[kq] = opN(Wd, kq, lr, lq);
+                }
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
+                wave_fence();
+                stD(x, lr, lq, a);
+            } else if (d.I == J && d.K < J) {
+                sqph_acc4 a = {{0, 0, 0, 0}};
+                T av[4];
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) av[kq] = opN(Wd, kq, lr, lq);
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], B[s].v[kq], a);  // the D layout of a block is its B-operand layout
+                B[s] = a;
+                stD(XS + d.K * BS, lr, lq, a);
+            } else if (d.I == J && d.K == J) {
+                ldD(wk + Lay::O_MD + (J & 1) * BS, lr, lq, B[s]);  // W_JJ = Winv_JJ D_J
+            }
+        }
+        // look-ahead: the next diagonal block, updated now (with my own L_J+1,J) and handed to the eliminating wavefront
+        wave_fence();
+#pragma unroll
+        for (int s = 0; s <= NB; s++) {
+            const Slot d = slot_of(W, s);
+            if (d.valid && d.I == J + 1 && d.K == J + 1) {
+                const T *x = XS + d.I * BS;
+                T av[4];
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) av[kq] = opN(x, kq, lr, lq);
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) mfma16(-av[kq], av[kq], B[s]);
+                stD(wk + Lay::O_MD + ((J + 1) & 1) * BS, lr, lq, B[s]);
+            }
+        }
+    }
+    static __device__ __forceinline__ void elim_B(int W, int J, sqph_acc4 (&B)[NB + 1], const T *wk, const T *sj, int lr, int lq) {
+        const T *XS = wk + Lay::O_XS;
+        const T *Wd = wk + Lay::O_TB + (J & 1) * BS;
+        const T dc = sj[16 * J + lr];
+        const int I1 = NB - 1 - W, I0 = W;
+        T av1[4] = {0, 0, 0, 0}, av0[4] = {0, 0, 0, 0};
+        if (I1 > J) {
+#pragma unroll
+            for (int kq = 0; kq < 4; kq++) av1[kq] = -opN(XS + I1 * BS, kq, lr, lq);
+        }
+        if (I0 < I1 && I0 > J) {
+#pragma unroll
+            for (int kq = 0; kq < 4; kq++) av0[kq] = -opN(XS + I0 * BS, kq, lr, lq);
+        }
+#pragma unroll
+        for (int s = 0; s <= NB; s++) {
+            const Slot d = slot_of(W, s);
+            if (!d.valid || d.I <= J) continue;
+            T av[4], bv[4];
+#pragma unroll
+            for (int kq = 0; kq < 4; kq++) av[kq] = s <= I1 ? av1[kq] : av0[kq];  // (a scalar condition)
+            if (d.K < J) {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) bv[kq] = opT(XS + d.K * BS, kq, lr, lq);
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
+            } else if (d.K == J) {
+                sqph_acc4 a = {{0, 0, 0, 0}};
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) bv[kq] = opT(Wd, kq, lr, lq);
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
+#pragma unroll
+                for (int e = 0; e < 4; e++) B[s].v[e] = a.v[e] * dc;
+            } else if (!(d.I == J + 1 && d.K == J + 1)) {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) bv[kq] = opN(XS + d.K * BS, kq, lr, lq);
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
+            }
+        }
+    }
+#define SQPH_CSB_SWITCH(wave, CALL) \
+    switch (wave) { \
+        case 0: if constexpr (Own<0>::any) { CALL(0); } break; \
+        case 1: if constexpr (Own<1>::any) { CALL(1); } break; \
+        case 2: if constexpr (Own<2>::any) { CALL(2); } break; \
+        case 3: if constexpr (Own<3>::any) { CALL(3); } break; \
+        case 4: if constexpr (Own<4>::any) { CALL(4); } break; \
+        case 5: if constexpr (Own<5>::any) { CALL(5); } break; \
+        case 6: if constexpr (Own<6>::any) { CALL(6); } break; \
+        default: break; \
+    }
+    // returns false (block-uniform) when S is not positive definite / not finite; leaves W in B
+#ifdef SQPH_PHASE_TIMING
+#define SQPH_FTICK_ARGS , unsigned long long (&tacc)[16], unsigned long long &tprev
+#define SQPH_FTICK_PASS , tacc, tprev
+#define SQPH_FTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
+#else
+#define SQPH_FTICK_ARGS
+#define SQPH_FTICK_PASS
+#define SQPH_FTICK(k)
+#endif
+    static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, int n, T sigma, const Lay &L, unsigned char *smem, int t,
+                                                  sqph_acc4 (&B)[NB + 1] SQPH_FTICK_ARGS) {
+        T *lds = reinterpret_cast<T *>(smem);
+        T *sj = lds + Lay::o_sj, *flag = lds + Lay::o_flag, *wk = lds;
+        const int wave = wave_of(t), l = t & 63, lr = l & 15, lq = l >> 4;
+        form_S(gP, n, sigma, L, smem, t, wave, B);
+        SQPH_FTICK(1)
+        if (t < 2) flag[t] = T(0);
+        if (t < NP) sj[t] = T(1);
+        __syncthreads();
+        diag_to_sj(wave, B, sj, lr, lq);
+        __syncthreads();
+        if (t < NP) {
+            const T d = sj[t];
+            const bool bad = !(d > T(0)) || !(d * T(0) == T(0));  // non-positive / non-finite diagonal => not SPD
+            sj[t] = bad ? T(1) : T(1) / (T)sqrt((double)d);
+            if (bad) flag[0] = T(1);
+        }
+        __syncthreads();
+        if (flag[0] != T(0)) return false;
+        scale_blocks(wave, B, sj, wk, lr, lq);
+        __syncthreads();
+        SQPH_FTICK(2)
+        if (wave == DW) MS::diag_block(wk + Lay::O_MD, wk + Lay::O_TB, sj, flag, l);
+#pragma unroll 1
+        for (int J = 0; J < NB; J++) {
+            __syncthreads();
+            SQPH_FTICK(12)
+            elim_A(wave, J, B, wk, lr, lq);
+            SQPH_FTICK(13)
+            if (J == NB - 1) break;
+            __syncthreads();
+            SQPH_FTICK(14)
+            if (wave == DW)
+                MS::diag_block(wk + Lay::O_MD + ((J + 1) & 1) * BS, wk + Lay::O_TB + ((J + 1) & 1) * BS, sj + 16 * (J + 1), flag, l);
+            else
+                elim_B(wave, J, B, wk, sj, lr, lq);
+            SQPH_FTICK(15)
+        }
+        __syncthreads();
+        SQPH_FTICK(7)
+        return flag[1] == T(0);
+    }
+
+    // ---------------------------------------------------------------- the two dense stages of an iteration, one wavefront
+    // y1 = W t for my block rows (partial sums over the 16 lanes of a DPP row through my slice of PW, summed by two lanes per
+    // value), then the partial column sums of W' y1 over my rows, reduced over the four DPP rows and written to XP[column][wave].
+    template <int W>
+    static __device__ __forceinline__ void stages(const sqph_acc4 (&B)[NB + 1], const T *tv, T *pw, T *xp, int n, int wave, int lr, int lq) {
+        using O = Own<W>;
+        T acc1[4] = {0, 0, 0, 0}, acc0[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int K = 0; K <= O::I1; K++) {
+            const T tk = tv[16 * K + lr];
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc1[e] = wg_fma(B[K].v[e], tk, acc1[e]);
+            if (O::has0 && K <= O::I0) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc0[e] = wg_fma(B[O::has0 ? O::I1 + 1 + K : 0].v[e], tk, acc0[e]);
+            }
+        }
+        T *mine = pw + wave * 512;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            mine[((e)*4 + lq) * 16 + lr] = acc1[e];
+            mine[((4 + e) * 4 + lq) * 16 + lr] = acc0[e];
+        }
+        wave_fence();
+        T ytot;
+        {
+            const int v = lr & 7, h = lr >> 3;
+            T p[8];
+            wg_read<8>(mine + (v * 4 + lq) * 16 + 8 * h, p);
+            T s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            s += xchg16<8>(s);
+            const int i = 16 * (v < 4 ? O::I1 : O::I0) + lq + 4 * (v & 3);
+            ytot = i < n ? s : T(0);  // lanes v and v + 8 of DPP row lq: y1 of row 16 I(v) + lq + 4 (v & 3)
+        }
+        T cacc[14];
+#pragma unroll
+        for (int K = 0; K < 14; K++) cacc[K] = T(0);
+#pragma unroll
+        for (int K = 0; K <= O::I1; K++) {
+            cacc[K] = fmac4_bcast16<0>(cacc[K], ytot, B[K]);
+            if (O::has0 && K <= O::I0) cacc[K] = fmac4_bcast16<4>(cacc[K], ytot, B[O::has0 ? O::I1 + 1 + K : 0]);
+        }
+        T r[8];
+#pragma unroll
+        for (int i = 0; i < 7; i++) r[i] = swap_reduce32(cacc[i], cacc[i + 7]);
+        r[7] = T(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const T q = swap_reduce16(r[i], r[i + 4]);
+            // row lq holds the total of column block K = i (lq 0), i + 4 (lq 1), i + 7 (lq 2), i + 11 (lq 3)
+            const int K = i + ((lq & 1) ? 4 : 0) + ((lq & 2) ? 7 : 0);
+            const bool valid = ((lq & 1) ? i < 3 : true) && K < NB;
+            if (valid) xp[(16 * K + lr) * 8 + wave] = q;
+        }
+    }
+
+    // tile <-> global workspace (the factor survives between setup() and solve() calls there), canonical col-major n x n, lower part
+    static __device__ __forceinline__ void store_blocks(int W, T *__restrict__ gW, int n, int lr, int lq, const sqph_acc4 (&B)[NB + 1]) {
+#pragma unroll
+        for (int s = 0; s <= NB; s++) {
+            const Slot d = slot_of(W, s);
+            if (!d.valid) continue;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 16 * d.I + lq + 4 * e, j = 16 * d.K + lr;
+                if (i < n && j < n && i >= j) gW[(long)j * n + i] = B[s].v[e];
+            }
+        }
+    }
+    static __device__ __forceinline__ void load_blocks(int W, const T *__restrict__ gW, int n, int lr, int lq, sqph_acc4 (&B)[NB + 1]) {
+#pragma unroll
+        for (int s = 0; s <= NB; s++) {
+            const Slot d = slot_of(W, s);
+            if (!d.valid) continue;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 16 * d.I + lq + 4 * e, j = 16 * d.K + lr;
+                B[s].v[e] = (i < n && j < n && i >= j) ? gW[(long)j * n + i] : T(0);
+            }
+        }
+    }
+
+    // CHECKS = false: the instantiation for calls that never look at the residuals (check_termination == 0, no adaptive rho)
+    template <bool CHECKS = true>
+    static __device__ __forceinline__ void run(const KArgs<T, TIN> &a, const CsrArgs<TIN> &ca, unsigned char *smem) {
+        const int qp = blockIdx.x;
+        if (qp >= a.batch) return;
+        const int n = a.n, m = a.m;
+        const Lay L = Lay::make(m, ca.nnz_cap);
+        T *lds = reinterpret_cast<T *>(smem);
+        int *li = reinterpret_cast<int *>(smem);
+        const int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr;
+        const unsigned *csc = reinterpret_cast<const unsigned *>(li + L.o_csc);
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(li + L.o_col);
+        const T *val = lds + L.o_val;
+        T *tv = lds + Lay::o_t, *xt = lds + Lay::o_xt, *ux = lds + Lay::o_ux, *qv = lds + Lay::o_qv, *wv = lds + L.o_wv;
+        T *lov = lds + L.o_lo, *upv = lds + L.o_up, *rinvv = lds + L.o_rinv;
+        T *zs = lds + L.o_zs, *ys = lds + L.o_ys, *rhov = lds + L.o_rho;  // z, y, rho of the constraint rows live in LDS (written by a row's lead lane)
+        T *pw = lds + Lay::O_PW, *xp = lds + Lay::O_XP;
+
+        const TIN *gP = a.P + (long)qp * a.sP;
+        const TIN *gq = a.q + (long)qp * a.sq;
+        const TIN *gl = a.l + (long)qp * a.sl;
+        const TIN *gu = a.u + (long)qp * a.su;
+        T *sx = a.x + (long)qp * n;
+        T *sz = a.z + (long)qp * m;
+        T *sy = a.y + (long)qp * m;
+        T *srho = a.rho_vec + (long)qp * m;
+        int *sct = a.ctype + (long)qp * m;
+        T *gW = a.Sinv + (long)qp * 2 * n * n;
+
+        sqph_info info = a.info[qp];
+        T rho_s = a.rho[qp];
+        const int mode = a.mode;
+        if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
+            return;  // qp.cpp:68-71 (block-uniform)
+
+        const int t = threadIdx.x, wave = wave_of(t), l = t & 63, lr = l & 15, lq = l >> 4;
+#ifdef SQPH_PHASE_TIMING
+        unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+        const unsigned long long tstart = tprev;
+#define SQPH_BTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
+#else
+#define SQPH_BTICK(k)
+#endif
+        // element owners: lane j < n tracks x_j; the lanes the ROW MAP gives constraint row i track z_i, y_i, rho_i (all of them keep a
+        // copy, the one with part 0 writes); the COLUMN MAP's lanes sum the columns of A' w
+        load_sparse(ca, qp, n, m, L, smem);
+        int rmap, cmap;
+        bool rreg, creg;
+        {
+            unsigned short *tmap = reinterpret_cast<unsigned short *>(lds);  // the work area is idle
+            int *scratch = reinterpret_cast<int *>(tmap + 2 * NT);
+            const int Kr = build_lane_map(rowptr, m, tmap, scratch);
+            const int Kc = build_lane_map(colptr, n, tmap + NT, scratch);
+            rmap = (int)tmap[t];
+            cmap = (int)tmap[NT + t];
+            rreg = Kr <= KR;
+            creg = Kc <= KR;
+            __syncthreads();
+        }
+        SQPH_BTICK(0)
+        const int im = rmap & 511;
+        const bool mown = (rmap & MAP_VALID) != 0, lead = mown && ((rmap >> 9) & 7) == 0;
+        const bool nown = t < n;
+
+        T x = 0;
+        if (t < NP) {
+            qv[t] = nown ? (T)gq[t] : T(0);
+            tv[t] = T(0);
+            xt[t] = T(0);
+            ux[t] = T(0);
+        }
+        if (lead) {
+            lov[im] = (T)gl[im];
+            upv[im] = (T)gu[im];
+        }
+        __syncthreads();
+        if (mode & (MODE_SETUP | MODE_UPDATE)) {
+            rho_s = a.rho0;
+            if (lead) {
+                const T lo = lov[im], up = upv[im];
+                int ctype = SQPH_INEQUALITY_CONSTRAINT;
+                if (lo < -a.loose_thresh && up > a.loose_thresh)
+                    ctype = SQPH_LOOSE_BOUNDS;
+                else if (up - lo < a.eq_tol)
+                    ctype = SQPH_EQUALITY_CONSTRAINT;
+                const T rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
+                rhov[im] = rho;
+                rinvv[im] = T(1) / rho;
+                sct[im] = ctype;
+                srho[im] = rho;
+                const bool keep = !(mode & MODE_SETUP);
+                zs[im] = keep ? sz[im] : T(0);
+                ys[im] = keep ? sy[im] : T(0);
+            }
+            info.rho_updates += 1;
+            if (!(mode & MODE_SETUP) && nown) x = sx[t];
+        } else {
+            if (nown) x = sx[t];
+            if (lead) {
+                const T rho = srho[im];
+                zs[im] = sz[im];
+                ys[im] = sy[im];
+                rhov[im] = rho;
+                rinvv[im] = T(1) / rho;
+            }
+        }
+
+        sqph_acc4 B[NB + 1];
+#pragma unroll
+        for (int s = 0; s <= NB; s++) B[s] = sqph_acc4{{0, 0, 0, 0}};  // (defined on every path: the slots a wavefront does not own are never touched)
+        T rv[KR], cv[KR];
+        int ri[KR / 2], ci[KR / 2];
+        bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
+        bool solving = false;
+        bool state_dirty = (mode & MODE_SETUP) != 0;
+        if (!need_factor) {
+            load_blocks(wave, gW, n, lr, lq, B);
+        }
+        const T alpha = a.alpha, sigma = a.sigma, oma = T(1) - a.alpha;
+        int iter = 1;
+        int next_check = a.check_termination > 0 ? a.check_termination : -1;
+        int next_adapt = (a.adaptive_rho && a.adaptive_rho_interval > 0) ? a.adaptive_rho_interval : -1;
+        for (;;) {
+            if (need_factor) {
+                __syncthreads();
+                SQPH_BTICK(10)
+                const bool ok = factor(gP, n, sigma, L, smem, t, B SQPH_FTICK_PASS);
+                SQPH_BTICK(11)
+                if (!(mode & MODE_NO_FACTOR_STORE)) {  // kept for later solve() calls
+                    store_blocks(wave, gW, n, lr, lq, B);
+                }
+                __syncthreads();
+                need_factor = false;
+                if (!solving) {
+                    if (mode & (MODE_SETUP | MODE_UPDATE)) info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;  // qp.cpp:39-43, 57-61
+                    else if (!ok) info.status = SQPH_NUMERICAL_ISSUES;  // solve() rebuilding a factor that was not kept
+                } else if (!ok) {
+                    info.status = SQPH_NUMERICAL_ISSUES;  // qp.cpp:139-142
+                    break;
+                } else {
+                    iter++;
+                }
+            }
+            if (!(mode & MODE_SOLVE) || info.status == SQPH_NUMERICAL_ISSUES || info.status == SQPH_UNINITIALIZED) break;
+            if (!solving) {
+                solving = true;
+                state_dirty = true;
+                if ((mode & MODE_COLD_RESET) && !a.warm_start) {
+                    x = 0;
+                    if (lead) zs[im] = ys[im] = T(0);
+                }
+            }
+            // (re)load the sparse slices: the work area they border on was used by the set-up; w, u of the first iteration
+            __syncthreads();
+            // the blocks start new live ranges here: whatever the set-up's register pressure made the allocator do with them, the
+            // iteration loop gets them in registers
+#pragma unroll
+            for (int s = 0; s <= NB; s++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) B[s].v[e] = split_range(B[s].v[e]);
+            if (rreg) load_row_regs(rowptr, col, val, rmap, rv, ri);
+            if (creg) load_col_regs(colptr, csc, val, cmap, cv, ci);
+            for (int e = t; e < NP * 8; e += NT) xp[e] = T(0);
+            if (lead) wv[im] = rhov[im] * (zs[im] - rinvv[im] * ys[im]);
+            if (t < NP) ux[t] = nown ? sigma * x - qv[t] : T(0);
+            SQPH_BTICK(10)
+            for (; iter <= a.max_iter; iter++) {
+                __syncthreads();
+                SQPH_BTICK(8)
+                {   // t = (sigma x - q) + A' w
+                    pin_blocks(B);
+                    const T s = creg ? reg_dot(cv, ci, wv, cmap) : csc_col_dot_lds(colptr, csc, val, wv, cmap);
+                    const int j = cmap & 511;
+                    if ((cmap & MAP_VALID) && ((cmap >> 9) & 7) == 0) tv[j] = ux[j] + s;
+                    pin_blocks(B);
+                }
+                __syncthreads();
+                SQPH_BTICK(3)
+#define SQPH_CSB_CALL(W_) stages<W_>(B, tv, pw, xp, n, wave, lr, lq)
+                SQPH_CSB_SWITCH(wave, SQPH_CSB_CALL)
+#undef SQPH_CSB_CALL
+                __syncthreads();
+                SQPH_BTICK(4)
+                if (t < NP) {  // x~ = W' y1; x relaxation (qp.cpp:96)
+                    T p[8];
+                    wg_read<8>(xp + t * 8, p);
+                    const T xtj = nown ? ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) : T(0);
+                    xt[t] = xtj;
+                    x = alpha * xtj + oma * x;
+                    ux[t] = nown ? sigma * x - qv[t] : T(0);  // next iteration's u
+                }
+                __syncthreads();
+                SQPH_BTICK(5)
+                {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
+                    pin_blocks(B);
+                    const T zt = rreg ? reg_dot(rv, ri, xt, rmap) : csr_row_dot_lds(rowptr, col, val, xt, rmap);
+                    if (lead) {
+                        const T z = zs[im], y = ys[im], rho = rhov[im], rinv = rinvv[im];
+                        const T zr = alpha * zt + oma * z;
+                        T zn = zr + rinv * y;
+                        const T lo = lov[im], up = upv[im];
+                        zn = zn < lo ? lo : zn;
+                        zn = zn > up ? up : zn;
+                        const T yn = y + rho * (zr - zn);
+                        zs[im] = zn;
+                        ys[im] = yn;
+                        wv[im] = rho * (zn - rinv * yn);  // next iteration's w (read after the loop-top barrier)
+                    }
+                    pin_blocks(B);
+                }
+                SQPH_BTICK(6)
+                bool check = false, adapt = false;
+                if constexpr (CHECKS) {
+                    if (--next_check == 0) {
+                        check = true;
+                        next_check = a.check_termination;
+                    }
+                    if (--next_adapt == 0) {
+                        adapt = true;
+                        next_adapt = a.adaptive_rho_interval;
+                    }
+                }
+                if (CHECKS && (check || adapt)) {
+                    // update_state + residuals, qp.cpp:316-331, 353-361
+                    __syncthreads();
+                    if (t < NP) xt[t] = nown ? x : T(0);
+                    if (lead) wv[im] = ys[im];
+                    __syncthreads();
+                    const T Ax = rreg ? reg_dot(rv, ri, xt, rmap) : csr_row_dot_lds(rowptr, col, val, xt, rmap);
+                    {   // A' y by the column map's lanes, handed to the lanes that track x through tv
+                        const T sATy = creg ? reg_dot(cv, ci, wv, cmap) : csc_col_dot_lds(colptr, csc, val, wv, cmap);
+                        if ((cmap & MAP_VALID) && ((cmap >> 9) & 7) == 0) tv[cmap & 511] = sATy;
+                    }
+                    {   // P x with the full P (both triangles, qp.cpp:324), streamed: lane t takes row t & 255 and every second column
+                        const int i = t & 255, h = t >> 8;
+                        T acc = 0;
+                        if (i < n) {
+                            const TIN *pr = gP + i;
+                            int j = h;
+                            for (; j + 6 < n; j += 8) {
+                                const T p0 = (T)pr[(long)j * n], p1 = (T)pr[(long)(j + 2) * n], p2 = (T)pr[(long)(j + 4) * n],
+                                        p3 = (T)pr[(long)(j + 6) * n];
+                                acc = wg_fma(p0, xt[j], acc);
+                                acc = wg_fma(p1, xt[j + 2], acc);
+                                acc = wg_fma(p2, xt[j + 4], acc);
+                                acc = wg_fma(p3, xt[j + 6], acc);
+                            }
+                            for (; j < n; j += 2) acc = wg_fma((T)pr[(long)j * n], xt[j], acc);
+                        }
+                        pw[h * 256 + i] = acc;
+                    }
+                    __syncthreads();
+                    T v[7] = {0, 0, 0, 0, 0, 0, 0};
+                    if (lead) {
+                        const T z = zs[im];
+                        v[0] = tabs(Ax);
+                        v[1] = tabs(z);
+                        v[2] = tabs(Ax - z);
+                    }
+                    if (nown) {
+                        const T Px = pw[t] + pw[256 + t], ATy = tv[t], q = qv[t];
+                        v[3] = tabs(Px);
+                        v[4] = tabs(ATy);
+                        v[5] = tabs(q);
+                        v[6] = tabs(Px + q + ATy);
+                    }
+                    {
+                        T *red = lds + Lay::o_red;
+#pragma unroll
+                        for (int e = 0; e < 7; e++) v[e] = wave_nanmax(v[e]);
+                        if (l == 0) {
+#pragma unroll
+                            for (int e = 0; e < 7; e++) red[e * 8 + wave] = v[e];
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int e = 0; e < 7; e++) {
+                            T mval = red[e * 8];
+#pragma unroll
+                            for (int k = 1; k < 8; k++) mval = nanmax(mval, red[e * 8 + k]);
+                            v[e] = mval;
+                        }
+                        __syncthreads();
+                    }
+                    const T nrm_prim = nanmax(v[0], v[1]);
+                    const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
+                    info.res_prim = (double)v[2];
+                    info.res_dual = (double)v[6];
+                    if (check) {
+                        if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
+                            info.status = SQPH_SOLVED;
+                            break;
+                        }
+                    }
+                    if (adapt) {
+                        const T eps = a.regul;
+                        const T rp_norm = v[2] / (nrm_prim + eps);
+                        const T rd_norm = v[6] / (nrm_dual + eps);
+                        T new_rho = rho_s * (T)sqrt((double)(rp_norm / (rd_norm + eps)));
+                        new_rho = new_rho < a.rho_max ? new_rho : a.rho_max;
+                        new_rho = new_rho > a.rho_min ? new_rho : a.rho_min;
+                        info.rho_estimate = (double)new_rho;
+                        if (new_rho < rho_s / a.rho_tol || new_rho > rho_s * a.rho_tol) {
+                            rho_s = new_rho;
+                            if (lead) {
+                                const T rho = rho_for_type<T>(sct[im], rho_s, a.rho_min, a.rho_eq_factor);
+                                rhov[im] = rho;
+                                rinvv[im] = T(1) / rho;
+                            }
+                            info.rho_updates += 1;
+                            need_factor = true;
+                            break;  // leave WITHOUT advancing iter; the factor block does it
+                        }
+                    }
+                    // the check borrowed xp's neighbours: PW held the P x partial sums, wv held y
+                    __syncthreads();
+                    if (lead) wv[im] = rhov[im] * (zs[im] - rinvv[im] * ys[im]);
+                }
+            }
+            if (!need_factor) break;
+        }
+        if (solving) {
+            if (iter > a.max_iter) info.status = SQPH_MAX_ITER_EXCEEDED;
+            info.iter = iter;
+        }
+#ifdef SQPH_PHASE_TIMING
+        tacc[9] = __builtin_amdgcn_s_memtime() - tstart;
+        if (t < 16) x = (T)tacc[t];  // debug build only: wave 0's phase ticks instead of x[0..12)
+#endif
+        if (state_dirty) {
+            if (nown) sx[t] = x;
+            if (lead) {
+                sz[im] = zs[im];
+                sy[im] = ys[im];
+                srho[im] = rhov[im];
+            }
+        }
+        if (t == 0) {
+            a.info[qp] = info;
+            a.rho[qp] = rho_s;
+        }
+    }
+#undef SQPH_CSB_SWITCH
+};
+
+template <typename TIN, int NB>
+__global__ __launch_bounds__(512) void admm_csrb_kernel(CsrLaunch<TIN> p) {
+    SQPH_DYN_SMEM(smem_raw);
+    CsbKernel<TIN, NB>::template run<true>(p.a, p.ca, smem_raw);
+}
+// the same without the residual-check block
+template <typename TIN, int NB>
+__global__ __launch_bounds__(512) void admm_csrb_nocheck_kernel(CsrLaunch<TIN> p) {
+    SQPH_DYN_SMEM(smem_raw);
+    CsbKernel<TIN, NB>::template run<false>(p.a, p.ca, smem_raw);
+}
+
+// block-row counts compiled into the library (n <= 16 NB): first fit wins
+#if defined(SQPH_SLIM) && defined(SQPH_SLIM_CSR)
+#define SQPH_CSB_SHAPES(X) X(13)
+#elif defined(SQPH_SLIM)
+#define SQPH_CSB_SHAPES(X)
+#else
+#define SQPH_CSB_SHAPES(X) X(5) X(9) X(13) X(14)
+#endif
+// additional small counts for the host SIMT emulation in the CPU test-suite
+#define SQPH_CSB_SIM_SHAPES(X) X(1) X(2) X(3) X(5) X(13)
+
+// launches the kernel (nocheck: the instantiation without the residual-check block) where a block-row count NB is compiled in:
+// > 0 launched, 0 no such count, < 0 HIP error.  Defined in csrb.hip, the only translation unit that instantiates these kernels.
+template <typename TIN>
+int csrb_launch(int NB, bool nocheck, int m, int nnz_cap, int batch, hipStream_t stream, const CsrLaunch<TIN> &p);
+extern template int csrb_launch<double>(int, bool, int, int, int, hipStream_t, const CsrLaunch<double> &);
+extern template int csrb_launch<float>(int, bool, int, int, int, hipStream_t, const CsrLaunch<float> &);
+
+#ifdef SQPH_SIM
+template <typename TIN>
+inline int sim_run_csrb(const KArgs<double, TIN> &a, const CsrArgs<TIN> &ca) {
+    if (a.m > 512) return -1;
+#define SQPH_SIM_CASE(NB_)                                                                                               \
+    if (a.n <= 16 * NB_) {                                                                                               \
+        const CsbLayout<NB_> L = CsbLayout<NB_>::make(a.m, ca.nnz_cap);                                                  \
+        if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0))                                \
+            ::sqph_sim::launch(admm_csrb_nocheck_kernel<TIN, NB_>, dim3(a.batch), dim3(512), L.bytes, CsrLaunch<TIN>{a, ca}); \
+        else                                                                                                             \
+            ::sqph_sim::launch(admm_csrb_kernel<TIN, NB_>, dim3(a.batch), dim3(512), L.bytes, CsrLaunch<TIN>{a, ca});    \
+        return 0;                                                                                                        \
+    }
+    SQPH_CSB_SIM_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+#endif
+
+}  // namespace sqph

@@ -27,6 +27,7 @@ typedef enum { ncclInt8 = 0, ncclFloat64 = 8 } ncclDataType_t;
 #include "../../include/sqp_hip.h"
 #include "admm_generic.h"
 #include "admm_csr_kernel.h"
+#include "admm_csrb_kernel.h"
 #include "admm_dispatch.h"
 #include "kargs.h"
 
@@ -554,6 +555,7 @@ struct CsrDesc {  // device-resident CSR arrays of the native sparse path
     const void *val;
     long long s_rowptr, s_colind, s_val;
     int nnz_cap, TT;
+    int NB;  // > 0: the block-row kernel (admm_csrb_kernel.h) with this block-row count; 0: the 32 x 32 lane-grid kernel with tile edge TT
 };
 
 template <typename TIN>
@@ -652,8 +654,15 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         a.mode = for_family('c');
         p.a = a;
         p.ca = CsrArgs<TIN>{csr->rowptr, csr->colind, (const TIN *)csr->val, csr->s_rowptr, csr->s_colind, csr->s_val, csr->nnz_cap};
+        const bool nocheck = st.check_termination <= 0 && !(st.adaptive_rho && st.adaptive_rho_interval > 0);
+        if (csr->NB > 0) {  // block-row kernel: 512 lanes per QP, W as MFMA blocks in registers (csrb.hip)
+            const int rc = csrb_launch<TIN>(csr->NB, nocheck, s->m, csr->nnz_cap, qp->batch, s->stream, p);
+            if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "sparse kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+            launched = rc > 0;
+            if (launched) s->kernel_name = csr->NB == 14 ? "csb_nb14" : csr->NB == 13 ? "csb_nb13" : csr->NB == 9 ? "csb_nb9" : csr->NB == 5 ? "csb_nb5" : "csb";
+        }
         // calls that never look at the residuals take the instantiation without the check block (csr_nocheck.hip)
-        if (st.check_termination <= 0 && !(st.adaptive_rho && st.adaptive_rho_interval > 0)) {
+        if (!launched && nocheck) {
             const int rc = csr_nocheck_launch<TIN>(csr->TT, s->m, csr->nnz_cap, qp->batch, s->stream, p);
             if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "sparse kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
             if (rc > 0) {
@@ -914,7 +923,17 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
     }
         SQPH_CSR_SHAPES(SQPH_CSR_PICK)
 #undef SQPH_CSR_PICK
-        if (TT && lds_bytes <= 160 * 1024) {
+        // the block-row kernel where a block-row count is compiled in and its LDS map fits (SQPH_CSR_FORM=tile in the environment
+        // keeps the 32 x 32 lane-grid kernel: A/B measurements)
+        int NB = 0;
+        {
+            static const bool tile_form = getenv("SQPH_CSR_FORM") && !strcmp(getenv("SQPH_CSR_FORM"), "tile");
+#define SQPH_CSB_PICK(NB_)                                                                                          \
+    if (!NB && !tile_form && (int)n <= 16 * NB_ && sqph::CsbLayout<NB_>::make((int)m, (int)c->nnz_max).bytes <= 160 * 1024) NB = NB_;
+            SQPH_CSB_SHAPES(SQPH_CSB_PICK)
+#undef SQPH_CSB_PICK
+        }
+        if (NB || (TT && lds_bytes <= 160 * 1024)) {
             if (!s->cBad) SQPH_HIP(s, hipMalloc((void **)&s->cBad, sizeof(int)));
             SQPH_HIP(s, hipMemsetAsync(s->cBad, 0, sizeof(int), s->stream));
             const size_t npat = s_row ? B : 1;
@@ -926,7 +945,7 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
             SQPH_HIP(s, hipStreamSynchronize(s->stream));
             if (bad & 3) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed CSR (%s)", what, (bad & 1) ? "row pointers not monotone" : "column index out of range");
             if (!(bad & 4)) {
-                CsrDesc cd{rowptr, colind, val, s_row, s_col, s_val ? s_val : 0, (int)c->nnz_max, TT};
+                CsrDesc cd{rowptr, colind, val, s_row, s_col, s_val ? s_val : 0, (int)c->nnz_max, TT, NB};
                 return run(s, &d, mode, what, &cd);
             }
         }

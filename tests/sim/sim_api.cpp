@@ -9,6 +9,7 @@
 #include "../../sqp_solver_amd/csrc/admm_lane_kernel.h"
 #include "../../sqp_solver_amd/csrc/admm_wg_kernel.h"
 #include "../../sqp_solver_amd/csrc/admm_csr_kernel.h"
+#include "../../sqp_solver_amd/csrc/admm_csrb_kernel.h"
 
 extern "C" {
 
@@ -104,5 +105,16 @@ int sim_run_csr(const SimArgs *s, const int *rowptr, const int *colind, const vo
     }
     sqph::CsrArgs<double> ca{rowptr, colind, (const double *)val, s_rowptr, s_colind, s_val, nnz_cap};
     return sqph::sim_run_csr<double>(convert<double>(*s), ca);
+}
+
+// the block-row sparse kernel (admm_csrb_kernel.h), same arguments
+int sim_run_csrb(const SimArgs *s, const int *rowptr, const int *colind, const void *val, long long s_rowptr, long long s_colind,
+                 long long s_val, int nnz_cap, int dtype) {
+    if (dtype == SQPH_F32) {
+        sqph::CsrArgs<float> ca{rowptr, colind, (const float *)val, s_rowptr, s_colind, s_val, nnz_cap};
+        return sqph::sim_run_csrb<float>(convert<float>(*s), ca);
+    }
+    sqph::CsrArgs<double> ca{rowptr, colind, (const double *)val, s_rowptr, s_colind, s_val, nnz_cap};
+    return sqph::sim_run_csrb<double>(convert<double>(*s), ca);
 }
 }

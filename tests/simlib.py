@@ -17,6 +17,7 @@ GENERIC_F32_ARITH = 9  # measurement only: the generic kernel in fp32 arithmetic
 WG_STACK = 12  # register-tiled kernel on the stacked operator (m <= 104 at the C3 shape)
 CSR_DENSE = 11  # the sparse kernel's dense-A mode (A streamed from global memory, W in the CU's registers)
 LANE_QUAD = 13  # the one-QP-per-lane kernel's quad variant (four lanes per QP, m <= 4: small batches)
+CSRB = 14  # the block-row sparse kernel (admm_csrb_kernel.h): 512 lanes per QP, W as MFMA blocks in registers
 WG_F32 = 10  # register-tiled kernels with fp32 products (SQPH_FLAG_F32_ARITH), float interface only
 
 
@@ -48,6 +49,8 @@ def lib():
         _lib.sim_run_csr.argtypes = [ctypes.POINTER(SimArgs), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
                                      ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
         _lib.sim_run_csr.restype = ctypes.c_int
+        _lib.sim_run_csrb.argtypes = _lib.sim_run_csr.argtypes
+        _lib.sim_run_csrb.restype = ctypes.c_int
     return _lib
 
 
@@ -125,7 +128,8 @@ class SimSolverBatch:
             ci = np.ascontiguousarray(ci, np.int32)
             v = np.ascontiguousarray(v, self.dtype)
             shared = rp.ndim == 1
-            rc = lib().sim_run_csr(ctypes.byref(a), rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 0 if shared else rp.shape[-1],
+            fn = lib().sim_run_csrb if self.variant == CSRB else lib().sim_run_csr
+            rc = fn(ctypes.byref(a), rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 0 if shared else rp.shape[-1],
                                    0 if shared else ci.shape[-1], 0 if v.ndim == 1 else v.shape[-1], ci.shape[-1],
                                    1 if self.dtype == np.float32 else 0)
             if rc != 0:

@@ -117,6 +117,84 @@ def test_csr_kernel_adaptive_rho_refactors_in_kernel():
     assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
 
 
+# ------------------------------------------------------------------ the block-row sparse kernel (admm_csrb_kernel.h), 512 lanes per QP
+def make_csrb(n, m, batch, dtype=np.float64, **kw):
+    return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.CSRB, **kw)
+
+
+class _DenseAsCsr(simlib.SimSolverBatch):
+    """the dense-A call surface on top of the CSR entry points (every entry of A stored, NaN included: the stateful cases of cases.py)"""
+
+    @staticmethod
+    def _csr(A):
+        A = np.asarray(A, np.float64)
+        lead = A.shape[:-2]
+        m, n = A.shape[-2:]
+        rp = np.broadcast_to(np.arange(m + 1, dtype=np.int32) * n, lead + (m + 1,)).copy()
+        ci = np.broadcast_to(np.tile(np.arange(n, dtype=np.int32), m), lead + (m * n,)).copy()
+        return rp, ci, A.reshape(lead + (m * n,))
+
+    def setup(self, P, q, A, l, u):
+        self.setup_csr(P, q, *self._csr(A), l, u)
+
+    def update_qp(self, P, q, A, l, u):
+        self.update_qp_csr(P, q, *self._csr(A), l, u)
+
+    def solve(self, P, q, A, l, u):
+        self.solve_csr(P, q, *self._csr(A), l, u)
+
+    def setup_solve(self, P, q, A, l, u):
+        self.setup_solve_csr(P, q, *self._csr(A), l, u)
+
+
+def make_csrb_dense_A(n, m, batch, dtype=np.float64, **kw):
+    return _DenseAsCsr(n, m, batch, dtype=dtype, variant=simlib.CSRB, **kw)
+
+
+def test_csrb_kernel_reference_cases():
+    """tests/qp_solver_sparse_test.cpp (SimpleQP, multiple solve, update_qp) through the block-row kernel, one block row"""
+    cases.csr_reference_cases(make_csrb)
+
+
+@pytest.mark.parametrize("n,m,density,shared", [(12, 20, 0.3, False), (30, 44, 0.2, False), (40, 60, 0.15, True), (70, 90, 0.1, False)],
+                         ids=["nb1", "nb2", "nb3", "nb5"])
+def test_csrb_kernel_parity(n, m, density, shared):
+    """MFMA set-up with the blocks in registers, in-wavefront stage-1 reduction, register-resident slices of A: 1, 2, 3 and 5 block rows
+    (5: every block-owning wavefront pair plus the single middle row)"""
+    cases.csr_parity(make_csrb, n, m, 1, iters=30, density=density, shared_pattern=shared)
+
+
+def test_csrb_kernel_config5_shape():
+    """BASELINE config 5's shape (13 block rows, seven block-owning wavefronts and the eliminating one)"""
+    cases.csr_parity(make_csrb, 200, 400, 1, iters=12, density=0.05)
+
+
+def test_csrb_kernel_dense_rows_take_the_lds_products():
+    """rows of 20 entries on 300 rows: more than KR entries per lane, the sparse products read their entries from LDS"""
+    cases.csr_parity(make_csrb, 20, 300, 1, iters=20, density=1.0)
+
+
+def test_csrb_kernel_adaptive_rho_refactors_in_kernel():
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    n, m = 14, 24
+    P, q, rp, ci, v, l, u, A = random_csr_qp_batch(2, n, m, density=0.3, seed=4)
+    s = make_csrb(n, m, 2)
+    s.settings.adaptive_rho, s.settings.adaptive_rho_interval, s.settings.eps_abs, s.settings.eps_rel = 1, 10, 1e-5, 1e-5
+    s.setup_solve_csr(P, q, rp, ci, v, l, u)
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings))
+    assert (io["rho_updates"] > 1).any()  # the case does exercise a refactorisation
+    assert (info.status == io["status"]).all() and (info.iter == io["iter"]).all() and (info.rho_updates == io["rho_updates"]).all()
+    assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
+
+
+def test_csrb_kernel_stateful_calls():
+    cases.fused_then_solve(make_csrb_dense_A, n=33, m=40, batch=2)
+    cases.warm_start_and_resolve(make_csrb_dense_A, n=20, m=30)
+    cases.uninitialized_and_numerical_issues(make_csrb_dense_A)
+
+
 # ------------------------------------------------------------------ four QPs per wavefront (admm_wg_kernel.h, run_group)
 def make_g16(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
     return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.G16, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
