@@ -50,7 +50,13 @@
  *     adapted: as in the reference it then enters the residuals only (src/qp.cpp:324,360;
  *     the factor is setup()'s).  A must be the matrix of the preceding set-up: the iteration
  *     runs on B = A W', rebuilt from the call's A (the reference reads solve()'s A for the
- *     residuals alone).
+ *     residuals alone).  The batch entry points cannot check this (device pointers); the
+ *     drop-in class qp_solver::QPSolver<Scalar>::solve (include/sqp_hip/qp.hpp) compares its
+ *     argument with the A of the preceding setup()/update_qp() and throws
+ *     std::invalid_argument on a difference instead of solving another problem silently.
+ *   - thread safety: distinct handles may be used from distinct host threads concurrently
+ *     (tests/cpp/qp_facade_test.cpp: testTwoHostThreadsTwoHandles); one handle must not be.
+ *     sqph_global_error() is per thread, sqph_last_error(s) per handle.
  */
 #ifndef SQP_HIP_H
 #define SQP_HIP_H

@@ -324,17 +324,26 @@ class QPSolver {
         }
         push(false);
         impl_->setup(impl_->packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
+        A_factored_.assign(qp.A, qp.A + (size_t)qp.n * qp.m);
         pull();
     }
     void update_qp(const RawQP &qp) {
         if (!impl_) return;
         push(true);
         impl_->update_qp(impl_->packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
+        A_factored_.assign(qp.A, qp.A + (size_t)qp.n * qp.m);
         pull();
     }
     void solve(const RawQP &qp) {
         if (!impl_) return;  // UNINITIALIZED: solve() returns silently, src/qp.cpp:68-71
         if (info_.status == UNINITIALIZED || info_.status == NUMERICAL_ISSUES) return;
+        // The reference iterates on the factor of setup()'s A and reads solve()'s A for the residuals only (src/qp.cpp:319-331,
+        // 355-360); the device iterates on B = A W', so another A here would silently solve another problem: rejected instead
+        // (update_qp() is the call that takes a new A, as in the reference's own use, src/qp.cpp:46-62).
+        if (qp.n != impl_->n() || qp.m != impl_->m()) throw std::invalid_argument("QPSolver::solve: problem shape differs from setup()'s");
+        for (size_t k = 0; k < A_factored_.size(); k++)
+            if (!(qp.A[k] == A_factored_[k]) && !(qp.A[k] != qp.A[k] && A_factored_[k] != A_factored_[k]))
+                throw std::invalid_argument("QPSolver::solve: A differs from the A of the preceding setup()/update_qp(); call update_qp()");
         if (settings_.verbose) settings_.print();  // QP_SOLVER_PRINTING, src/qp.cpp:72-76
         push(true);
         impl_->solve(impl_->packed(1, qp.P, qp.q, qp.A, qp.l, qp.u));
@@ -406,6 +415,7 @@ class QPSolver {
     Info info_;
     Vector x_, y_;
     std::vector<Scalar> x_seen_, y_seen_;
+    std::vector<Scalar> A_factored_;  // the A the resident factor was built from (solve() checks its argument against it)
 };
 
 }  // namespace supported

@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/sqp_hip/qp.hpp"
 
@@ -51,6 +53,26 @@ static void testSimpleQP() {
     CHECK(solver.info().iter < solver.settings().max_iter);
     CHECK(solver.info().status == SOLVED);
     CHECK(solver.info().iter == 125);  // oracle-pinned
+}
+static void testSolveWithAnotherAIsRejected() {  // src/qp.cpp:319-331: the reference would iterate on setup()'s A; here the call is refused
+    SimpleQP<double> qp;
+    QPSolver<double> solver;
+    solver.setup(qp);
+    solver.solve(qp);
+    qp.ld[1] = -0.1;  // q, l, u may change between setup() and solve() (src/qp.cpp:89,100)
+    solver.solve(qp);
+    CHECK(solver.info().status == SOLVED);
+    qp.Ad[3] = 2.0;
+    bool thrown = false;
+    try {
+        solver.solve(qp);
+    } catch (const std::invalid_argument &) {
+        thrown = true;
+    }
+    CHECK(thrown);
+    solver.update_qp(qp);  // the call that takes a new A
+    solver.solve(qp);
+    CHECK(solver.info().status == SOLVED);
 }
 static void testVerboseTrace() {  // QP_SOLVER_PRINTING: settings, "iter obj rp rd" table at every check, info (src/qp.cpp:72-76,113-117,152-156)
     SimpleQP<double> qp;
@@ -177,10 +199,50 @@ static void testSparseCsr() {  // tests/qp_solver_sparse_test.cpp:34-98 through 
     CHECK(is_approx(prob.primal_solution(0), sol2, 2, 1e-2) && prob.info(0).status == SOLVED);
 }
 
+// distinct handles may be driven from distinct host threads.  Two threads, each with a handle of its own (own
+// stream, own state), solve different batches 40 times concurrently; every result must equal the same solve done alone.  The
+// process-wide error channel is per thread: a failing sqph_create on each thread reports that thread's arguments.
+static void twoThreadWorker(int id, std::vector<double> *out, std::string *err) {
+    const int B = 192 + 64 * id;
+    BatchQPSolver<double> solver(2, 3, B);
+    SimpleQP<double> qp;
+    std::vector<double> q(2 * B), l(3 * B), u(3 * B);
+    for (int b = 0; b < B; b++) {
+        q[2 * b] = 1 + 0.001 * b + 0.5 * id; q[2 * b + 1] = 1 - 0.25 * id;
+        for (int i = 0; i < 3; i++) { l[3 * b + i] = qp.ld[i]; u[3 * b + i] = qp.ud[i]; }
+    }
+    auto batch = solver.packed(B, qp.Pd, q.data(), qp.Ad, l.data(), u.data());
+    batch.stride_P = 0;
+    batch.stride_A = 0;
+    for (int rep = 0; rep < 40; rep++) {
+        solver.setup_solve(batch);
+        sqph_solver *bad = nullptr;
+        CHECK(sqph_create(&bad, 0, -(7 + id), 3, 1, SQPH_F64, 0) != SQPH_OK && bad == nullptr);  // (writes the thread's error string)
+    }
+    *err = sqph_global_error();
+    out->resize(2 * B);
+    for (int b = 0; b < B; b++) { (*out)[2 * b] = solver.primal_solution(b)[0]; (*out)[2 * b + 1] = solver.primal_solution(b)[1]; }
+}
+static void testTwoHostThreadsTwoHandles() {
+    std::vector<double> alone[2], together[2];
+    std::string e_alone[2], e_together[2];
+    for (int id = 0; id < 2; id++) twoThreadWorker(id, &alone[id], &e_alone[id]);
+    std::thread t0(twoThreadWorker, 0, &together[0], &e_together[0]), t1(twoThreadWorker, 1, &together[1], &e_together[1]);
+    t0.join();
+    t1.join();
+    for (int id = 0; id < 2; id++) {
+        CHECK(alone[id].size() == together[id].size() && !alone[id].empty());
+        for (size_t k = 0; k < alone[id].size(); k++) CHECK(alone[id][k] == together[id][k]);  // bit-identical
+        CHECK(e_together[id] == e_alone[id]);
+        CHECK(e_together[id].find(id == 0 ? "n=-7" : "n=-8") != std::string::npos);
+    }
+}
+
 int main() {
     try {
         TestConstraint();  // host-only, no device needed
         testSimpleQP();
+        testSolveWithAnotherAIsRejected();
         testVerboseTrace();
         testSinglePrecisionFloat();
         testConstraintViolation();
@@ -189,6 +251,7 @@ int main() {
         testLegacyFixedSize();
         testBatch();
         testSparseCsr();
+        testTwoHostThreadsTwoHandles();
     } catch (const std::runtime_error &e) {
         if (std::string(e.what()).find("no HIP device") != std::string::npos) {
             fprintf(stderr, "no HIP device: %s\n", e.what());

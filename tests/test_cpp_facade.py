@@ -16,7 +16,7 @@ def build():
     _capi.load()
     lib = _capi.lib_path()
     libdir = os.path.dirname(lib)
-    cmd = ["g++", "-std=c++14", "-O1", "-o", EXE, SRC, lib, "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = ["g++", "-std=c++14", "-O1", "-pthread", "-o", EXE, SRC, lib, "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return EXE
 

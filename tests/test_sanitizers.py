@@ -38,7 +38,7 @@ def test_facade_host_side_under_asan_ubsan():
     import torch
 
     exe = os.path.join(CPP, "qp_facade_test_san.bin")
-    subprocess.check_call(["g++", "-std=c++14"] + SAN + ["-o", exe, os.path.join(CPP, "qp_facade_test.cpp")] + _link())
+    subprocess.check_call(["g++", "-std=c++14", "-pthread"] + SAN + ["-o", exe, os.path.join(CPP, "qp_facade_test.cpp")] + _link())
     p = _run(exe, leaks=False)
     assert p.returncode == (0 if torch.cuda.is_available() else 3), (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
     assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr
