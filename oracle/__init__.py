@@ -79,41 +79,62 @@ def build(force=False):
     return _LIB_PATH
 
 
+def _bind(_lib):
+    _lib.qpo_default_settings.argtypes = [ctypes.POINTER(Settings)]
+    _lib.qpo_max_threads.restype = ctypes.c_int
+    for sfx, ct in (("_f64", ctypes.c_double), ("_f32", ctypes.c_float), ("_f80", ctypes.c_longdouble)):
+        p = ctypes.POINTER(ct)
+        pi = ctypes.POINTER(ctypes.c_int)
+        g = lambda name: getattr(_lib, name + sfx)  # noqa: E731
+        g("qpo_create").restype = ctypes.c_void_p
+        g("qpo_destroy").argtypes = [ctypes.c_void_p]
+        g("qpo_settings_ptr").restype = ctypes.POINTER(Settings)
+        g("qpo_settings_ptr").argtypes = [ctypes.c_void_p]
+        g("qpo_info_ptr").restype = ctypes.POINTER(Info)
+        g("qpo_info_ptr").argtypes = [ctypes.c_void_p]
+        g("qpo_set_legacy_cold_start").argtypes = [ctypes.c_void_p, ctypes.c_int]
+        for name in ("qpo_primal", "qpo_dual", "qpo_z", "qpo_rho_vec"):
+            g(name).restype = p
+            g(name).argtypes = [ctypes.c_void_p]
+        g("qpo_constr_type").restype = pi
+        g("qpo_constr_type").argtypes = [ctypes.c_void_p]
+        g("qpo_set_state").argtypes = [ctypes.c_void_p, p, p, p]
+        g("qpo_constr_type_init").argtypes = [ctypes.c_int, p, p, pi]
+        g("qpo_setup").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, p, p, p, p, p]
+        g("qpo_update_qp").argtypes = [ctypes.c_void_p, p, p, p, p, p]
+        g("qpo_solve").argtypes = [ctypes.c_void_p, p, p, p, p, p]
+        g("qpo_solve_batch").argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, p, p, p, p, p,
+            ctypes.POINTER(Settings), p, p, p, ctypes.POINTER(Info), ctypes.c_int,
+        ]
+        g("qpo_ldlt_factor_solve").restype = ctypes.c_int
+        g("qpo_ldlt_factor_solve").argtypes = [ctypes.c_int, p, p, pi, p]
+    return _lib
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_LIB_PATH)
-        _lib.qpo_default_settings.argtypes = [ctypes.POINTER(Settings)]
-        _lib.qpo_max_threads.restype = ctypes.c_int
-        for sfx, ct in (("_f64", ctypes.c_double), ("_f32", ctypes.c_float), ("_f80", ctypes.c_longdouble)):
-            p = ctypes.POINTER(ct)
-            pi = ctypes.POINTER(ctypes.c_int)
-            g = lambda name: getattr(_lib, name + sfx)  # noqa: E731
-            g("qpo_create").restype = ctypes.c_void_p
-            g("qpo_destroy").argtypes = [ctypes.c_void_p]
-            g("qpo_settings_ptr").restype = ctypes.POINTER(Settings)
-            g("qpo_settings_ptr").argtypes = [ctypes.c_void_p]
-            g("qpo_info_ptr").restype = ctypes.POINTER(Info)
-            g("qpo_info_ptr").argtypes = [ctypes.c_void_p]
-            g("qpo_set_legacy_cold_start").argtypes = [ctypes.c_void_p, ctypes.c_int]
-            for name in ("qpo_primal", "qpo_dual", "qpo_z", "qpo_rho_vec"):
-                g(name).restype = p
-                g(name).argtypes = [ctypes.c_void_p]
-            g("qpo_constr_type").restype = pi
-            g("qpo_constr_type").argtypes = [ctypes.c_void_p]
-            g("qpo_set_state").argtypes = [ctypes.c_void_p, p, p, p]
-            g("qpo_constr_type_init").argtypes = [ctypes.c_int, p, p, pi]
-            g("qpo_setup").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, p, p, p, p, p]
-            g("qpo_update_qp").argtypes = [ctypes.c_void_p, p, p, p, p, p]
-            g("qpo_solve").argtypes = [ctypes.c_void_p, p, p, p, p, p]
-            g("qpo_solve_batch").argtypes = [
-                ctypes.c_int, ctypes.c_int, ctypes.c_int, p, p, p, p, p,
-                ctypes.POINTER(Settings), p, p, p, ctypes.POINTER(Info), ctypes.c_int,
-            ]
-            g("qpo_ldlt_factor_solve").restype = ctypes.c_int
-            g("qpo_ldlt_factor_solve").argtypes = [ctypes.c_int, p, p, pi, p]
+        _lib = _bind(ctypes.CDLL(_LIB_PATH))
     return _lib
+
+
+_native = None
+
+
+def native_lib():
+    """The timing copy built with -O3 -march=native ON THIS MACHINE (oracle/Makefile: libqp_oracle_native.so), or None when it cannot
+    be built here.  Only bench.py's cpu_baseline leg asks for it; same sources, same results (no -ffast-math, no contraction)."""
+    global _native
+    if _native is None:
+        path = os.path.join(_HERE, "libqp_oracle_native.so")
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libqp_oracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _native = _bind(ctypes.CDLL(path))
+        except Exception:  # noqa: BLE001
+            _native = False
+    return _native or None
 
 
 def default_settings(**kw):
@@ -238,7 +259,7 @@ def constr_type_init(l, u, dtype=np.float64):
     return out
 
 
-def solve_batch(P, q, A, l, u, settings=None, nthreads=0, dtype=np.float64):
+def solve_batch(P, q, A, l, u, settings=None, nthreads=0, dtype=np.float64, native=False):
     """setup()+solve() for every QP of a batch (cold start, fresh solver each).
 
     Layout: P[b] (n,n), A[b] (m,n) as numpy arrays indexed [b, i, j]; they are
@@ -261,7 +282,8 @@ def solve_batch(P, q, A, l, u, settings=None, nthreads=0, dtype=np.float64):
     info = np.zeros(B, dtype=INFO_DTYPE)
     if settings is None:
         settings = default_settings()
-    getattr(lib(), "qpo_solve_batch" + sfx)(
+    L = (native_lib() if native else None) or lib()  # native: the -O3 -march=native timing copy where it can be built
+    getattr(L, "qpo_solve_batch" + sfx)(
         n, m, B, _ptr(Pc, ct), _ptr(q, ct), _ptr(Ac, ct), _ptr(l, ct), _ptr(u, ct),
         ctypes.byref(settings), _ptr(x, ct), _ptr(y, ct), _ptr(z, ct),
         info.ctypes.data_as(ctypes.POINTER(Info)), int(nthreads),

@@ -340,10 +340,30 @@ static int SFX(factorize_KKT)(SFX(qpo_solver) * s) {
 void SFX(qpo_setup)(SFX(qpo_solver) * s, int n, int m, const SCALAR *P, const SCALAR *q,
                     const SCALAR *A, const SCALAR *l, const SCALAR *u) {
     (void)q;
+    const int N = n + m;
+    if (s->x && s->n == n && s->m == m && s->lin.mat && s->lin.size == N) {
+        /* same shape as the last set-up of this object (the batched driver, one object per thread): the arrays are cleared in
+         * place instead of freed and calloc'ed again — the same zero-initialised state, none of the allocator traffic (two of
+         * the arrays are beyond glibc's mmap threshold at n = 50, m = 100: every QP page-faulted them in under the process lock) */
+        memset(s->x, 0, sizeof(SCALAR) * (size_t)(n > 0 ? n : 1));
+        memset(s->z, 0, sizeof(SCALAR) * (size_t)(m > 0 ? m : 1));
+        memset(s->y, 0, sizeof(SCALAR) * (size_t)(m > 0 ? m : 1));
+        memset(s->x_tilde, 0, sizeof(SCALAR) * (size_t)(n > 0 ? n : 1));
+        memset(s->z_tilde, 0, sizeof(SCALAR) * (size_t)(m > 0 ? m : 1));
+        memset(s->z_prev, 0, sizeof(SCALAR) * (size_t)(m > 0 ? m : 1));
+        memset(s->rho_vec, 0, sizeof(SCALAR) * (size_t)(m > 0 ? m : 1));
+        memset(s->rho_inv_vec, 0, sizeof(SCALAR) * (size_t)(m > 0 ? m : 1));
+        memset(s->rhs, 0, sizeof(SCALAR) * (size_t)(N > 0 ? N : 1));
+        memset(s->x_tilde_nu, 0, sizeof(SCALAR) * (size_t)(N > 0 ? N : 1));
+        memset(s->constr_type, 0, sizeof(int) * (size_t)(m > 0 ? m : 1));
+        memset(s->kkt, 0, sizeof(SCALAR) * (size_t)(N > 0 ? N : 1) * (size_t)(N > 0 ? N : 1));
+        memset(s->tmp_n, 0, sizeof(SCALAR) * (size_t)(n > 0 ? n : 1));
+        memset(s->tmp_m, 0, sizeof(SCALAR) * (size_t)(m > 0 ? m : 1));
+        s->lin.ok = 0;
+    } else {
     SFX(free_state)(s);
     s->n = n;
     s->m = m;
-    const int N = n + m;
     s->x = (SCALAR *)calloc((size_t)(n > 0 ? n : 1), sizeof(SCALAR));
     s->z = (SCALAR *)calloc((size_t)(m > 0 ? m : 1), sizeof(SCALAR));
     s->y = (SCALAR *)calloc((size_t)(m > 0 ? m : 1), sizeof(SCALAR));
@@ -359,6 +379,7 @@ void SFX(qpo_setup)(SFX(qpo_solver) * s, int n, int m, const SCALAR *P, const SC
     s->tmp_n = (SCALAR *)calloc((size_t)(n > 0 ? n : 1), sizeof(SCALAR));
     s->tmp_m = (SCALAR *)calloc((size_t)(m > 0 ? m : 1), sizeof(SCALAR));
     SFX(ldlt_alloc)(&s->lin, N);
+    }
 
     SFX(qpo_constr_type_init)(m, l, u, s->constr_type);
     SFX(rho_vec_update)(s, (SCALAR)s->settings.rho);

@@ -91,11 +91,12 @@ def test_bench_spawned_path_runs_the_rccl_gather():
     assert d["config"]["gather"] is True and d["config"]["global_batch"] == 1023 and d["scaling"] == "strong"
 
 
-EXTRA_KEYS = ("c2", "c3_default", "c3_sqp", "c3_whole_65536", "c5")
+EXTRA_KEYS_R4 = ("c2", "c3_default", "c3_sqp", "c3_whole_65536", "c5")  # round 4: the 8,192-QP shard was the headline
+EXTRA_KEYS = ("c2", "c3_default", "c3_sqp", "c3_shard_8192", "c5")  # round 5 on: the whole 65,536 batch is
 
 
-def check_extra(ex):
-    for k in EXTRA_KEYS:
+def check_extra(ex, keys=EXTRA_KEYS):
+    for k in keys:
         e = ex[k]
         for f in ("workload", "ms_per_step", "kernel_ms_avg", "value", "frac", "traffic", "kernel", "algorithmic_bytes_per_qp", "parity"):
             assert f in e, (k, f)
@@ -114,7 +115,7 @@ def test_recorded_default_line_carries_every_baseline_config():
     with_extra = [d for d in lines if "extra" in d]
     assert with_extra, "the default line of the round carries `extra`"
     for d in with_extra:
-        check_extra(d["extra"])
+        check_extra(d["extra"], EXTRA_KEYS_R4)
 
 
 @pytest.mark.gpu
@@ -125,4 +126,9 @@ def test_default_bench_line_has_the_extra_configs():
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     for k in REQUIRED:
         assert k in d, k
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 65536 and d["config"]["batch_per_gpu"] == 65536
     check_extra(d["extra"])
+    pc = d["pcie_inclusive"]
+    assert pc["value"] > 0 and pc["value"] < d["value"] and pc["batch"] == 8192
+    c = d["cpu_baseline"]
+    assert c["threads_over_one_thread"] > 0 and "build" in c
