@@ -201,7 +201,30 @@ def extra_configs(dev, c3_data):
     P, q, rp, ci, v, l, u, A_dense, nnz_avg = bench_csr.make(8192, 200, 400, 0.05, 20250228 + 5, dev)
     out["c5"] = extra_line("configs[4]", 200, 400, 8192, "fixed", (P, q, None, l, u), dev, steps=3, warmup=1, csr=(rp, ci, v),
                            nnz_avg=nnz_avg, oracle_k=64, A_dense=A_dense)
+    del P, q, rp, ci, v, l, u, A_dense
+    torch.cuda.empty_cache()
+    out["c4"] = sqp_driver_line()
     return out
+
+
+def sqp_driver_line():
+    """configs[3]: the batched SQP host driver (include/sqp_hip/sqp.hpp, C++) on 1,024 SimpleNLP instances — measured by the test
+    binary's `bench` mode (tests/cpp/sqp_batch_test.bin, built by __graft_entry__.build() / tests/test_cpp_sqp.py): wall per batch
+    with the reference's cold subproblems and with sqp_settings_t::warm_start_qp, launches, ADMM iterations, end points equal to the
+    serial CPU oracle's."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "tests", "cpp", "sqp_batch_test.bin")
+    if not os.path.exists(exe):
+        return {"error": "tests/cpp/sqp_batch_test.bin not built"}
+    try:
+        p = subprocess.run([exe, "bench"], capture_output=True, text=True, timeout=300)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": "sqp_batch_test.bin bench failed (rc %d): %s" % (p.returncode, (p.stderr or p.stdout)[-300:])}
+        return json.loads(line[0])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def main():

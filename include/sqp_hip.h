@@ -17,6 +17,7 @@
  *   QPSolver::update_qp(qp)       src/qp.cpp:46-62                 sqph_update_qp
  *   QPSolver::solve(qp)           src/qp.cpp:64-157                sqph_solve
  *   setup(qp); solve(qp)          src/sqp.cpp:221-222 (run_solve_qp) sqph_setup_solve (one launch)
+ *   update_qp(qp); solve(qp)      src/qp.cpp:46-62, 64-157         sqph_update_solve (one launch, iterates kept)
  *   primal_solution()/dual_solution()/info()  qp.hpp:160-170       sqph_get_solution / sqph_device_state
  *   settings()                    qp.hpp:166-167                   sqph_set_settings / sqph_get_settings
  *   static constr_type_init(l,u,type)  src/qp.cpp:283-294          sqph_constr_type_init (host utility)
@@ -196,6 +197,11 @@ int sqph_setup_solve(sqph_solver *s, const sqph_qp_batch *qp); /* setup()+solve(
  * skipped for every QP whose rho vector comes out equal to the one the resident factor was built with.  Needs the factor
  * resident (SQPH_FLAG_KEEP_FACTOR, or a preceding sqph_setup/sqph_update_qp); otherwise identical to sqph_setup_solve. */
 int sqph_setup_solve_reuse(sqph_solver *s, const sqph_qp_batch *qp);
+/* update_qp()+solve() in one launch: the constraints are re-classified, rho goes back to settings.rho and the factor is rebuilt as
+ * in sqph_update_qp (src/qp.cpp:46-62), the iterates x, z, y of every QP are KEPT and the solve starts from them — the route the
+ * reference intends for successive subproblems (its SQP driver sets warm_start = true, src/sqp.cpp:16, and then defeats it by
+ * calling setup(), src/sqp.cpp:221 / src/qp.cpp:16-18).  sqp::BatchSQP uses it when sqp_settings_t::warm_start_qp is set. */
+int sqph_update_solve(sqph_solver *s, const sqph_qp_batch *qp);
 
 /* CSR-A variants of the four calls above (legacy sparse QPSolver, unsupported/qp_solver.hpp:215-330). */
 int sqph_setup_csr(sqph_solver *s, const sqph_csr_batch *qp);

@@ -177,6 +177,8 @@ class BatchQPSolver {
     // the same for QPs whose P and A are those of the previous setup (only q, l, u differ — the SQP second-order correction,
     // src/sqp.cpp:244-276): the resident factor is reused where the rho vector did not move (create with SQPH_FLAG_KEEP_FACTOR)
     void setup_solve_reuse(const Batch &b) { call(sqph_setup_solve_reuse, b, "sqph_setup_solve_reuse"); }
+    // update_qp() + solve() in one launch: the iterates of the previous call are the starting point (src/qp.cpp:46-62)
+    void update_solve(const Batch &b) { call(sqph_update_solve, b, "sqph_update_solve"); }
 
     // The same calls with the constraint matrices in CSR (legacy sparse class, unsupported/qp_solver.hpp:17-32; BASELINE
     // config 5).  Per-QP arrays: rowptr [m+1], colind/val [nnz_max]; packed_csr lays QPs back to back.

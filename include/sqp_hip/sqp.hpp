@@ -60,6 +60,13 @@ struct sqp_settings_t {
     int max_iter = 100;
     int line_search_max_iter = 20;
     bool second_order_correction = false;
+    // NOT in the reference's struct.  Off (default): every QP subproblem is set up from scratch (x, z, y zeroed) exactly as the
+    // reference's run_solve_qp does — setup(); solve(), src/sqp.cpp:221-222 — and the trajectories are the reference's.  On: from the
+    // second outer iteration on the subproblems go through update_qp(); solve() (src/qp.cpp:46-62), i.e. the ADMM iterates of an
+    // instance's previous subproblem are the starting point of its next one — what the reference's `warm_start = true`
+    // (src/sqp.cpp:16) asks for and its setup() call undoes.  Fewer ADMM iterations per outer iteration; the iterates differ from
+    // the reference's within the subproblems' tolerance (eps 1e-4), the known answers are reached all the same.
+    bool warm_start_qp = false;
 };
 
 typedef enum { SOLVED, MAX_ITER_EXCEEDED, INVALID_SETTINGS } Status;
@@ -229,6 +236,7 @@ class BatchSQP {
     void set_host_threads(int threads) { pool_.resize(threads); }
     int host_threads() const { return pool_.threads(); }
     qp_solver::QPSolverSettings<Scalar> &qp_settings() { return qp_.settings(); }
+    QPBackend &qp_backend() { return qp_; }
 
     // probs[i] is the NLP of instance i (several entries may point to one stateless object).
     // X0: [batch][num_var], Lambda0: [batch][num_constr] (nullptr = zeros, as SQP::solve(prob) does).
@@ -242,6 +250,9 @@ class BatchSQP {
             I.info = Info();
             live.push_back(i);
         }
+        // warm-started subproblems keep their state in the QP backend by SLOT: instance i stays in slot i for the whole solve
+        // (finished instances are not compacted out; their slot is re-solved from its own solution, which ends at the first check)
+        const bool warm = settings_.warm_start_qp;
         int iter;
         for (iter = 1; iter <= settings_.max_iter && !live.empty(); iter++) {
             // ---- solve_qp (src/sqp.cpp:139-199) for every live instance: build the QP on the host ...
@@ -276,11 +287,11 @@ class BatchSQP {
                     I.ql[a] = I.l[a] - I.constr[a];
                     I.qu[a] = I.u[a] - I.constr[a];
                 }
-                pack(k, I);
+                pack(warm ? (size_t)live[k] : k, I);
             }
             });
             // ---- ... and run_solve_qp (src/sqp.cpp:210-242) for all of them in one launch
-            run_qp(live);
+            run_qp(live, false, warm, iter == 1);
             if (settings_.second_order_correction) {  // src/sqp.cpp:244-276
                 phase((int)live.size(), [&](int k_lo, int k_hi) {
                 for (size_t k = (size_t)k_lo; k < (size_t)k_hi; k++) {
@@ -295,10 +306,10 @@ class BatchSQP {
                         I.ql[a] = I.l[a] - d;
                         I.qu[a] = I.u[a] - d;
                     }
-                    pack(k, I);
+                    pack(warm ? (size_t)live[k] : k, I);
                 }
                 });
-                run_qp(live, /*same_matrices=*/true);
+                run_qp(live, /*same_matrices=*/true, warm, false);
             }
             // ---- step, line search, termination (src/sqp.cpp:76-96)
             std::vector<int> still;
@@ -383,21 +394,24 @@ class BatchSQP {
         std::copy(I.ql.begin(), I.ql.begin() + m, l_.begin() + k * m);
         std::copy(I.qu.begin(), I.qu.begin() + m, u_.begin() + k * m);
     }
-    void run_qp(const std::vector<int> &live, bool same_matrices = false) {
+    void run_qp(const std::vector<int> &live, bool same_matrices = false, bool warm = false, bool first = true) {
         const auto t0 = std::chrono::steady_clock::now();
-        const auto batch = qp_.packed((int)live.size(), P_.data(), q_.data(), A_.data(), l_.data(), u_.data());
-        if (same_matrices) qp_.setup_solve_reuse(batch);  // P, A of the call before (same live set, same order): factor reuse
+        // warm: every slot of the batch (slot = instance), cold set-up only in the first outer iteration
+        const auto batch = qp_.packed(warm ? batch_ : (int)live.size(), P_.data(), q_.data(), A_.data(), l_.data(), u_.data());
+        if (warm && !first) qp_.update_solve(batch);
+        else if (same_matrices && !warm) qp_.setup_solve_reuse(batch);  // P, A of the call before (same live set, same order): factor reuse
         else qp_.setup_solve(batch);
         (void)qp_.info(0);  // fetch the results (one packed D2H)
         qp_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         launches_++;
         for (size_t k = 0; k < live.size(); k++) {
             Inst &I = inst_[live[k]];
-            const auto &qi = qp_.info((int)k);
+            const int slot = warm ? live[k] : (int)k;
+            const auto &qi = qp_.info(slot);
             I.info.qp_solver_iter += qi.iter;
             if (qi.status == qp_solver::NUMERICAL_ISSUES) continue;  // prim/dual left untouched, src/sqp.cpp:226-229
-            for (int a = 0; a < n_; a++) I.p[a] = qp_.primal_solution((int)k)[a];
-            for (int a = 0; a < m_; a++) I.p_lambda[a] = qp_.dual_solution((int)k)[a];
+            for (int a = 0; a < n_; a++) I.p[a] = qp_.primal_solution(slot)[a];
+            for (int a = 0; a < m_; a++) I.p_lambda[a] = qp_.dual_solution(slot)[a];
         }
     }
     // Eigen::LLT-style test, src/sqp.cpp:115-122

@@ -23,6 +23,7 @@ SYMBOLS = [
     "sqph_setup_csr", "sqph_update_qp_csr", "sqph_solve_csr", "sqph_setup_solve_csr",
     "sqph_shard_bounds", "sqph_device_count", "sqph_own_stream", "sqph_gather_create", "sqph_gather_create_ex", "sqph_gather_transport", "sqph_gather_destroy",
     "sqph_gather_post", "sqph_gather_fetch", "sqph_gather_device_ptrs", "sqph_setup_solve_reuse", "sqph_set_trace_qp", "sqph_get_trace",
+    "sqph_update_solve",
 ]
 
 
@@ -107,7 +108,7 @@ def load(build_if_missing=True):
     L.sqph_set_stream.argtypes = [vp, vp]
     L.sqph_set_settings.argtypes = [vp, ctypes.POINTER(Settings)]
     L.sqph_get_settings.argtypes = [vp, ctypes.POINTER(Settings)]
-    for name in ("sqph_setup", "sqph_update_qp", "sqph_solve", "sqph_setup_solve"):
+    for name in ("sqph_setup", "sqph_update_qp", "sqph_solve", "sqph_setup_solve", "sqph_update_solve"):
         getattr(L, name).argtypes = [vp, ctypes.POINTER(QPBatch)]
     for name in ("sqph_setup_csr", "sqph_update_qp_csr", "sqph_solve_csr", "sqph_setup_solve_csr"):
         getattr(L, name).argtypes = [vp, ctypes.POINTER(CsrBatch)]

@@ -1262,6 +1262,9 @@ int sqph_solve(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph
 int sqph_setup_solve(sqph_solver *s, const sqph_qp_batch *qp) {
     return run(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE, "sqph_setup_solve");
 }
+int sqph_update_solve(sqph_solver *s, const sqph_qp_batch *qp) {
+    return run(s, qp, sqph::MODE_UPDATE | sqph::MODE_SOLVE, "sqph_update_solve");
+}
 int sqph_setup_solve_reuse(sqph_solver *s, const sqph_qp_batch *qp) {
     return run(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE | sqph::MODE_SAME_MATRICES, "sqph_setup_solve_reuse");
 }

@@ -212,6 +212,10 @@ class QPSolverBatch:
         """setup(); solve() in one kernel launch (what SQP::run_solve_qp does, src/sqp.cpp:221-222)."""
         self._call(self._L.sqph_setup_solve, "sqph_setup_solve", P, q, A, l, u, colmajor)
 
+    def update_solve(self, P, q, A, l, u, colmajor=False):
+        """update_qp(); solve() in one launch: new matrices and bounds, the iterates of the previous call kept (src/qp.cpp:46-62)."""
+        self._call(self._L.sqph_update_solve, "sqph_update_solve", P, q, A, l, u, colmajor)
+
     def set_trace_qp(self, index):
         self._check(self._L.sqph_set_trace_qp(self._h, int(index)), "sqph_set_trace_qp")
 

@@ -372,7 +372,7 @@ def warm_start_and_resolve(make, n=8, m=12, batch=4, **kw):
     l2, u2 = l - 0.05, u + 0.05
     s.solve(P, q2, A, l2, u2)
     x, y, z, info = s.solution()
-    xs, ys = [], []
+    xs, ys, os_ = [], [], []
     for b in range(batch):
         o = oracle.QPSolver()
         o.settings.max_iter = 40
@@ -382,8 +382,23 @@ def warm_start_and_resolve(make, n=8, m=12, batch=4, **kw):
         o.solve(P[b], q2[b], A[b], l2[b], u2[b])
         xs.append(o.primal_solution())
         ys.append(o.dual_solution())
+        os_.append(o)
         assert o.info.rho_updates == info.rho_updates[b] == 1
     assert relerr(x, np.array(xs)) < TOL_F64 and relerr(y, np.array(ys)) < TOL_F64
+    if hasattr(s, "update_solve"):
+        # update_qp(); solve() in one launch (sqph_update_solve; src/qp.cpp:46-62 then 64-157): new matrices, iterates kept
+        P3 = 0.8 * P + 0.1 * np.eye(n)[None]
+        A3 = 1.1 * A
+        s.update_solve(P3, q2, A3, l2, u2)
+        x, y, z, info = s.solution()
+        xs, ys = [], []
+        for b, o in enumerate(os_):
+            o.update_qp(P3[b], q2[b], A3[b], l2[b], u2[b])
+            o.solve(P3[b], q2[b], A3[b], l2[b], u2[b])
+            xs.append(o.primal_solution())
+            ys.append(o.dual_solution())
+            assert o.info.rho_updates == info.rho_updates[b] == 2 and o.info.status == info.status[b] and o.info.iter == info.iter[b]
+        assert relerr(x, np.array(xs)) < TOL_F64 and relerr(y, np.array(ys)) < TOL_F64
 
 
 def solve_with_other_P(make, n=8, m=12, batch=4, **kw):

@@ -153,6 +153,9 @@ class SimSolverBatch:
     def setup_solve(self, P, q, A, l, u):
         self._run(MODE_SETUP | MODE_SOLVE, P, q, A, l, u)
 
+    def update_solve(self, P, q, A, l, u):
+        self._run(MODE_UPDATE | MODE_SOLVE, P, q, A, l, u)
+
     def setup_solve_reuse(self, P, q, A, l, u):
         self._run(MODE_SETUP | MODE_SOLVE | MODE_SAME_MATRICES, P, q, A, l, u)
 
@@ -164,6 +167,9 @@ class SimSolverBatch:
 
     def solve_csr(self, P, q, rp, ci, v, l, u):
         self._run(MODE_SOLVE, P, q, None, l, u, csr=(rp, ci, v))
+
+    def update_solve_csr(self, P, q, rp, ci, v, l, u):
+        self._run(MODE_UPDATE | MODE_SOLVE, P, q, None, l, u, csr=(rp, ci, v))
 
     def setup_solve_csr(self, P, q, rp, ci, v, l, u):
         self._run(MODE_SETUP | MODE_SOLVE, P, q, None, l, u, csr=(rp, ci, v))

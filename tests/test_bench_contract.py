@@ -104,6 +104,12 @@ def check_extra(ex, keys=EXTRA_KEYS):
         p = e["parity"]
         assert p["max_rel_err_x"] < 1e-6 and p["max_rel_err_y"] < 1e-6 and p["status_equal"] and p["iter_equal"], (k, p)
     assert "needed_bytes_per_qp" in ex["c5"] and ex["c5"]["frac_needed"] <= ex["c5"]["frac"]
+    if keys is EXTRA_KEYS:  # configs[3], the batched SQP driver: cold (the reference's trajectories) and with warm-started subproblems
+        c4 = ex["c4"]
+        assert "error" not in c4, c4
+        assert c4["instances"] == 1024 and c4["ms_per_batch"] > 0 and c4["launches"] > 0 and c4["strict_parity_with_serial_oracle"] >= 0.85 * 1024
+        w = c4["warm_start_qp"]
+        assert w["sum_qp_iter"] < c4["sum_qp_iter"] and w["solved"] >= c4["solved"] - 32 and w["ms_per_batch"] < c4["ms_per_batch"]
 
 
 def test_recorded_default_line_carries_every_baseline_config():

@@ -48,6 +48,14 @@ def test_batch_sqp_host_driver_is_bit_exact_with_the_oracle_qp_backend():
     assert "exact cases passed" in p.stdout
 
 
+def test_batch_sqp_warm_started_subproblems_reach_the_known_answers_with_the_oracle_backend():
+    """sqp_settings_t::warm_start_qp (update_qp(); solve() from the second outer iteration on, src/qp.cpp:46-62) over the oracle QP
+    backend: the known answers of the reference's SQP tests, TestRosenbrock2 asserted in the state the source explains"""
+    p = subprocess.run([build(), "warm-oracle"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "warm oracle cases passed" in p.stdout and p.stdout.count("known answer REACHED") == 7
+
+
 def test_batch_sqp_refuses_without_device():
     import torch
 

@@ -146,6 +146,9 @@ class _DenseAsCsr(simlib.SimSolverBatch):
     def setup_solve(self, P, q, A, l, u):
         self.setup_solve_csr(P, q, *self._csr(A), l, u)
 
+    def update_solve(self, P, q, A, l, u):
+        self.update_solve_csr(P, q, *self._csr(A), l, u)
+
 
 def make_csrb_dense_A(n, m, batch, dtype=np.float64, **kw):
     return _DenseAsCsr(n, m, batch, dtype=dtype, variant=simlib.CSRB, **kw)
