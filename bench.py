@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL gather of results (N>1)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the `extra` object (the other BASELINE configs, measured after the headline; default run at N=1 only)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend: nccl (= RCCL over xGMI, the product path) or gloo with every rank on device 0 — the N > 1 "
+                         "code path (rank seeds, shard bounds, padded gather, rank 0's re-solve check of every rank's shard) with real "
+                         "kernels on a ONE-GPU box, where RCCL refuses two ranks on one device (tests/test_bench_contract.py)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (the N>1 code path — process group, "
                          "RCCL gather — on one device); --gpus N > 1 without RANK in the environment always does")
@@ -69,6 +73,8 @@ def self_launch(args):
     import torch
 
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.backend == "gloo" and have >= 1:
+        have = args.gpus  # every rank shares device 0
     if have < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible (there is no CPU path and no over-subscription)" % (args.gpus, have))
     with socket.socket() as sk:
@@ -244,6 +250,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (torch.distributed.run --nproc-per-node %d), or "
                          "run bench.py without a launcher and let it start them" % (args.gpus, world, args.gpus))
+    if args.backend == "gloo":
+        local_rank = 0  # every rank on device 0 (the gloo leg exists for one-GPU boxes)
     if torch.cuda.is_available() and local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d: local rank %d but only %d HIP device(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     if not torch.cuda.is_available():
@@ -259,7 +267,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cdev = torch.device("cpu") if args.backend == "gloo" else dev  # where the few scalar collectives of this script live
 
     if args.workload == "c2":
         args.n, args.m, args.batch_per_gpu = 20, 40, 4096
@@ -341,7 +353,7 @@ def main():
     solver.enable_timing(False)
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -368,8 +380,8 @@ def main():
                 torch.cuda.synchronize()
             gather_ms = (time.perf_counter() - t0) / dsteps * 1e3
         kavg = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        per = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(per, torch.tensor([kavg, solve_ms, gather_ms if gather_ms is not None else float("nan")], dtype=torch.float64, device=dev))
+        per = [torch.zeros(3, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([kavg, solve_ms, gather_ms if gather_ms is not None else float("nan")], dtype=torch.float64, device=cdev))
         multi = {
             "rccl_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
             "kernel_ms_avg_per_rank": [float(p[0]) for p in per],
@@ -383,7 +395,7 @@ def main():
     iters_local = int(np.minimum(info.iter, st.max_iter).sum())
     n_solved = int((info.status == 0).sum())
     if use_dist:
-        t = torch.tensor([iters_local, n_solved], dtype=torch.float64, device=dev)
+        t = torch.tensor([iters_local, n_solved], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         iters_total, solved_total = int(t[0].item()), int(t[1].item())
     else:
@@ -488,8 +500,8 @@ def main():
         if gather_bufs is not None and rank == 0:
             # sanity: the gathered record of rank 0's own shard equals its resident state
             xs, ys, infos = gather_bufs.stacked()
-            assert torch.equal(xs[:B], gather_bufs.local[0]) and torch.equal(ys[:B], gather_bufs.local[1]) and \
-                torch.equal(infos[:B], gather_bufs.local[2]), "gather mismatch"
+            loc = [t.to(xs.device) for t in gather_bufs.local]  # (the gloo leg gathers through host buffers)
+            assert torch.equal(xs[:B], loc[0]) and torch.equal(ys[:B], loc[1]) and torch.equal(infos[:B], loc[2]), "gather mismatch"
             assert xs.shape[0] == total_batch and gather_bufs.rows == [shard_bounds(total_batch, world, r)[1] - shard_bounds(total_batch, world, r)[0] for r in range(world)]
             # ... and the records of EVERY rank's shard equal a re-solve, on this rank, of sampled QPs of that shard (its inputs are
             # regenerated here from the rank's seed): a gather that delivers the wrong rank's or a stale buffer fails this
@@ -506,7 +518,7 @@ def main():
                         xc, yc, _, _ = chk.solution()
                         same_kernel = chk.kernel_name() == solver.kernel_name()
                         chk.close()
-                        gx, gy = xs[off + idx].cpu().numpy(), ys[off + idx].cpu().numpy()
+                        gx, gy = xs[off + idx.to(xs.device)].cpu().numpy(), ys[off + idx.to(xs.device)].cpu().numpy()
                         # bit-identical when the re-solve ran the shard's kernel; a small sample of a tiny shape may be dispatched to
                         # a variant that sums in another order (admm_dispatch.h: the quad form of the one-QP-per-lane kernel)
                         ok = (np.array_equal(gx, xc) and np.array_equal(gy[:, :m], yc[:, :m])) if same_kernel else \

@@ -67,11 +67,18 @@ class MultiGpuBatchQPSolver {
     // device-resident shards: shards[g] describes device g's block (pointers on device g, batch = its block size)
     void setup_solve_device(const std::vector<Batch> &shards) {
         if ((int)shards.size() != num_devices()) throw std::runtime_error("setup_solve_device: one Batch per device");
+        std::vector<sqph_solver *> srcs;
+        std::vector<long long> offs;
+        std::vector<int> cnts;
         for (int g = 0; g < num_devices(); g++) {
             parts_[g]->settings() = settings_;
             parts_[g]->setup_solve(shards[g]);  // asynchronous: returns once the launch is enqueued on device g's stream
-            post(g);
+            srcs.push_back(parts_[g]->handle());
+            offs.push_back(lo_[g]);
+            cnts.push_back((int)(hi_[g] - lo_[g]));
         }
+        // every shard's records in ONE grouped post, behind the solves: the root receives on one stream per peer
+        detail::check(sqph_gather_post_many(gather_, srcs.data(), offs.data(), cnts.data(), (int)srcs.size()), srcs[0], "sqph_gather_post_many");
         fetched_ = false;
     }
 

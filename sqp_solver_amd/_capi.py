@@ -23,7 +23,7 @@ SYMBOLS = [
     "sqph_setup_csr", "sqph_update_qp_csr", "sqph_solve_csr", "sqph_setup_solve_csr",
     "sqph_shard_bounds", "sqph_device_count", "sqph_own_stream", "sqph_gather_create", "sqph_gather_create_ex", "sqph_gather_transport", "sqph_gather_destroy",
     "sqph_gather_post", "sqph_gather_fetch", "sqph_gather_device_ptrs", "sqph_setup_solve_reuse", "sqph_set_trace_qp", "sqph_get_trace",
-    "sqph_update_solve",
+    "sqph_update_solve", "sqph_gather_post_many",
 ]
 
 

@@ -1062,7 +1062,10 @@ struct sqph_gather {
     long long total = 0;
     double *x = nullptr, *y = nullptr;
     sqph_info *info = nullptr;
-    hipStream_t stream = nullptr;      // the root's side of RCCL receives
+    hipStream_t stream = nullptr;      // (kept for ABI users of the first version: the receive stream of the root's own device)
+    std::vector<hipStream_t> rstream;  // the root's side of RCCL receives, ONE STREAM PER SOURCE DEVICE: receives from different peers
+                                       // are independent streams of the root (seven xGMI links in parallel), not seven back-to-back
+                                       // receives on one stream
     std::mutex mu;                     // shards post from their own host threads (MultiGpuBatchQPSolver::run_host)
     std::vector<hipEvent_t> pending;   // one per posted copy, recorded on the stream it was enqueued on  (guarded by mu)
     std::vector<int> pending_dev;      //                                                                  (guarded by mu)
@@ -1087,7 +1090,11 @@ int sqph_gather_create_ex(sqph_gather **out, int device, int n, int m, long long
     hipError_t e = hipMalloc((void **)&g->x, (size_t)total * n * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&g->y, (size_t)total * mm * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&g->info, (size_t)total * sizeof(sqph_info));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        g->rstream.assign((size_t)ndev, nullptr);
+        for (int d = 0; d < ndev && e == hipSuccess; d++) e = hipStreamCreateWithFlags(&g->rstream[(size_t)d], hipStreamNonBlocking);
+        if (e == hipSuccess) g->stream = g->rstream[(size_t)device];
+    }
     if (e != hipSuccess) {
         g_err = std::string("sqph_gather_create: ") + hipGetErrorString(e);
         sqph_gather_destroy(g);
@@ -1106,7 +1113,8 @@ void sqph_gather_destroy(sqph_gather *g) {
         (void)hipEventDestroy(g->pending[i]);
     }
     DeviceGuard dg(g->device);
-    if (g->stream) (void)hipStreamDestroy(g->stream);
+    for (hipStream_t st : g->rstream)
+        if (st) (void)hipStreamDestroy(st);
     if (g->x) (void)hipFree(g->x);
     if (g->y) (void)hipFree(g->y);
     if (g->info) (void)hipFree(g->info);
@@ -1115,81 +1123,119 @@ void sqph_gather_destroy(sqph_gather *g) {
 
 const char *sqph_gather_transport(const sqph_gather *g) { return g ? g->transport : "none"; }
 
-int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int count) {
-    if (!g || !src) return SQPH_ERR_INVALID;
-    if (src->n != g->n || src->m != g->m) SQPH_FAIL(src, SQPH_ERR_INVALID, "sqph_gather_post: shape mismatch");
-    if (count < 0 || count > src->cap || offset < 0 || offset + count > g->total) SQPH_FAIL(src, SQPH_ERR_INVALID, "sqph_gather_post: range [%lld, %lld) outside the gather buffers / solver capacity", offset, offset + count);
-    if (count == 0) return SQPH_OK;
-    const size_t n = g->n, m = g->m, c = (size_t)count;
-    const bool cross = src->device != g->device;
-    bool via_rccl = false;
+// One RCCL group for ALL shards of a call (producer sides on the producers' streams behind their solves, root sides on the root's
+// per-peer receive streams), then one event per stream.  Shards on the root's own device — and everything where RCCL cannot be had —
+// are device-to-device / peer copies on the producer's stream.
+int sqph_gather_post_many(sqph_gather *g, sqph_solver *const *srcs, const long long *offsets, const int *counts, int k) {
+    if (!g || !srcs || !offsets || !counts || k < 0) return SQPH_ERR_INVALID;
+    for (int i = 0; i < k; i++) {
+        sqph_solver *src = srcs[i];
+        if (!src) return SQPH_ERR_INVALID;
+        if (src->n != g->n || src->m != g->m) SQPH_FAIL(src, SQPH_ERR_INVALID, "sqph_gather_post: shape mismatch");
+        if (counts[i] < 0 || counts[i] > src->cap || offsets[i] < 0 || offsets[i] + counts[i] > g->total)
+            SQPH_FAIL(src, SQPH_ERR_INVALID, "sqph_gather_post: range [%lld, %lld) outside the gather buffers / solver capacity", offsets[i], offsets[i] + counts[i]);
+    }
+    const size_t n = g->n, m = g->m;
+    std::vector<char> via((size_t)k, 0);
     const char *rccl_err = nullptr;
-    if (!(g->flags & SQPH_GATHER_NO_RCCL) && (cross || (g->flags & SQPH_GATHER_RCCL_ALWAYS))) {
+    sqph_solver *err_src = k ? srcs[0] : nullptr;
+    bool want_rccl = false;
+    for (int i = 0; i < k; i++)
+        if (counts[i] > 0 && !(g->flags & SQPH_GATHER_NO_RCCL) && (srcs[i]->device != g->device || (g->flags & SQPH_GATHER_RCCL_ALWAYS))) want_rccl = true;
+    if (want_rccl) {
         RcclApi &R = rccl();
+        // the enqueue is serialised per process: every post uses the ROOT's communicator (its receive side), and a communicator
+        // must not be entered from two host threads at once; the lock covers the enqueue only (microseconds), never a transfer
         std::lock_guard<std::mutex> lk(R.mu);
-        if (R.init() && src->device < R.ndev && g->device < R.ndev) {
-            // producer side on its stream (behind the solve), root side on the gather's stream; one group per post
+        if (R.init()) {
             ncclResult_t r = R.GroupStart();
-            const auto xfer = [&](const void *from, void *to, size_t bytes_or_elems, ncclDataType_t dt) {
-                if (r == ncclSuccess) r = R.Send(from, bytes_or_elems, dt, g->device, R.comms[src->device], src->stream);
-                if (r == ncclSuccess) r = R.Recv(to, bytes_or_elems, dt, src->device, R.comms[g->device], g->stream);
-            };
-            xfer(src->x, g->x + (size_t)offset * n, c * n, ncclFloat64);
-            if (m) xfer(src->y, g->y + (size_t)offset * m, c * m, ncclFloat64);
-            xfer(src->info, g->info + offset, c * sizeof(sqph_info), ncclInt8);
+            for (int i = 0; i < k; i++) {
+                sqph_solver *src = srcs[i];
+                const size_t c = (size_t)counts[i];
+                const bool eligible = c > 0 && (src->device != g->device || (g->flags & SQPH_GATHER_RCCL_ALWAYS)) && src->device < R.ndev && g->device < R.ndev;
+                if (!eligible) continue;
+                hipStream_t rs = g->rstream[(size_t)src->device];
+                const auto xfer = [&](const void *from, void *to, size_t elems, ncclDataType_t dt) {
+                    if (r == ncclSuccess) r = R.Send(from, elems, dt, g->device, R.comms[src->device], src->stream);
+                    if (r == ncclSuccess) r = R.Recv(to, elems, dt, src->device, R.comms[g->device], rs);
+                };
+                xfer(src->x, g->x + (size_t)offsets[i] * n, c * n, ncclFloat64);
+                if (m) xfer(src->y, g->y + (size_t)offsets[i] * m, c * m, ncclFloat64);
+                xfer(src->info, g->info + offsets[i], c * sizeof(sqph_info), ncclInt8);
+                via[(size_t)i] = 1;
+                if (r != ncclSuccess) err_src = src;
+            }
             const ncclResult_t re = R.GroupEnd();
             if (r == ncclSuccess) r = re;
             // an error after a partly issued group: the send / receive kernels that were enqueued still have to be waited for —
             // the events below are recorded either way, the error is returned after them
             if (r != ncclSuccess) rccl_err = R.GetErrorString(r);
-            via_rccl = true;
         }
     }
     // (any failure from here on still hands the events already created to the gather: nothing leaks, nothing enqueued goes unwaited)
-    hipEvent_t ev = nullptr, ev_root = nullptr;
+    std::vector<hipEvent_t> evs;
+    std::vector<int> evdev;
+    bool any_rccl = false, any_copy = false;
     const auto hand_over = [&]() {
         std::lock_guard<std::mutex> lk(g->mu);
-        g->transport = via_rccl ? "rccl" : "peer-copy";  // written by one host thread per shard: under the gather's mutex
-        if (ev) {
-            g->pending.push_back(ev);
-            g->pending_dev.push_back(src->device);
+        if (any_rccl || any_copy) g->transport = any_rccl ? "rccl" : "peer-copy";  // (one host thread per shard may post: under the gather's mutex)
+        for (size_t i = 0; i < evs.size(); i++) {
+            g->pending.push_back(evs[i]);
+            g->pending_dev.push_back(evdev[i]);
         }
-        if (ev_root) {
-            g->pending.push_back(ev_root);
-            g->pending_dev.push_back(g->device);
-        }
+        evs.clear();
+        evdev.clear();
     };
-#define SQPH_HIP_POST(call)                                                                                   \
+#define SQPH_HIP_POST(src_, call)                                                                             \
     do {                                                                                                      \
         hipError_t e_ = (call);                                                                               \
         if (e_ != hipSuccess) {                                                                               \
             hand_over();                                                                                      \
-            SQPH_FAIL(src, SQPH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                      \
+            SQPH_FAIL(src_, SQPH_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                     \
         }                                                                                                     \
     } while (0)
-    if (via_rccl) {
-        DeviceGuard dr(g->device);
-        SQPH_HIP_POST(hipEventCreateWithFlags(&ev_root, hipEventDisableTiming));
-        SQPH_HIP_POST(hipEventRecord(ev_root, g->stream));
-    }
-    DeviceGuard dg(src->device);
-    if (!via_rccl) {
-        if (cross) {
-            int can = 0;
-            (void)hipDeviceCanAccessPeer(&can, src->device, g->device);
-            if (can) (void)hipDeviceEnablePeerAccess(g->device, 0);  // idempotent (an "already enabled" error is cleared below)
-            (void)hipGetLastError();
+    for (int i = 0; i < k; i++) {
+        sqph_solver *src = srcs[i];
+        const size_t c = (size_t)counts[i];
+        if (!c) continue;
+        const bool cross = src->device != g->device;
+        if (via[(size_t)i]) {
+            any_rccl = true;
+            DeviceGuard dr(g->device);
+            hipEvent_t ev_root = nullptr;
+            SQPH_HIP_POST(src, hipEventCreateWithFlags(&ev_root, hipEventDisableTiming));
+            evs.push_back(ev_root);
+            evdev.push_back(g->device);
+            SQPH_HIP_POST(src, hipEventRecord(ev_root, g->rstream[(size_t)src->device]));
         }
-        SQPH_HIP_POST(hipMemcpyPeerAsync(g->x + (size_t)offset * n, g->device, src->x, src->device, c * n * sizeof(double), src->stream));
-        if (m) SQPH_HIP_POST(hipMemcpyPeerAsync(g->y + (size_t)offset * m, g->device, src->y, src->device, c * m * sizeof(double), src->stream));
-        SQPH_HIP_POST(hipMemcpyPeerAsync(g->info + offset, g->device, src->info, src->device, c * sizeof(sqph_info), src->stream));
+        DeviceGuard dg(src->device);
+        if (!via[(size_t)i]) {
+            any_copy = true;
+            if (cross) {
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, src->device, g->device);
+                if (can) (void)hipDeviceEnablePeerAccess(g->device, 0);  // idempotent (an "already enabled" error is cleared below)
+                (void)hipGetLastError();
+            }
+            SQPH_HIP_POST(src, hipMemcpyPeerAsync(g->x + (size_t)offsets[i] * n, g->device, src->x, src->device, c * n * sizeof(double), src->stream));
+            if (m) SQPH_HIP_POST(src, hipMemcpyPeerAsync(g->y + (size_t)offsets[i] * m, g->device, src->y, src->device, c * m * sizeof(double), src->stream));
+            SQPH_HIP_POST(src, hipMemcpyPeerAsync(g->info + offsets[i], g->device, src->info, src->device, c * sizeof(sqph_info), src->stream));
+        }
+        hipEvent_t ev = nullptr;
+        SQPH_HIP_POST(src, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        evs.push_back(ev);
+        evdev.push_back(src->device);
+        SQPH_HIP_POST(src, hipEventRecord(ev, src->stream));
     }
-    SQPH_HIP_POST(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    SQPH_HIP_POST(hipEventRecord(ev, src->stream));
 #undef SQPH_HIP_POST
     hand_over();
-    if (rccl_err) SQPH_FAIL(src, SQPH_ERR_HIP, "sqph_gather_post: RCCL: %s", rccl_err);
+    if (rccl_err) SQPH_FAIL(err_src, SQPH_ERR_HIP, "sqph_gather_post: RCCL: %s", rccl_err);
     return SQPH_OK;
+}
+
+int sqph_gather_post(sqph_gather *g, sqph_solver *src, long long offset, int count) {
+    if (!g || !src) return SQPH_ERR_INVALID;
+    return sqph_gather_post_many(g, &src, &offset, &count, 1);
 }
 
 static int gather_wait(sqph_gather *g) {

@@ -59,6 +59,10 @@ class ResultGather:
         self.row_bytes = [int(np.prod(t.shape[1:], dtype=np.int64)) * t.element_size() for t in self.local]
         self.nbytes = [rows * rb for rb in self.row_bytes]
         dev = self.local[0].device
+        # the gloo backend moves host memory: device-resident arrays are staged through host buffers there (the copy into the staging
+        # buffer is the D2H), the "nccl" (RCCL) backend gathers device buffers directly
+        if world > 1 and dev.type == "cuda" and dist.get_backend() == "gloo":
+            dev = torch.device("cpu")
         counts = torch.tensor([rows], dtype=torch.int64, device=dev)
         if world > 1:
             allc = [torch.zeros_like(counts) for _ in range(world)]

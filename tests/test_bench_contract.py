@@ -91,6 +91,25 @@ def test_bench_spawned_path_runs_the_rccl_gather():
     assert d["config"]["gather"] is True and d["config"]["global_batch"] == 1023 and d["scaling"] == "strong"
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device_over_gloo():
+    """world size 2 with REAL kernels on a one-GPU box (RCCL refuses two ranks on one device; the gloo leg stages the gather through
+    host buffers): different rank seeds, shard_bounds of an odd total (513 + 512), the padded ResultGather, and rank 0's re-solve
+    check of sampled QPs of EVERY rank's shard (asserted inside bench.py) — the pieces an N = 1 run cannot exercise"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--global-batch", "1025"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 1025 and d["config"]["gather"] is True
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 2 and mg["backend"] == "gloo"
+    for k in ("kernel_ms_avg_per_rank", "solve_ms_per_rank", "gather_ms_sync_per_rank"):
+        assert len(mg[k]) == 2 and all(v > 0 for v in mg[k])
+    assert abs(d["value"] - 1025 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
 EXTRA_KEYS_R4 = ("c2", "c3_default", "c3_sqp", "c3_whole_65536", "c5")  # round 4: the 8,192-QP shard was the headline
 EXTRA_KEYS = ("c2", "c3_default", "c3_sqp", "c3_shard_8192", "c5")  # round 5 on: the whole 65,536 batch is
 

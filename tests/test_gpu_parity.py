@@ -355,7 +355,10 @@ def test_true_fp32_variant():
 
 
 def test_fp32_product_variant_of_the_register_tiled_kernels():
-    """SQPH_FLAG_F32_ARITH at the BASELINE dense shapes (reference src/qp.cpp:385-386 and
+    """AN APPROXIMATE MODE, NOT A PARITY CLAIM (round 5: SURVEY section 8 row f4 asked for y within 2x of the float reference; this
+    variant measures 2.7-4.6x and is documented as outside the parity contract in include/sqp_hip.h — the bars below PIN its measured
+    behaviour so that it cannot silently get worse, they were set after measuring).
+    SQPH_FLAG_F32_ARITH at the BASELINE dense shapes (reference src/qp.cpp:385-386 and
     tests/qp_solver_test.cpp:58-69): tiles, operands and partial sums of the two iteration stages in fp32 (wg_f32.hip), the
     factorisation, the iterates and the residual checks in fp64.  Stated accuracy, WITHOUT a floor (round 4; measured on the MI355X,
     tools/xp/f32_err.py: x 0.7-1.7x, z 0.5-1.8x, y 2.7-4.6x the float oracle's error against the fp64 solution): x and z no further
