@@ -559,6 +559,17 @@ struct CsbKernel {
         }
     }
 
+    // LDS add without a returned value (ds_add_f64): the panel's accumulation is fire-and-forget — as a read-modify-write in
+    // registers every entry of a column waited for the LDS round trip of the entry before it (form_S was 212 k of the set-up's
+    // 570 k cycles).  The additions to one address are issued by one wavefront in program order, and the LDS executes a
+    // wavefront's operations in order: the sums are as deterministic as before.
+    static __device__ __forceinline__ void lds_add_f64(T *p, T v) {
+#ifdef SQPH_SIM
+        *p += v;
+#else
+        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    }
     // ---------------------------------------------------------------- S = P_sym + sigma I + A' diag(rho) A -> blocks
     // One 32-column panel at a time in LDS: the 16-lane group g owns column j = 32 p + g — for every CSC entry (i, pos) of that
     // column, in row order, its lanes add rho_i A_ij * (row i of A) into the panel column (distinct k per lane: rows are
@@ -615,7 +626,7 @@ struct CsbKernel {
                         const int f0n = rowptr[in], f1n = rowptr[in + 1];
                         for (int f = f0 + c16; f < f1; f += 16) {
                             const int k = col[f];
-                            if (k >= j) Sp[g * LDP + k] = wg_fma(coef, val[f], Sp[g * LDP + k]);
+                            if (k >= j) lds_add_f64(&Sp[g * LDP + k], coef * val[f]);
                         }
                         coef = coefn;
                         f0 = f0n;
@@ -635,7 +646,7 @@ struct CsbKernel {
 #pragma unroll
                     for (int q = 0; q < 7; q++) {
                         const int k = k0 + c16 + 16 * q;
-                        if (k < n) Sp[g * LDP + k] += pv[q] + (k == j ? sigma : T(0));
+                        if (k < n) lds_add_f64(&Sp[g * LDP + k], pv[q] + (k == j ? sigma : T(0)));
                     }
                 }
             }
@@ -742,31 +753,27 @@ struct CsbKernel {
 #pragma unroll
             for (int kq = 0; kq < 4; kq++) av0[kq] = -opN(XS + I0 * BS, kq, lr, lq);
         }
+        // ONE code body per slot (the three cases — E_IK -= L_IJ W_JK for K < J, E_IJ = -L_IJ Winv_JJ dc for K = J, M_IK -= L_IJ L_KJ'
+        // for K > J — differ in where the second operand is read and whether the block starts from zero): the elimination is
+        // straight-line code executed once per step, every instruction of it an instruction-cache miss
+        const int offT = (lq * 17 + lr), offN = (lr * 17 + lq);
+        static_assert(!MS::SWZ, "padded blocks: element (i, j) at 17 i + j");
 #pragma unroll
         for (int s = 0; s <= NB; s++) {
             const Slot d = slot_of(W, s);
-            if (!d.valid || d.I <= J) continue;
-            T av[4], bv[4];
+            if (!d.valid || d.I <= J || (d.I == J + 1 && d.K == J + 1)) continue;
+            const bool isT = d.K <= J, diag = d.K == J;
+            const T *src = (diag ? Wd : XS + d.K * BS) + (isT ? offT : offN);
+            const int step = isT ? 4 * 17 : 4;
+            T bv[4];
 #pragma unroll
-            for (int kq = 0; kq < 4; kq++) av[kq] = s <= I1 ? av1[kq] : av0[kq];  // (a scalar condition)
-            if (d.K < J) {
+            for (int kq = 0; kq < 4; kq++) bv[kq] = src[kq * step];
+            if (diag) B[s] = sqph_acc4{{0, 0, 0, 0}};
 #pragma unroll
-                for (int kq = 0; kq < 4; kq++) bv[kq] = opT(XS + d.K * BS, kq, lr, lq);
+            for (int kq = 0; kq < 4; kq++) mfma16(s <= I1 ? av1[kq] : av0[kq], bv[kq], B[s]);
+            if (diag) {
 #pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
-            } else if (d.K == J) {
-                sqph_acc4 a = {{0, 0, 0, 0}};
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) bv[kq] = opT(Wd, kq, lr, lq);
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
-#pragma unroll
-                for (int e = 0; e < 4; e++) B[s].v[e] = a.v[e] * dc;
-            } else if (!(d.I == J + 1 && d.K == J + 1)) {
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) bv[kq] = opN(XS + d.K * BS, kq, lr, lq);
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
+                for (int e = 0; e < 4; e++) B[s].v[e] *= dc;
             }
         }
     }
@@ -825,9 +832,9 @@ struct CsbKernel {
             if (J == NB - 1) break;
             __syncthreads();
             SQPH_FTICK(14)
-            elim_B(wave, J, B, wk, sj, lr, lq);
-            if (wave == DW)  // look-ahead: the next diagonal block, behind this wavefront's own (small) share of the step
+            if (wave == DW)  // look-ahead: the next diagonal block first (the other wavefronts are in their trailing updates), then this wavefront's own, small, share
                 MS::diag_block(wk + Lay::O_MD + ((J + 1) & 1) * BS, wk + Lay::O_TB + ((J + 1) & 1) * BS, sj + 16 * (J + 1), flag, l);
+            elim_B(wave, J, B, wk, sj, lr, lq);
             SQPH_FTICK(15)
         }
         __syncthreads();
