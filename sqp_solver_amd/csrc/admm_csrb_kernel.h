@@ -1,9 +1,9 @@
 // Sparse-A ADMM kernel, block-row form (BASELINE config 5: n = 200, m = 400, CSR A): ONE 512-lane workgroup (8 wavefronts) per QP.
 //
 // The factor W (S^-1 = W'W, lower triangular, n <= 16 NB) lives in the CU's register file as 16 x 16 blocks in the accumulator
-// layout of v_mfma_f64_16x16x4_f64 (lane l of a wavefront holds rows (l >> 4) + 4 e, e < 4, of column l & 15).  Every wavefront
-// owns one or two whole block rows (at most 14 blocks, 4 doubles per lane each; dealt so that the four SIMDs carry equal numbers
-// of blocks: OwnTab below).  What this layout buys over the 32 x 32 lane grid of admm_csr_kernel.h:
+// layout of v_mfma_f64_16x16x4_f64 (lane l of a wavefront holds rows (l >> 4) + 4 e, e < 4, of column l & 15).  Wavefront w owns
+// the block rows I1 = NB - 1 - w and I0 = w (NB + 1 blocks, 4 doubles per lane each); the last wavefront owns none and
+// eliminates the diagonal blocks.  What this layout buys over the 32 x 32 lane grid of admm_csr_kernel.h:
 //   * the set-up runs on the matrix pipe with the blocks in registers: blocked elimination, only the current panel column / block
 //     row (NB blocks) and two diagonal blocks go through LDS (the 2-D cyclic tile of the other kernel took n pivots of ~80
 //     instructions and a workgroup barrier each);
@@ -134,59 +134,22 @@ struct CsbKernel {
     using MS = MSetup<2, 16, 8, 7, 7, 4>;  // the in-wavefront elimination of a 16 x 16 diagonal block (admm_wg_msetup.h: diag_block)
     static_assert(!MS::SWZ && MS::BS == Lay::BS, "diag_block works on padded blocks");
     static constexpr int NT = Lay::NT, NW = Lay::NW, NP = Lay::NP, BS = Lay::BS, LDP = Lay::LDP;
+    static constexpr int NH = (NB + 1) / 2;  // wavefronts that own blocks
+    static constexpr int DW = NW - 1;        // the wavefront that eliminates the diagonal blocks
     static constexpr int KR = SQPH_CSB_KR;   // entries of A per lane and orientation held in registers
-    static_assert(NB >= 1 && NB <= 14 && (KR % 2) == 0, "at most 14 block rows");
+    static_assert(NH <= DW && NB >= 1 && NB <= 14 && (KR % 2) == 0, "block rows pair up on seven wavefronts");
 
-    // Which wavefront owns which block rows.  Row I has I + 1 blocks (4 multiply-adds per lane and block in each of the
-    // iteration's two dense stages); wavefront w runs on SIMD w % 4 and the two wavefronts of a SIMD share its vector pipe, so the
-    // rows are dealt largest first to the SIMD with the least blocks so far (to its wavefront with fewer; at most two rows and 14
-    // blocks per wavefront).  NB = 13: {12} {11} {10} {9,0} {5,4} {6,3} {7,2} {8,1} — 24 / 23 / 22 / 22 blocks per SIMD
-    // (the first version paired row I with NB - 1 - I on seven wavefronts: 28 / 28 / 21 / 14).  The wavefront with the least
-    // elimination work (a row costs ~I (I + 1) block products) also eliminates the diagonal blocks.
-    struct OwnTab {
-        int rowA[NW], rowB[NW], dw;
-    };
-    static constexpr OwnTab make_tab() {
-        OwnTab T{};
-        int wl[NW] = {}, sl[4] = {}, nr[NW] = {};
-        for (int w = 0; w < NW; w++) T.rowA[w] = T.rowB[w] = -1;
-        for (int I = NB - 1; I >= 0; I--) {
-            int best = -1;
-            for (int w = 0; w < NW; w++) {
-                if (nr[w] >= 2 || wl[w] + I + 1 > 14) continue;
-                if (best < 0 || sl[w % 4] < sl[best % 4] || (sl[w % 4] == sl[best % 4] && wl[w] < wl[best])) best = w;
-            }
-            if (nr[best] == 0) T.rowA[best] = I;
-            else T.rowB[best] = I;
-            nr[best]++;
-            wl[best] += I + 1;
-            sl[best % 4] += I + 1;
-        }
-        int bw = 0, bcost = 1 << 30;
-        for (int w = 0; w < NW; w++) {
-            const int a = T.rowA[w], bb = T.rowB[w];
-            const int cost = (a >= 0 ? a * (a + 1) : 0) + (bb >= 0 ? bb * (bb + 1) : 0);
-            if (cost <= bcost) {
-                bcost = cost;
-                bw = w;
-            }
-        }
-        T.dw = bw;
-        return T;
-    }
-    static constexpr OwnTab TAB = make_tab();
-    static constexpr int DW = TAB.dw;  // the wavefront that eliminates the diagonal blocks (after its own, small, share of a step)
-
-    // block rows and register slots of wavefront W: slots 0 .. I1 hold row I1 (its larger row), slots I1 + 1 .. I1 + 1 + I0 row I0
+    // block rows and register slots of wavefront W: slots 0 .. I1 hold row I1 = NB - 1 - W, slots I1 + 1 .. I1 + 1 + I0 row I0 = W
     template <int W>
     struct Own {
-        static constexpr int I1 = TAB.rowA[W], I0 = TAB.rowB[W];
-        static constexpr bool any = I1 >= 0;
-        static constexpr bool has0 = any && I0 >= 0;
+        static constexpr bool any = W < NH;
+        static constexpr int I1 = NB - 1 - W, I0 = W;
+        static constexpr bool has0 = any && I0 < I1;
         static constexpr int nslots = any ? (I1 + 1) + (has0 ? I0 + 1 : 0) : 0;
         static constexpr int row(int s) { return s <= I1 ? I1 : I0; }
         static constexpr int col(int s) { return s <= I1 ? s : s - I1 - 1; }
     };
+
     // the same map with the wavefront index a run-time scalar: the set-up is ONE code path for all wavefronts (seven specialised
     // copies of the elimination — 14 eight-register accumulator tuples each — were more than the register allocator could hold
     // together: two of the copies kept their blocks in scratch memory); only the iteration's two dense stages are specialised
@@ -194,23 +157,12 @@ struct CsbKernel {
         int I, K;
         bool valid;
     };
-    static __device__ __forceinline__ int row_a(int W) {
-        int r = -1;
-#pragma unroll
-        for (int w = 0; w < NW; w++) r = W == w ? TAB.rowA[w] : r;  // (scalar selects on compile-time constants)
-        return r;
-    }
-    static __device__ __forceinline__ int row_b(int W) {
-        int r = -1;
-#pragma unroll
-        for (int w = 0; w < NW; w++) r = W == w ? TAB.rowB[w] : r;
-        return r;
-    }
     static __device__ __forceinline__ Slot slot_of(int W, int s) {
-        const int I1 = row_a(W), I0 = row_b(W), n1 = I1 + 1;
+        const int I1 = NB - 1 - W, n1 = I1 + 1;
+        const bool has0 = W < I1;
         Slot d;
-        d.valid = I1 >= 0 && (s < n1 || (I0 >= 0 && s < n1 + I0 + 1));
-        d.I = s < n1 ? I1 : I0;
+        d.valid = W < NH && (s < n1 || (has0 && s < n1 + W + 1));
+        d.I = s < n1 ? I1 : W;
         d.K = s < n1 ? s : s - n1;
         return d;
     }
@@ -559,17 +511,6 @@ struct CsbKernel {
         }
     }
 
-    // LDS add without a returned value (ds_add_f64): the panel's accumulation is fire-and-forget — as a read-modify-write in
-    // registers every entry of a column waited for the LDS round trip of the entry before it (form_S was 212 k of the set-up's
-    // 570 k cycles).  The additions to one address are issued by one wavefront in program order, and the LDS executes a
-    // wavefront's operations in order: the sums are as deterministic as before.
-    static __device__ __forceinline__ void lds_add_f64(T *p, T v) {
-#ifdef SQPH_SIM
-        *p += v;
-#else
-        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-    }
     // ---------------------------------------------------------------- S = P_sym + sigma I + A' diag(rho) A -> blocks
     // One 32-column panel at a time in LDS: the 16-lane group g owns column j = 32 p + g — for every CSC entry (i, pos) of that
     // column, in row order, its lanes add rho_i A_ij * (row i of A) into the panel column (distinct k per lane: rows are
@@ -626,7 +567,7 @@ struct CsbKernel {
                         const int f0n = rowptr[in], f1n = rowptr[in + 1];
                         for (int f = f0 + c16; f < f1; f += 16) {
                             const int k = col[f];
-                            if (k >= j) lds_add_f64(&Sp[g * LDP + k], coef * val[f]);
+                            if (k >= j) Sp[g * LDP + k] = wg_fma(coef, val[f], Sp[g * LDP + k]);
                         }
                         coef = coefn;
                         f0 = f0n;
@@ -646,7 +587,7 @@ struct CsbKernel {
 #pragma unroll
                     for (int q = 0; q < 7; q++) {
                         const int k = k0 + c16 + 16 * q;
-                        if (k < n) lds_add_f64(&Sp[g * LDP + k], pv[q] + (k == j ? sigma : T(0)));
+                        if (k < n) Sp[g * LDP + k] += pv[q] + (k == j ? sigma : T(0));
                     }
                 }
             }
@@ -743,37 +684,41 @@ struct CsbKernel {
         const T *XS = wk + Lay::O_XS;
         const T *Wd = wk + Lay::O_TB + (J & 1) * BS;
         const T dc = sj[16 * J + lr];
-        const int I1 = row_a(W), I0 = row_b(W);
+        const int I1 = NB - 1 - W, I0 = W;
         T av1[4] = {0, 0, 0, 0}, av0[4] = {0, 0, 0, 0};
         if (I1 > J) {
 #pragma unroll
             for (int kq = 0; kq < 4; kq++) av1[kq] = -opN(XS + I1 * BS, kq, lr, lq);
         }
-        if (I0 > J) {
+        if (I0 < I1 && I0 > J) {
 #pragma unroll
             for (int kq = 0; kq < 4; kq++) av0[kq] = -opN(XS + I0 * BS, kq, lr, lq);
         }
-        // ONE code body per slot (the three cases — E_IK -= L_IJ W_JK for K < J, E_IJ = -L_IJ Winv_JJ dc for K = J, M_IK -= L_IJ L_KJ'
-        // for K > J — differ in where the second operand is read and whether the block starts from zero): the elimination is
-        // straight-line code executed once per step, every instruction of it an instruction-cache miss
-        const int offT = (lq * 17 + lr), offN = (lr * 17 + lq);
-        static_assert(!MS::SWZ, "padded blocks: element (i, j) at 17 i + j");
 #pragma unroll
         for (int s = 0; s <= NB; s++) {
             const Slot d = slot_of(W, s);
-            if (!d.valid || d.I <= J || (d.I == J + 1 && d.K == J + 1)) continue;
-            const bool isT = d.K <= J, diag = d.K == J;
-            const T *src = (diag ? Wd : XS + d.K * BS) + (isT ? offT : offN);
-            const int step = isT ? 4 * 17 : 4;
-            T bv[4];
+            if (!d.valid || d.I <= J) continue;
+            T av[4], bv[4];
 #pragma unroll
-            for (int kq = 0; kq < 4; kq++) bv[kq] = src[kq * step];
-            if (diag) B[s] = sqph_acc4{{0, 0, 0, 0}};
+            for (int kq = 0; kq < 4; kq++) av[kq] = s <= I1 ? av1[kq] : av0[kq];  // (a scalar condition)
+            if (d.K < J) {
 #pragma unroll
-            for (int kq = 0; kq < 4; kq++) mfma16(s <= I1 ? av1[kq] : av0[kq], bv[kq], B[s]);
-            if (diag) {
+                for (int kq = 0; kq < 4; kq++) bv[kq] = opT(XS + d.K * BS, kq, lr, lq);
 #pragma unroll
-                for (int e = 0; e < 4; e++) B[s].v[e] *= dc;
+                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
+            } else if (d.K == J) {
+                sqph_acc4 a = {{0, 0, 0, 0}};
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) bv[kq] = opT(Wd, kq, lr, lq);
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
+#pragma unroll
+                for (int e = 0; e < 4; e++) B[s].v[e] = a.v[e] * dc;
+            } else if (!(d.I == J + 1 && d.K == J + 1)) {
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) bv[kq] = opN(XS + d.K * BS, kq, lr, lq);
+#pragma unroll
+                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
             }
         }
     }
@@ -786,7 +731,6 @@ struct CsbKernel {
         case 4: if constexpr (Own<4>::any) { CALL(4); } break; \
         case 5: if constexpr (Own<5>::any) { CALL(5); } break; \
         case 6: if constexpr (Own<6>::any) { CALL(6); } break; \
-        case 7: if constexpr (Own<7>::any) { CALL(7); } break; \
         default: break; \
     }
     // returns false (block-uniform) when S is not positive definite / not finite; leaves W in B
@@ -832,9 +776,10 @@ struct CsbKernel {
             if (J == NB - 1) break;
             __syncthreads();
             SQPH_FTICK(14)
-            if (wave == DW)  // look-ahead: the next diagonal block first (the other wavefronts are in their trailing updates), then this wavefront's own, small, share
+            if (wave == DW)
                 MS::diag_block(wk + Lay::O_MD + ((J + 1) & 1) * BS, wk + Lay::O_TB + ((J + 1) & 1) * BS, sj + 16 * (J + 1), flag, l);
-            elim_B(wave, J, B, wk, sj, lr, lq);
+            else
+                elim_B(wave, J, B, wk, sj, lr, lq);
             SQPH_FTICK(15)
         }
         __syncthreads();
