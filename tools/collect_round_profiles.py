@@ -15,6 +15,7 @@ W = {  # name -> (n, m, batch, mode)
     "c2": (20, 40, 4096, "fixed"), "c5": (200, 400, 8192, "fixed"), "lane": (2, 3, 65536, "fixed"),
     "c3_full": (50, 100, 65536, "fixed"), "c3_f32": (50, 100, 8192, "fixed"), "c2_f32": (20, 40, 4096, "fixed"),
 }
+W = {k: v for k, v in W.items() if os.path.isdir(os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, k)))}  # (the workloads this round profiled)
 for name, (n, m, batch, mode) in W.items():
     src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, name))
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(ROOT, "profiles", "%s_%s_summary.txt" % (tag, name)))

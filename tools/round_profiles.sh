@@ -11,23 +11,21 @@ run() {  # name, bench args...
     if [ $PHASE = prof ]; then
         bash tools/profile_gpu.sh ${TAG}_$name "$@" > gpurun_out/prof_${TAG}_$name.out 2>&1
     else
-        python bench.py "$@" >> gpurun_out/${TAG}_bench_lines.new 2>gpurun_out/bench_$name.err
+        timeout 900 python bench.py "$@" >> gpurun_out/${TAG}_bench_lines.new 2>gpurun_out/bench_$name.err
     fi
 }
 rm -f gpurun_out/${TAG}_bench_lines.new
-run c3 --workload c3
-run c3_default --workload c3 --mode default
-run c3_sqp --workload c3 --mode sqp
+run c3_full --workload c3                                   # the headline: configs[2], 65,536 QPs in one launch
+run c3 --workload c3 --global-batch 0                       # the 8,192-QP shard one of eight GPUs solves
+run c3_default --workload c3 --global-batch 0 --mode default
+run c3_sqp --workload c3 --global-batch 0 --mode sqp
 run c2 --workload c2
 run c5 --workload c5 --steps 5
 run lane --n 2 --m 3 --batch-per-gpu 65536
-run c3_full --global-batch 65536 --steps 5
-run c3_f32 --workload c3 --dtype f32 --f32-arith
-run c2_f32 --workload c2 --dtype f32 --f32-arith
 [ $PHASE = prof ] && exit 0
-python bench.py --global-batch 65536 --steps 5 --mode default >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
-python bench.py --n 2 --m 3 --batch-per-gpu 65536 --dtype f32 --f32-arith >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
-python bench.py --n 4 --m 6 --batch-per-gpu 65536 >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
-python bench.py --n 4 --m 6 --batch-per-gpu 65536 --dtype f32 --f32-arith >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
-python bench.py --n 200 --m 400 --batch-per-gpu 512 --steps 5 >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null   # dense beyond the tiled shapes (csr_dense.hip)
+timeout 600 python bench.py --global-batch 65536 --steps 5 --mode default >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
+timeout 600 python bench.py --n 2 --m 3 --batch-per-gpu 65536 --dtype f32 --f32-arith >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
+timeout 600 python bench.py --n 4 --m 6 --batch-per-gpu 65536 >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
+timeout 600 python bench.py --n 4 --m 6 --batch-per-gpu 65536 --dtype f32 --f32-arith >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
+timeout 600 python bench.py --n 200 --m 400 --batch-per-gpu 512 --steps 5 >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null   # dense beyond the tiled shapes (csr_dense.hip)
 mv gpurun_out/${TAG}_bench_lines.new gpurun_out/${TAG}_bench_lines.jsonl
