@@ -10,7 +10,8 @@ LIB = os.environ.get("SQPH_LIB") or os.path.join(LIBDIR, "libsqp_hip.so")  # SQP
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 # extra compiler flags from the environment, e.g. SQPH_HIPCC_FLAGS=-DSQPH_LANE_NO_FMA for users who want the one-QP-per-lane kernel's
-# unfused multiply / add back (it tracks the reference's unfused CPU arithmetic almost bit for bit: admm_lane_kernel.h)
+# unfused multiplies / adds back (closer to the reference's unfused CPU arithmetic; the summation order of A'w is still the
+# kernel's two-chain one: admm_lane_kernel.h)
 FLAGS += os.environ.get("SQPH_HIPCC_FLAGS", "").split()
 # flags of single translation units (csrb.hip says why)
 UNIT_FLAGS = {"csrb.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}

@@ -43,8 +43,12 @@ struct CsbLayout {
     static constexpr int O_TB = O_XS + NB * BS;     // [2][BS]  unscaled inverse of the current / next diagonal block
     static constexpr int O_MD = O_TB + 2 * BS;      // [2][BS]  the diagonal block handed to the eliminating wavefront, W_JJ on return
     static constexpr int W_ELIM = O_MD + 2 * BS;
-    static constexpr int O_PW = 0;                  // [8 waves][8 values][64 lanes] partial sums of y1 = W t
-    static constexpr int O_XP = O_PW + 8 * 8 * 64;  // [NP][8] partial sums of x~ = W' y1, one per wavefront
+    // [8 waves][8 values x 4 DPP rows][PWS] partial sums of y1 = W t.  Element j of row (v, lq) sits at (j + 4 v) mod 16 of a row of
+    // PWS = 18 doubles: with plain rows of 16 the four ds_read_b128 of the reduction were 4-way bank conflicted (64 instead of 16 LDS
+    // cycles; tools/xp/lds_bank_model.py finds this rotation + stride conflict-free for the reads and the eight ds_write_b64)
+    static constexpr int PWS = 18, PWW = 32 * PWS;
+    static constexpr int O_PW = 0;
+    static constexpr int O_XP = O_PW + 8 * PWW;     // [8 waves][NP] partial sums of x~ = W' y1, wavefront-major (lane-consecutive stores and loads)
     static constexpr int W_ITER = O_XP + NP * 8;
     static constexpr int W_MAP = (2 * NT * 2 + (544 + 32) * 4 + 7) / 8;
     static constexpr int WORK = ev(mx(mx(W_PANEL, W_ELIM), mx(W_ITER, W_MAP)));
@@ -804,18 +808,25 @@ struct CsbKernel {
                 for (int e = 0; e < 4; e++) acc0[e] = wg_fma(B[O::has0 ? O::I1 + 1 + K : 0].v[e], tk, acc0[e]);
             }
         }
-        T *mine = pw + wave * 512;
+        T *mine = pw + wave * Lay::PWW;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            mine[((e)*4 + lq) * 16 + lr] = acc1[e];
-            mine[((4 + e) * 4 + lq) * 16 + lr] = acc0[e];
+            mine[(e * 4 + lq) * Lay::PWS + ((lr + 4 * e) & 15)] = acc1[e];
+            mine[((4 + e) * 4 + lq) * Lay::PWS + ((lr + 4 * (4 + e)) & 15)] = acc0[e];
         }
         wave_fence();
         T ytot;
         {
             const int v = lr & 7, h = lr >> 3;
             T p[8];
-            wg_read<8>(mine + (v * 4 + lq) * 16 + 8 * h, p);
+            const T *row = mine + (v * 4 + lq) * Lay::PWS;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {  // elements 8 h + 2 q, + 1 (an aligned pair stays one: the rotation is a multiple of 2)
+                T two[2];
+                wg_read<2>(row + ((8 * h + 2 * q + 4 * v) & 15), two);
+                p[2 * q] = two[0];
+                p[2 * q + 1] = two[1];
+            }
             T s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
             s += xchg16<8>(s);
             const int i = 16 * (v < 4 ? O::I1 : O::I0) + lq + 4 * (v & 3);
@@ -839,7 +850,7 @@ struct CsbKernel {
             // row lq holds the total of column block K = i (lq 0), i + 4 (lq 1), i + 7 (lq 2), i + 11 (lq 3)
             const int K = i + ((lq & 1) ? 4 : 0) + ((lq & 2) ? 7 : 0);
             const bool valid = ((lq & 1) ? i < 3 : true) && K < NB;
-            if (valid) xp[(16 * K + lr) * 8 + wave] = q;
+            if (valid) xp[wave * NP + 16 * K + lr] = q;
         }
     }
 
@@ -1054,7 +1065,8 @@ struct CsbKernel {
                 SQPH_BTICK(4)
                 if (t < NP) {  // x~ = W' y1; x relaxation (qp.cpp:96)
                     T p[8];
-                    wg_read<8>(xp + t * 8, p);
+#pragma unroll
+                    for (int w = 0; w < 8; w++) p[w] = xp[w * NP + t];
                     const T xtj = nown ? ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) : T(0);
                     xt[t] = xtj;
                     x = alpha * xtj + oma * x;

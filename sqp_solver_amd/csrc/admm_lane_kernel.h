@@ -17,8 +17,9 @@
 
 namespace sqph {
 
-// products of the iteration: fused multiply-add, like every other kernel of the library (round 3; -DSQPH_LANE_NO_FMA restores the
-// separate multiply and add of rounds 1-2, which tracked the oracle's unfused arithmetic almost bit for bit).  Measured on the MI355X:
+// products of the iteration: fused multiply-add, like every other kernel of the library (round 3; -DSQPH_LANE_NO_FMA gives separate
+// multiplies and adds back — NOT the exact statement order of rounds 1-2: the A'w accumulation keeps its two interleaved chains,
+// see the iteration below — for callers who want the oracle's unfused products).  Measured on the MI355X:
 // 0.083 -> 0.062 ms per 65,536 x 200 iterations, 72 -> 55 us per SQP-style launch, BatchSQP 19.9 -> 17.8 ms per 1,024 SimpleNLP
 // instances; iterates move by ~1e-8 relative on some adaptive-rho QPs (inside the 1e-6 bar).  The SQP parity suite
 // (tests/cpp/sqp_batch_test.cpp) is unchanged by it: 936 / 869 / 149 / 231 strict instances against 937 / 874 / 150 / 231 before,
@@ -34,7 +35,7 @@ __device__ __forceinline__ float lane_fma(float a, float b, float c) { return __
 
 // An ADMM iteration of a QP this small is ONE chain of dependent fp64 operations (w -> A'w -> W -> W' -> A x~ -> relax -> clip -> y), and a
 // lone wavefront pays ~25 cycles per link (measured, tools/xp/quad_lat.sh): the three helpers below are the same formulas with fewer
-// links (round 4: 20 -> 17 per iteration).  -DSQPH_LANE_NO_FMA keeps the statement order of rounds 1-2.
+// links (round 4: 20 -> 17 per iteration).  -DSQPH_LANE_NO_FMA keeps the unfused forms of these three helpers.
 // w = R (z - R^-1 y), the rhs tail of qp.cpp:275 pre-multiplied by R:  rho z - y in one fused operation
 template <typename T>
 __device__ __forceinline__ T lane_w(T rho, T rinv, T y, T z) {
