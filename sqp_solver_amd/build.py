@@ -64,7 +64,7 @@ def build_f32_tiles_experiment(verbose=False):
     """Measurement build for SURVEY section 8 row f4 (tests/test_f32_tiles.py, tools/f32_tiles_measure.py): the C2 / C3 kernels with
     their B and W' tiles rounded through fp32 (-DSQPH_F32_TILE_STORAGE).  Never loaded by the package itself."""
     out = os.path.join(LIBDIR, "libsqp_hip_f32tiles.so")
-    srcs = [os.path.join(CSRC, f) for f in ("capi.hip", "wg_nocheck.hip", "csr_nocheck.hip", "wg_f32.hip", "csr_dense.hip", "wg_stack.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("capi.hip", "wg_nocheck.hip", "csr_nocheck.hip", "wg_f32.hip", "csr_dense.hip", "wg_stack.hip", "csrb.hip")]
     if os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in sources()):
         return out
     cmd = [HIPCC] + FLAGS + ["-DSQPH_SLIM", "-DSQPH_SLIM_C2", "-DSQPH_F32_TILE_STORAGE", "-o", out] + srcs
