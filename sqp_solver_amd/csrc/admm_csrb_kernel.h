@@ -55,7 +55,8 @@ struct CsbLayout {
     static constexpr int o_t = WORK;                // t = sigma x - q + A'w, plain-indexed
     static constexpr int o_xt = o_t + NP;
     static constexpr int o_ux = o_xt + NP;
-    static constexpr int o_qv = o_ux + NP;
+    static constexpr int o_xv = o_ux + NP;         // the primal iterate x (LDS, not a register: see run())
+    static constexpr int o_qv = o_xv + NP;
     static constexpr int o_sj = o_qv + NP;
     static constexpr int o_flag = o_sj + NP;        // [8]
     static constexpr int o_red = o_flag + 8;        // [8][8]
@@ -199,7 +200,18 @@ struct CsbKernel {
         return o;
 #endif
     }
-    static __device__ __forceinline__ void wave_fence() { MS::wave_fence(); }
+    // orders the LDS operations of ONE wavefront for the compiler (the hardware executes a wavefront's LDS operations in order).
+    // NOT the release / acquire fence pair of admm_wg_msetup.h: at wavefront scope that lowers to s_waitcnt vmcnt(0) lgkmcnt(0), and
+    // behind the elimination's spill stores every fence then waited for scratch memory (4.9 k cycles per elimination step)
+    static __device__ __forceinline__ void wave_fence() {
+#ifdef SQPH_SIM
+        MS::wave_fence();
+#else
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#endif
+    }
     static __device__ __forceinline__ T opN(const T *b, int kq, int lr, int lq) { return b[lr * 17 + 4 * kq + lq]; }
     static __device__ __forceinline__ T opT(const T *b, int kq, int lr, int lq) { return b[(4 * kq + lq) * 17 + lr]; }
     static __device__ __forceinline__ void ldD(const T *b, int lr, int lq, sqph_acc4 &a) {
@@ -896,7 +908,7 @@ struct CsbKernel {
         T *tv = lds + Lay::o_t, *xt = lds + Lay::o_xt, *ux = lds + Lay::o_ux, *qv = lds + Lay::o_qv, *wv = lds + L.o_wv;
         T *lov = lds + L.o_lo, *upv = lds + L.o_up, *rinvv = lds + L.o_rinv;
         T *zs = lds + L.o_zs, *ys = lds + L.o_ys, *rhov = lds + L.o_rho;  // z, y, rho of the constraint rows live in LDS (written by a row's lead lane)
-        T *pw = lds + Lay::O_PW, *xp = lds + Lay::O_XP;
+        T *pw = lds + Lay::O_PW, *xp = lds + Lay::O_XP, *xv = lds + Lay::o_xv;
 
         const TIN *gP = a.P + (long)qp * a.sP;
         const TIN *gq = a.q + (long)qp * a.sq;
@@ -944,7 +956,9 @@ struct CsbKernel {
         const bool mown = (rmap & MAP_VALID) != 0, lead = mown && ((rmap >> 9) & 7) == 0;
         const bool nown = t < n;
 
-        T x = 0;
+        // x lives in LDS: as a register it was spilled inside the iteration loop (a scratch round trip on the chain between two
+        // barriers, twice per iteration); each lane touches its own element only
+        if (t < NP) xv[t] = T(0);
         if (t < NP) {
             qv[t] = nown ? (T)gq[t] : T(0);
             tv[t] = T(0);
@@ -975,9 +989,9 @@ struct CsbKernel {
                 ys[im] = keep ? sy[im] : T(0);
             }
             info.rho_updates += 1;
-            if (!(mode & MODE_SETUP) && nown) x = sx[t];
+            if (!(mode & MODE_SETUP) && nown) xv[t] = sx[t];
         } else {
-            if (nown) x = sx[t];
+            if (nown) xv[t] = sx[t];
             if (lead) {
                 const T rho = srho[im];
                 zs[im] = sz[im];
@@ -1028,7 +1042,7 @@ struct CsbKernel {
                 solving = true;
                 state_dirty = true;
                 if ((mode & MODE_COLD_RESET) && !a.warm_start) {
-                    x = 0;
+                    if (t < NP) xv[t] = T(0);
                     if (lead) zs[im] = ys[im] = T(0);
                 }
             }
@@ -1044,7 +1058,7 @@ struct CsbKernel {
             if (creg) load_col_regs(colptr, csc, val, cmap, cv, ci);
             for (int e = t; e < NP * 8; e += NT) xp[e] = T(0);
             if (lead) wv[im] = rhov[im] * (zs[im] - rinvv[im] * ys[im]);
-            if (t < NP) ux[t] = nown ? sigma * x - qv[t] : T(0);
+            if (t < NP) ux[t] = nown ? sigma * xv[t] - qv[t] : T(0);
             SQPH_BTICK(10)
             for (; iter <= a.max_iter; iter++) {
                 __syncthreads();
@@ -1058,19 +1072,29 @@ struct CsbKernel {
                 }
                 __syncthreads();
                 SQPH_BTICK(3)
-#define SQPH_CSB_CALL(W_) stages<W_>(B, tv, pw, xp, n, wave, lr, lq)
+                int li = l;
+                SQPH_OPAQUE_V(li);
+                const int lr_i = li & 15, lq_i = li >> 4;
+#define SQPH_CSB_CALL(W_) stages<W_>(B, tv, pw, xp, n, wave, lr_i, lq_i)
                 SQPH_CSB_SWITCH(wave, SQPH_CSB_CALL)
 #undef SQPH_CSB_CALL
                 __syncthreads();
                 SQPH_BTICK(4)
-                if (t < NP) {  // x~ = W' y1; x relaxation (qp.cpp:96)
-                    T p[8];
+                {   // x~ = W' y1; x relaxation (qp.cpp:96)
+                    int ti = t;
+                    SQPH_OPAQUE_V(ti);  // (addresses derived from the lane index are recomputed per phase: hoisted out of the loop they were spilled)
+                    if (ti < NP) {
+                        T p[8];
 #pragma unroll
-                    for (int w = 0; w < 8; w++) p[w] = xp[w * NP + t];
-                    const T xtj = nown ? ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) : T(0);
-                    xt[t] = xtj;
-                    x = alpha * xtj + oma * x;
-                    ux[t] = nown ? sigma * x - qv[t] : T(0);  // next iteration's u
+                        for (int w = 0; w < 8; w++) p[w] = xp[w * NP + ti];
+                        const T xo = xv[ti], qj = qv[ti];
+                        const bool own = ti < n;
+                        const T xtj = own ? ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) : T(0);
+                        xt[ti] = xtj;
+                        const T xn = alpha * xtj + oma * xo;
+                        xv[ti] = xn;
+                        ux[ti] = own ? sigma * xn - qj : T(0);  // next iteration's u
+                    }
                 }
                 __syncthreads();
                 SQPH_BTICK(5)
@@ -1106,7 +1130,7 @@ struct CsbKernel {
                 if (CHECKS && (check || adapt)) {
                     // update_state + residuals, qp.cpp:316-331, 353-361
                     __syncthreads();
-                    if (t < NP) xt[t] = nown ? x : T(0);
+                    if (t < NP) xt[t] = nown ? xv[t] : T(0);
                     if (lead) wv[im] = ys[im];
                     __syncthreads();
                     const T Ax = rreg ? reg_dot(rv, ri, xt, rmap) : csr_row_dot_lds(rowptr, col, val, xt, rmap);
@@ -1208,10 +1232,10 @@ struct CsbKernel {
         }
 #ifdef SQPH_PHASE_TIMING
         tacc[9] = __builtin_amdgcn_s_memtime() - tstart;
-        if (t < 16) x = (T)tacc[t];  // debug build only: wave 0's phase ticks instead of x[0..12)
+        if (t < 16) xv[t] = (T)tacc[t];  // debug build only: wave 0's phase ticks instead of x[0..16)
 #endif
         if (state_dirty) {
-            if (nown) sx[t] = x;
+            if (nown) sx[t] = xv[t];
             if (lead) {
                 sz[im] = zs[im];
                 sy[im] = ys[im];
