@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -105,6 +106,41 @@ static void sharded_vs_single(int n, int m, int B) {
         single.solve(single.packed(B, P.data(), q.data(), A.data(), l.data(), u.data()));
         for (int b = 0; b < B; b++) CHECK(!std::memcmp(multi.primal_solution(b), single.primal_solution(b), sizeof(double) * n));
         single.setup_solve(single.packed(B, P.data(), q.data(), A.data(), l.data(), u.data()));
+        {   // device-resident shards: one launch per device back to back from this thread, every shard's records posted in ONE
+            // sqph_gather_post_many (one RCCL group, the root's receives on one stream per source device)
+            static void *hip = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
+            CHECK(hip);
+            auto hipSetDevice_ = (int (*)(int))dlsym(hip, "hipSetDevice");
+            auto hipMalloc_ = (int (*)(void **, size_t))dlsym(hip, "hipMalloc");
+            auto hipMemcpy_ = (int (*)(void *, const void *, size_t, int))dlsym(hip, "hipMemcpy");
+            auto hipFree_ = (int (*)(void *))dlsym(hip, "hipFree");
+            CHECK(hipSetDevice_ && hipMalloc_ && hipMemcpy_ && hipFree_);
+            std::vector<MultiGpuBatchQPSolver<double>::Batch> shards;
+            std::vector<void *> bufs;
+            for (int gi = 0; gi < multi.num_devices(); gi++) {
+                const long long lo = multi.shard_begin(gi), hi = multi.shard_end(gi);
+                const size_t c = (size_t)(hi - lo);
+                CHECK(hipSetDevice_(devices[(size_t)gi]) == 0);
+                const double *src[5] = {&P[(size_t)lo * n * n], &q[(size_t)lo * n], &A[(size_t)lo * m * n], &l[(size_t)lo * m], &u[(size_t)lo * m]};
+                const size_t len[5] = {c * n * n, c * n, c * (size_t)m * n, c * m, c * m};
+                double *d[5];
+                for (int k = 0; k < 5; k++) {
+                    CHECK(hipMalloc_((void **)&d[k], len[k] * sizeof(double)) == 0);
+                    CHECK(hipMemcpy_(d[k], src[k], len[k] * sizeof(double), 1 /* hipMemcpyHostToDevice */) == 0);
+                    bufs.push_back(d[k]);
+                }
+                MultiGpuBatchQPSolver<double>::Batch b{(int)c, SQPH_DEVICE, d[0], d[1], d[2], d[3], d[4], (long long)n * n, n, (long long)m * n, m, m};
+                shards.push_back(b);
+            }
+            CHECK(hipSetDevice_(0) == 0);
+            multi.setup_solve_device(shards);
+            for (int b = 0; b < B; b++) {
+                CHECK(!std::memcmp(multi.primal_solution(b), single.primal_solution(b), sizeof(double) * n));
+                CHECK(!std::memcmp(multi.dual_solution(b), single.dual_solution(b), sizeof(double) * m));
+                CHECK(multi.info(b).iter == single.info(b).iter && multi.info(b).status == single.info(b).status);
+            }
+            for (void *bp : bufs) hipFree_(bp);
+        }
         bool distinct = true;
         for (size_t i = 0; i < devices.size(); i++) distinct = distinct && devices[i] == (int)i;
         if (pass || (distinct && G > 1)) CHECK(!std::strcmp(multi.gather_transport(), "rccl"));

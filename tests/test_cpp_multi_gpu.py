@@ -16,7 +16,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "multi_gpu_test.bin")
 def build():
     _capi.load()
     lib = _capi.lib_path()
-    subprocess.check_call(["g++", "-std=c++14", "-O1", "-pthread", "-o", EXE, SRC, lib, "-Wl,-rpath,$ORIGIN/../../sqp_solver_amd/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-pthread", "-o", EXE, SRC, lib, "-ldl", "-Wl,-rpath,$ORIGIN/../../sqp_solver_amd/lib", "-Wl,-rpath,/opt/rocm/lib"])
     return EXE
 
 

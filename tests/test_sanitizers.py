@@ -30,7 +30,7 @@ def test_oracle_under_asan_ubsan():
 def _link():
     _capi.load()
     lib = _capi.lib_path()
-    return [lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"]
+    return [lib, "-ldl", "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"]
 
 
 def test_facade_host_side_under_asan_ubsan():
