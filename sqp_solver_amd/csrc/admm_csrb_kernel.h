@@ -26,6 +26,10 @@
 #define SQPH_CSB_KR 14
 #endif
 
+#ifndef SQPH_CSB_EB
+#define SQPH_CSB_EB 4  // CSC entries of a column accumulated per batch in the S phase
+#endif
+
 namespace sqph {
 
 template <int NB>
@@ -527,6 +531,14 @@ struct CsbKernel {
         }
     }
 
+    // LDS add without a returned value (ds_add_f64)
+    static __device__ __forceinline__ void lds_add_f64(T *p, T v) {
+#ifdef SQPH_SIM
+        *p += v;
+#else
+        __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    }
     // ---------------------------------------------------------------- S = P_sym + sigma I + A' diag(rho) A -> blocks
     // One 32-column panel at a time in LDS: the 16-lane group g owns column j = 32 p + g — for every CSC entry (i, pos) of that
     // column, in row order, its lanes add rho_i A_ij * (row i of A) into the panel column (distinct k per lane: rows are
@@ -560,53 +572,73 @@ struct CsbKernel {
         const unsigned short *col = reinterpret_cast<const unsigned short *>(li + L.o_col);
         const T *val = lds + L.o_val, *rho = lds + L.o_rho;
         T *Sp = lds;
+        // the group's share of a column of P (lower triangle: rows j .. n - 1, 16 lanes x 14 = 224 rows), requested ONE PANEL AHEAD:
+        // P is read once per factorisation, cold from HBM — two exposed round trips per panel were a quarter of this phase
+        auto load_P = [&](int pp, T (&pv)[14]) {
+            const int j = 32 * pp + g;
+            const TIN *pc = gP + (long)(j < n ? j : 0) * n;
+#pragma unroll
+            for (int q = 0; q < 14; q++) {
+                const int k = j + c16 + 16 * q;
+                pv[q] = (j < n && k < n) ? (T)pc[k] : T(0);
+            }
+        };
+        T pv[14];
+        load_P(0, pv);
 #pragma unroll 1
         for (int p = 0; p < (NB + 1) / 2; p++) {
             __syncthreads();
             for (int e = t; e < 32 * LDP; e += NT) Sp[e] = 0;
             __syncthreads();
+            T pvn[14];
+            load_P(p + 1 < (NB + 1) / 2 ? p + 1 : p, pvn);
             const int j = 32 * p + g;
             if (j < n) {
-                // software-pipelined by one entry: the index / coefficient loads of entry e + 1 are issued before the
-                // read-modify-writes of entry e, which the compiler will not move loads across
+                constexpr int EB = SQPH_CSB_EB;
+                // EB CSC entries of the column at a time: their index / coefficient / row loads are all in flight together, the
+                // products go to the panel by ds_add_f64 (no returned value, so no entry waits for the LDS round trip of the one
+                // before it; additions to one address are issued by this wavefront in program order: deterministic sums).  As a
+                // read-modify-write chain, one entry at a time, this loop was ~700 cycles per entry (106 k of the phase's 211 k)
                 const int e1 = colptr[j + 1];
-                int e = colptr[j];
-                if (e < e1) {
-                    unsigned pk = csc[e];
-                    int i = (int)(pk >> 16);
-                    T coef = rho[i] * val[pk & 0xffffu];
-                    int f0 = rowptr[i], f1 = rowptr[i + 1];
-                    for (; e < e1; e++) {
-                        const unsigned pkn = csc[e + 1 < e1 ? e + 1 : e];
-                        const int in = (int)(pkn >> 16);
-                        const T coefn = rho[in] * val[pkn & 0xffffu];
-                        const int f0n = rowptr[in], f1n = rowptr[in + 1];
-                        for (int f = f0 + c16; f < f1; f += 16) {
-                            const int k = col[f];
-                            if (k >= j) Sp[g * LDP + k] = wg_fma(coef, val[f], Sp[g * LDP + k]);
+                for (int e = colptr[j]; e < e1; e += EB) {
+                    T cf[EB], v[EB];
+                    int f0[EB], f1[EB], k[EB];
+                    bool in[EB];
+#pragma unroll
+                    for (int bb = 0; bb < EB; bb++) {
+                        const bool ok = e + bb < e1;
+                        const unsigned pk = csc[ok ? e + bb : e];
+                        const int i = (int)(pk >> 16);
+                        cf[bb] = rho[i] * val[pk & 0xffffu];
+                        f0[bb] = rowptr[i] + c16;
+                        f1[bb] = ok ? rowptr[i + 1] : 0;
+                    }
+#pragma unroll
+                    for (int bb = 0; bb < EB; bb++) {
+                        in[bb] = f0[bb] < f1[bb];
+                        const int f = in[bb] ? f0[bb] : 0;
+                        k[bb] = col[f];
+                        v[bb] = val[f];
+                    }
+#pragma unroll
+                    for (int bb = 0; bb < EB; bb++)
+                        if (in[bb] && k[bb] >= j) lds_add_f64(&Sp[g * LDP + k[bb]], cf[bb] * v[bb]);
+#pragma unroll
+                    for (int bb = 0; bb < EB; bb++)  // (rows of more than 16 entries)
+                        for (int f = f0[bb] + 16; f < f1[bb]; f += 16) {
+                            const int kk = col[f];
+                            if (kk >= j) lds_add_f64(&Sp[g * LDP + kk], cf[bb] * val[f]);
                         }
-                        coef = coefn;
-                        f0 = f0n;
-                        f1 = f1n;
-                    }
                 }
-                // + lower triangle of P + sigma I: the group's 16 lanes walk down column j from the diagonal (all loads of a
-                // batch are issued before the first read-modify-write)
-                const TIN *pc = gP + (long)j * n;
-                for (int k0 = j; k0 < n; k0 += 16 * 7) {
-                    T pv[7];
+                // + lower triangle of P + sigma I
 #pragma unroll
-                    for (int q = 0; q < 7; q++) {
-                        const int k = k0 + c16 + 16 * q;
-                        pv[q] = k < n ? (T)pc[k] : T(0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 7; q++) {
-                        const int k = k0 + c16 + 16 * q;
-                        if (k < n) Sp[g * LDP + k] += pv[q] + (k == j ? sigma : T(0));
-                    }
+                for (int q = 0; q < 14; q++) {
+                    const int kk = j + c16 + 16 * q;
+                    if (kk < n) lds_add_f64(&Sp[g * LDP + kk], pv[q] + (kk == j ? sigma : T(0)));
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 14; q++) pv[q] = pvn[q];
             __syncthreads();
             pick_up(wave, p, n, Sp, lr, lq, B);
         }
