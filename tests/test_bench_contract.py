@@ -143,6 +143,20 @@ def test_recorded_default_line_carries_every_baseline_config():
         check_extra(d["extra"], EXTRA_KEYS_R4)
 
 
+def test_recorded_round5_default_line_is_the_whole_batch_with_every_config():
+    """round 5: the driver-recorded default line is configs[2]'s whole 65,536 batch (strong scaling) and carries the shard, configs[1],
+    [3] (the SQP driver, cold and warm-started) and [4] in `extra`, the PCIe-inclusive record and the traffic of the profiled kernels"""
+    f = os.path.join(ROOT, "profiles", "r05_bench_lines.jsonl")
+    if not os.path.exists(f):
+        pytest.skip("no round-5 lines recorded yet")
+    d = json.loads(open(f).readline())
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 65536 and d["n_gpus"] == 1
+    check_extra(d["extra"])
+    assert d["roofline"]["traffic"] and d["extra"]["c5"]["traffic"] and d["extra"]["c5"]["kernel"].startswith("csb_")
+    assert d["pcie_inclusive"]["value"] < d["value"]
+    assert d["cpu_baseline"]["threads_over_one_thread"] > 1
+
+
 @pytest.mark.gpu
 def test_default_bench_line_has_the_extra_configs():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-seconds", "2"],
