@@ -610,9 +610,17 @@ def cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt):
     native = oracle.native_lib() is not None
     pilot = min(B, max(cores * 4, 32))
     hp = host(pilot)
-    t0 = time.perf_counter()
-    oracle.solve_batch(*hp, settings=ost, nthreads=cores, dtype=ndt, native=native)
-    dt = max(time.perf_counter() - t0, 1e-6)
+    # thread count: every hardware thread, or one per SMT pair where that is faster (the oracle's per-QP working set — the (n+m)^2 KKT
+    # matrix and its factor, 360 KB at C3 — competes for the L2 the siblings share); the faster of the two pilots is the baseline
+    best = None
+    for nt in ([cores, cores // 2] if cores >= 16 else [cores]):
+        t0 = time.perf_counter()
+        oracle.solve_batch(*hp, settings=ost, nthreads=nt, dtype=ndt, native=native)
+        dtp = max(time.perf_counter() - t0, 1e-6)
+        if best is None or dtp < best[0]:
+            best = (dtp, nt)
+    dt, all_threads = best[0], cores
+    cores = best[1]
     sample = int(min(B, max(pilot, args.cpu_seconds / dt * pilot)))
     hs = host(sample)
     t0 = time.perf_counter()
@@ -633,6 +641,7 @@ def cpu_baseline(args, solver, P, q, A_cm, l, u, st, ndt):
         "value": sample / dt,
         "unit": "QP/s",
         "cores": cores,
+        "host_threads_available": all_threads,
         "kind": "port",
         "sample": "first %d QPs of rank 0's batch, same settings, oracle/qp_oracle.c with OpenMP over QPs, >= 4 QPs per thread (%.1f s)" % (sample, dt),
         "build": "-O3 -march=native -ffp-contract=off, compiled on this host" if native else "-O2 (portable copy: the native build failed here)",
