@@ -786,7 +786,9 @@ struct CsbKernel {
 #define SQPH_FTICK_ARGS , unsigned long long (&tacc)[16], unsigned long long &tprev
 #define SQPH_FTICK_PASS , tacc, tprev
 #define SQPH_FTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
+#define SQPH_BTICK(k) SQPH_FTICK(k)
 #else
+#define SQPH_BTICK(k)
 #define SQPH_FTICK_ARGS
 #define SQPH_FTICK_PASS
 #define SQPH_FTICK(k)
@@ -924,6 +926,219 @@ struct CsbKernel {
         }
     }
 
+    // ---------------------------------------------------------------- a check-free segment of `seg` iterations
+    // What an iteration needs besides the blocks (block-uniform values and this lane's maps), handed over as one record
+    struct IterCtx {
+        int n, rmap, cmap, im, flags;  // flags: 1 lead, 2 rreg, 4 creg
+        T alpha, oma, sigma;
+        int o_lo, o_up, o_rinv, o_wv, o_zs, o_ys, o_rho, o_val, o_rowptr, o_csc, o_col;
+    };
+    static __device__ __forceinline__ void segment(const sqph_acc4 (&B)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) {
+        SQPH_DYN_SMEM(smem);
+        T *lds = reinterpret_cast<T *>(smem);
+        const int *li = reinterpret_cast<const int *>(smem);
+        const int t = threadIdx.x, wave = wave_of(t), l = t & 63;
+        const int n = c.n, rmap = c.rmap, cmap = c.cmap, im = c.im;
+        const bool lead = c.flags & 1, rreg = c.flags & 2, creg = c.flags & 4;
+        const T alpha = c.alpha, oma = c.oma, sigma = c.sigma;
+        const int *rowptr = li + c.o_rowptr, *colptr = li + Lay::o_colptr;
+        const unsigned *csc = reinterpret_cast<const unsigned *>(li + c.o_csc);
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(li + c.o_col);
+        const T *val = lds + c.o_val;
+        T *tv = lds + Lay::o_t, *xt = lds + Lay::o_xt, *ux = lds + Lay::o_ux, *qv = lds + Lay::o_qv, *wv = lds + c.o_wv, *xv = lds + Lay::o_xv;
+        T *lov = lds + c.o_lo, *upv = lds + c.o_up, *rinvv = lds + c.o_rinv, *zs = lds + c.o_zs, *ys = lds + c.o_ys, *rhov = lds + c.o_rho;
+        T *pw = lds + Lay::O_PW, *xp = lds + Lay::O_XP;
+        // this lane's slices of A (CSR row group, CSC column group) in registers for the segment
+        T rv[KR], cv[KR];
+        int ri[KR / 2], ci[KR / 2];
+        if (rreg) load_row_regs(rowptr, col, val, rmap, rv, ri);
+        if (creg) load_col_regs(colptr, csc, val, cmap, cv, ci);
+#pragma unroll 1
+        for (int seg_i = 0; seg_i < seg; seg_i++) {
+                __syncthreads();
+                SQPH_BTICK(8)
+                {   // t = (sigma x - q) + A' w
+                    pin_blocks(B);
+                    const T s = creg ? reg_dot(cv, ci, wv, cmap) : csc_col_dot_lds(colptr, csc, val, wv, cmap);
+                    const int j = cmap & 511;
+                    if ((cmap & MAP_VALID) && ((cmap >> 9) & 7) == 0) tv[j] = ux[j] + s;
+                    pin_blocks(B);
+                }
+                __syncthreads();
+                SQPH_BTICK(3)
+                int li = l;
+                SQPH_OPAQUE_V(li);
+                const int lr_i = li & 15, lq_i = li >> 4;
+#define SQPH_CSB_CALL(W_) stages<W_>(B, tv, pw, xp, n, wave, lr_i, lq_i)
+                SQPH_CSB_SWITCH(wave, SQPH_CSB_CALL)
+#undef SQPH_CSB_CALL
+                __syncthreads();
+                SQPH_BTICK(4)
+                {   // x~ = W' y1; x relaxation (qp.cpp:96)
+                    int ti = t;
+                    SQPH_OPAQUE_V(ti);  // (addresses derived from the lane index are recomputed per phase: hoisted out of the loop they were spilled)
+                    if (ti < NP) {
+                        T p[8];
+#pragma unroll
+                        for (int w = 0; w < 8; w++) p[w] = xp[w * NP + ti];
+                        const T xo = xv[ti], qj = qv[ti];
+                        const bool own = ti < n;
+                        const T xtj = own ? ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) : T(0);
+                        xt[ti] = xtj;
+                        const T xn = alpha * xtj + oma * xo;
+                        xv[ti] = xn;
+                        ux[ti] = own ? sigma * xn - qj : T(0);  // next iteration's u
+                    }
+                }
+                __syncthreads();
+                SQPH_BTICK(5)
+                {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
+                    pin_blocks(B);
+                    const T zt = rreg ? reg_dot(rv, ri, xt, rmap) : csr_row_dot_lds(rowptr, col, val, xt, rmap);
+                    if (lead) {
+                        const T z = zs[im], y = ys[im], rho = rhov[im], rinv = rinvv[im];
+                        const T zr = alpha * zt + oma * z;
+                        T zn = zr + rinv * y;
+                        const T lo = lov[im], up = upv[im];
+                        zn = zn < lo ? lo : zn;
+                        zn = zn > up ? up : zn;
+                        const T yn = y + rho * (zr - zn);
+                        zs[im] = zn;
+                        ys[im] = yn;
+                        wv[im] = rho * (zn - rinv * yn);  // next iteration's w (read after the loop-top barrier)
+                    }
+                    pin_blocks(B);
+                }
+                SQPH_BTICK(6)
+                }
+    }
+    // the checking instantiation's segment as a REAL CALL with the blocks handed over through memory: inside the solve loop of that
+    // instantiation (nested in the refactorisation loop, next to the check) the allocator kept this lane's slices of A in scratch
+    // whatever the source did — both sparse products of every iteration then ran from scratch memory (15 k instead of 1.1 k cycles
+    // each).  Behind a call the segment is allocated on its own, like the no-check instantiation's loop.
+#ifdef SQPH_SIM
+    static inline void segment_call(const sqph_acc4 (&Bm)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) { segment(Bm, seg, c SQPH_FTICK_PASS); }
+#else
+    static __device__ __attribute__((noinline)) void segment_call(const sqph_acc4 (&Bm)[NB + 1], int seg_, const IterCtx &cm SQPH_FTICK_ARGS) {
+        IterCtx c = cm;
+        c.n = uniform_int(c.n);
+        c.o_lo = uniform_int(c.o_lo); c.o_up = uniform_int(c.o_up); c.o_rinv = uniform_int(c.o_rinv); c.o_wv = uniform_int(c.o_wv);
+        c.o_zs = uniform_int(c.o_zs); c.o_ys = uniform_int(c.o_ys); c.o_rho = uniform_int(c.o_rho); c.o_val = uniform_int(c.o_val);
+        c.o_rowptr = uniform_int(c.o_rowptr); c.o_csc = uniform_int(c.o_csc); c.o_col = uniform_int(c.o_col);
+        const int seg = uniform_int(seg_);
+        sqph_acc4 B[NB + 1];
+#pragma unroll
+        for (int s = 0; s <= NB; s++) B[s] = Bm[s];
+        segment(B, seg, c SQPH_FTICK_PASS);
+    }
+#endif
+
+    // the seven block-wide maxima of a termination check (|Ax|, |z|, |Ax - z|, |Px|, |A'y|, |q|, |Px + q + A'y|: qp.cpp:316-331, 353-361)
+    // with the sparse products read from LDS and P streamed from global memory; every lane of the workgroup calls this.
+    // PRIMAL FIRST, like the dense kernels: the dual half — A'y and above all P x, 8 n^2 bytes streamed per QP (2.6 GB per batch-wide
+    // check at config 5) — only runs when the primal test passes or the caller needs it (rho adaptation; the last check a solve can
+    // reach, whose residuals a MAX_ITER_EXCEEDED solve reports).  Returns whether v[3..6] were computed.
+#ifdef SQPH_SIM
+    static inline bool residuals(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int rmap, int cmap, bool lead, int im,
+                                 bool nown, T eps_abs, T eps_rel, bool force_dual, T (&v)[7]) {
+#else
+    static __device__ __attribute__((noinline)) bool residuals(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int rmap,
+                                                                int cmap, bool lead, int im, bool nown, T eps_abs, T eps_rel, bool force_dual,
+                                                                T (&v)[7]) {
+#endif
+        const int n = uniform_int(n_);
+        const TIN *__restrict__ gP = uniform_ptr(gP_);
+        const int t = threadIdx.x, wave = wave_of(t), l = t & 63;
+        (void)smem;
+        SQPH_DYN_SMEM(smem_l);  // (the LDS-qualified base: through the pointer argument the accesses would be flat ones)
+        T *lds = reinterpret_cast<T *>(smem_l);
+        const int *li = reinterpret_cast<const int *>(smem_l);
+        const int *rowptr = li + uniform_int(L.o_rowptr), *colptr = li + Lay::o_colptr;
+        const unsigned *csc = reinterpret_cast<const unsigned *>(li + uniform_int(L.o_csc));
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(li + uniform_int(L.o_col));
+        const T *val = lds + uniform_int(L.o_val);
+        T *tv = lds + Lay::o_t, *xt = lds + Lay::o_xt, *qv = lds + Lay::o_qv, *wv = lds + uniform_int(L.o_wv), *xv = lds + Lay::o_xv;
+        T *zs = lds + uniform_int(L.o_zs), *ys = lds + uniform_int(L.o_ys), *pw = lds + Lay::O_PW;
+        T *red = lds + Lay::o_red;
+        __syncthreads();
+        if (t < NP) xt[t] = nown ? xv[t] : T(0);
+        if (lead) wv[im] = ys[im];
+        __syncthreads();
+        const T Ax = csr_row_dot_lds(rowptr, col, val, xt, rmap);
+#pragma unroll
+        for (int e = 0; e < 7; e++) v[e] = T(0);
+        if (lead) {
+            const T z = zs[im];
+            v[0] = tabs(Ax);
+            v[1] = tabs(z);
+            v[2] = tabs(Ax - z);
+        }
+#pragma unroll
+        for (int e = 0; e < 3; e++) v[e] = wave_nanmax(v[e]);
+        if (l == 0) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) red[e * 8 + wave] = v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            T mval = red[e * 8];
+#pragma unroll
+            for (int k = 1; k < 8; k++) mval = nanmax(mval, red[e * 8 + k]);
+            v[e] = mval;
+        }
+        if (!force_dual && !(v[2] <= eps_abs + eps_rel * nanmax(v[0], v[1]))) {  // (block-uniform)
+            __syncthreads();
+            return false;
+        }
+        {   // A' y by the column map's lanes, handed to the lanes that track x through tv
+            const T sATy = csc_col_dot_lds(colptr, csc, val, wv, cmap);
+            if ((cmap & MAP_VALID) && ((cmap >> 9) & 7) == 0) tv[cmap & 511] = sATy;
+        }
+        {   // P x with the full P (both triangles, qp.cpp:324), streamed: lane t takes row t & 255 and every second column
+            const int i = t & 255, h = t >> 8;
+            T acc = 0;
+            if (i < n) {
+                const TIN *pr = gP + i;
+                int j = h;
+                for (; j + 6 < n; j += 8) {
+                    const T p0 = (T)pr[(long)j * n], p1 = (T)pr[(long)(j + 2) * n], p2 = (T)pr[(long)(j + 4) * n],
+                            p3 = (T)pr[(long)(j + 6) * n];
+                    acc = wg_fma(p0, xt[j], acc);
+                    acc = wg_fma(p1, xt[j + 2], acc);
+                    acc = wg_fma(p2, xt[j + 4], acc);
+                    acc = wg_fma(p3, xt[j + 6], acc);
+                }
+                for (; j < n; j += 2) acc = wg_fma((T)pr[(long)j * n], xt[j], acc);
+            }
+            pw[h * 256 + i] = acc;
+        }
+        __syncthreads();
+        if (nown) {
+            const T Px = pw[t] + pw[256 + t], ATy = tv[t], q = qv[t];
+            v[3] = tabs(Px);
+            v[4] = tabs(ATy);
+            v[5] = tabs(q);
+            v[6] = tabs(Px + q + ATy);
+        }
+#pragma unroll
+        for (int e = 3; e < 7; e++) v[e] = wave_nanmax(v[e]);
+        if (l == 0) {
+#pragma unroll
+            for (int e = 3; e < 7; e++) red[e * 8 + wave] = v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 3; e < 7; e++) {
+            T mval = red[e * 8];
+#pragma unroll
+            for (int k = 1; k < 8; k++) mval = nanmax(mval, red[e * 8 + k]);
+            v[e] = mval;
+        }
+        __syncthreads();
+        return true;
+    }
+
     // CHECKS = false: the instantiation for calls that never look at the residuals (check_termination == 0, no adaptive rho)
     template <bool CHECKS = true>
     static __device__ __forceinline__ void run(const KArgs<T, TIN> &a, const CsrArgs<TIN> &ca, unsigned char *smem) {
@@ -963,9 +1178,6 @@ struct CsbKernel {
 #ifdef SQPH_PHASE_TIMING
         unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
         const unsigned long long tstart = tprev;
-#define SQPH_BTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
-#else
-#define SQPH_BTICK(k)
 #endif
         // element owners: lane j < n tracks x_j; the lanes the ROW MAP gives constraint row i track z_i, y_i, rho_i (all of them keep a
         // copy, the one with part 0 writes); the COLUMN MAP's lanes sum the columns of A' w
@@ -1036,8 +1248,6 @@ struct CsbKernel {
         sqph_acc4 B[NB + 1];
 #pragma unroll
         for (int s = 0; s <= NB; s++) B[s] = sqph_acc4{{0, 0, 0, 0}};  // (defined on every path: the slots a wavefront does not own are never touched)
-        T rv[KR], cv[KR];
-        int ri[KR / 2], ci[KR / 2];
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
@@ -1052,11 +1262,22 @@ struct CsbKernel {
             if (need_factor) {
                 __syncthreads();
                 SQPH_BTICK(10)
-                const bool ok = factor(gP, n, sigma, L, smem, t, B SQPH_FTICK_PASS);
-                SQPH_BTICK(11)
-                if (!(mode & MODE_NO_FACTOR_STORE)) {  // kept for later solve() calls
-                    store_blocks(wave, gW, n, lr, lq, B);
+                bool ok;
+                if constexpr (CHECKS) {
+                    // (in this instantiation B is handed to segment_call by reference and therefore lives in memory: the set-up works on
+                    // a register copy of its own)
+                    sqph_acc4 Bf[NB + 1];
+#pragma unroll
+                    for (int s = 0; s <= NB; s++) Bf[s] = sqph_acc4{{0, 0, 0, 0}};
+                    ok = factor(gP, n, sigma, L, smem, t, Bf SQPH_FTICK_PASS);
+                    if (!(mode & MODE_NO_FACTOR_STORE)) store_blocks(wave, gW, n, lr, lq, Bf);  // kept for later solve() calls
+#pragma unroll
+                    for (int s = 0; s <= NB; s++) B[s] = Bf[s];
+                } else {
+                    ok = factor(gP, n, sigma, L, smem, t, B SQPH_FTICK_PASS);
+                    if (!(mode & MODE_NO_FACTOR_STORE)) store_blocks(wave, gW, n, lr, lq, B);  // kept for later solve() calls
                 }
+                SQPH_BTICK(11)
                 __syncthreads();
                 need_factor = false;
                 if (!solving) {
@@ -1082,150 +1303,65 @@ struct CsbKernel {
             __syncthreads();
             // the blocks start new live ranges here: whatever the set-up's register pressure made the allocator do with them, the
             // iteration loop gets them in registers
+            if constexpr (!CHECKS) {
 #pragma unroll
-            for (int s = 0; s <= NB; s++)
+                for (int s = 0; s <= NB; s++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) B[s].v[e] = split_range(B[s].v[e]);
-            if (rreg) load_row_regs(rowptr, col, val, rmap, rv, ri);
-            if (creg) load_col_regs(colptr, csc, val, cmap, cv, ci);
+                    for (int e = 0; e < 4; e++) B[s].v[e] = split_range(B[s].v[e]);
+            }
             for (int e = t; e < NP * 8; e += NT) xp[e] = T(0);
             if (lead) wv[im] = rhov[im] * (zs[im] - rinvv[im] * ys[im]);
             if (t < NP) ux[t] = nown ? sigma * xv[t] - qv[t] : T(0);
             SQPH_BTICK(10)
-            for (; iter <= a.max_iter; iter++) {
-                __syncthreads();
-                SQPH_BTICK(8)
-                {   // t = (sigma x - q) + A' w
-                    pin_blocks(B);
-                    const T s = creg ? reg_dot(cv, ci, wv, cmap) : csc_col_dot_lds(colptr, csc, val, wv, cmap);
-                    const int j = cmap & 511;
-                    if ((cmap & MAP_VALID) && ((cmap >> 9) & 7) == 0) tv[j] = ux[j] + s;
-                    pin_blocks(B);
+            // Segments: the iterations up to the next residual check run in an inner loop that contains no check code — with the check
+            // (it streams P and runs both sparse products again) inside the iteration loop the allocator reloaded the blocks from scratch
+            // in EVERY iteration (153 scratch loads per iteration; config 5 under the default settings 245 ms against the tile kernel's 97)
+            const IterCtx ic{n, rmap, cmap, im, (lead ? 1 : 0) | (rreg ? 2 : 0) | (creg ? 4 : 0), alpha, oma, sigma,
+                             L.o_lo, L.o_up, L.o_rinv, L.o_wv, L.o_zs, L.o_ys, L.o_rho, L.o_val, L.o_rowptr, L.o_csc, L.o_col};
+            while (iter <= a.max_iter) {
+                int seg = a.max_iter - iter + 1;
+                if constexpr (CHECKS) {
+                    if (next_check > 0 && next_check < seg) seg = next_check;
+                    if (next_adapt > 0 && next_adapt < seg) seg = next_adapt;
                 }
-                __syncthreads();
-                SQPH_BTICK(3)
-                int li = l;
-                SQPH_OPAQUE_V(li);
-                const int lr_i = li & 15, lq_i = li >> 4;
-#define SQPH_CSB_CALL(W_) stages<W_>(B, tv, pw, xp, n, wave, lr_i, lq_i)
-                SQPH_CSB_SWITCH(wave, SQPH_CSB_CALL)
-#undef SQPH_CSB_CALL
-                __syncthreads();
-                SQPH_BTICK(4)
-                {   // x~ = W' y1; x relaxation (qp.cpp:96)
-                    int ti = t;
-                    SQPH_OPAQUE_V(ti);  // (addresses derived from the lane index are recomputed per phase: hoisted out of the loop they were spilled)
-                    if (ti < NP) {
-                        T p[8];
-#pragma unroll
-                        for (int w = 0; w < 8; w++) p[w] = xp[w * NP + ti];
-                        const T xo = xv[ti], qj = qv[ti];
-                        const bool own = ti < n;
-                        const T xtj = own ? ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) : T(0);
-                        xt[ti] = xtj;
-                        const T xn = alpha * xtj + oma * xo;
-                        xv[ti] = xn;
-                        ux[ti] = own ? sigma * xn - qj : T(0);  // next iteration's u
-                    }
+                if constexpr (CHECKS) {
+                    // what only the checks need (the info record, the scalar rho) waits in LDS while a segment runs: every lane
+                    // writes the same values (they are block-uniform), every lane reads them back behind the segment
+                    T *park = lds + Lay::o_red + 56;
+                    park[0] = (T)info.status; park[1] = (T)info.rho_updates; park[2] = (T)info.rho_estimate;
+                    park[3] = (T)info.res_prim; park[4] = (T)info.res_dual; park[5] = rho_s;
                 }
-                __syncthreads();
-                SQPH_BTICK(5)
-                {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
-                    pin_blocks(B);
-                    const T zt = rreg ? reg_dot(rv, ri, xt, rmap) : csr_row_dot_lds(rowptr, col, val, xt, rmap);
-                    if (lead) {
-                        const T z = zs[im], y = ys[im], rho = rhov[im], rinv = rinvv[im];
-                        const T zr = alpha * zt + oma * z;
-                        T zn = zr + rinv * y;
-                        const T lo = lov[im], up = upv[im];
-                        zn = zn < lo ? lo : zn;
-                        zn = zn > up ? up : zn;
-                        const T yn = y + rho * (zr - zn);
-                        zs[im] = zn;
-                        ys[im] = yn;
-                        wv[im] = rho * (zn - rinv * yn);  // next iteration's w (read after the loop-top barrier)
-                    }
-                    pin_blocks(B);
+                if constexpr (CHECKS) segment_call(B, seg, ic SQPH_FTICK_PASS);
+                else segment(B, seg, ic SQPH_FTICK_PASS);
+                iter += seg - 1;  // the iteration the checks below belong to (qp.cpp:105: iter % check_termination == 0)
+                if constexpr (CHECKS) {
+                    const T *park = lds + Lay::o_red + 56;
+                    info.status = (int)park[0]; info.rho_updates = (int)park[1]; info.rho_estimate = (double)park[2];
+                    info.res_prim = (double)park[3]; info.res_dual = (double)park[4]; rho_s = park[5];
                 }
-                SQPH_BTICK(6)
                 bool check = false, adapt = false;
                 if constexpr (CHECKS) {
-                    if (--next_check == 0) {
+                    if (next_check > 0 && (next_check -= seg) == 0) {
                         check = true;
                         next_check = a.check_termination;
                     }
-                    if (--next_adapt == 0) {
+                    if (next_adapt > 0 && (next_adapt -= seg) == 0) {
                         adapt = true;
                         next_adapt = a.adaptive_rho_interval;
                     }
                 }
                 if (CHECKS && (check || adapt)) {
-                    // update_state + residuals, qp.cpp:316-331, 353-361
-                    __syncthreads();
-                    if (t < NP) xt[t] = nown ? xv[t] : T(0);
-                    if (lead) wv[im] = ys[im];
-                    __syncthreads();
-                    const T Ax = rreg ? reg_dot(rv, ri, xt, rmap) : csr_row_dot_lds(rowptr, col, val, xt, rmap);
-                    {   // A' y by the column map's lanes, handed to the lanes that track x through tv
-                        const T sATy = creg ? reg_dot(cv, ci, wv, cmap) : csc_col_dot_lds(colptr, csc, val, wv, cmap);
-                        if ((cmap & MAP_VALID) && ((cmap >> 9) & 7) == 0) tv[cmap & 511] = sATy;
-                    }
-                    {   // P x with the full P (both triangles, qp.cpp:324), streamed: lane t takes row t & 255 and every second column
-                        const int i = t & 255, h = t >> 8;
-                        T acc = 0;
-                        if (i < n) {
-                            const TIN *pr = gP + i;
-                            int j = h;
-                            for (; j + 6 < n; j += 8) {
-                                const T p0 = (T)pr[(long)j * n], p1 = (T)pr[(long)(j + 2) * n], p2 = (T)pr[(long)(j + 4) * n],
-                                        p3 = (T)pr[(long)(j + 6) * n];
-                                acc = wg_fma(p0, xt[j], acc);
-                                acc = wg_fma(p1, xt[j + 2], acc);
-                                acc = wg_fma(p2, xt[j + 4], acc);
-                                acc = wg_fma(p3, xt[j + 6], acc);
-                            }
-                            for (; j < n; j += 2) acc = wg_fma((T)pr[(long)j * n], xt[j], acc);
-                        }
-                        pw[h * 256 + i] = acc;
-                    }
-                    __syncthreads();
-                    T v[7] = {0, 0, 0, 0, 0, 0, 0};
-                    if (lead) {
-                        const T z = zs[im];
-                        v[0] = tabs(Ax);
-                        v[1] = tabs(z);
-                        v[2] = tabs(Ax - z);
-                    }
-                    if (nown) {
-                        const T Px = pw[t] + pw[256 + t], ATy = tv[t], q = qv[t];
-                        v[3] = tabs(Px);
-                        v[4] = tabs(ATy);
-                        v[5] = tabs(q);
-                        v[6] = tabs(Px + q + ATy);
-                    }
-                    {
-                        T *red = lds + Lay::o_red;
-#pragma unroll
-                        for (int e = 0; e < 7; e++) v[e] = wave_nanmax(v[e]);
-                        if (l == 0) {
-#pragma unroll
-                            for (int e = 0; e < 7; e++) red[e * 8 + wave] = v[e];
-                        }
-                        __syncthreads();
-#pragma unroll
-                        for (int e = 0; e < 7; e++) {
-                            T mval = red[e * 8];
-#pragma unroll
-                            for (int k = 1; k < 8; k++) mval = nanmax(mval, red[e * 8 + k]);
-                            v[e] = mval;
-                        }
-                        __syncthreads();
-                    }
+                    // update_state + residuals, qp.cpp:316-331, 353-361 — OUT OF LINE (residuals() is a real call): inlined, the block's
+                    // registers (P streamed eight loads deep, both sparse products, seven reductions) were part of the iteration loop's
+                    // allocation problem, and the register-resident slices of A lived in scratch for the whole solve
+                    T v[7];
+                    const bool last_check = check && iter + a.check_termination > a.max_iter;
+                    const bool dual = residuals(gP, n, L, smem, rmap, cmap, lead, im, nown, (T)a.eps_abs, (T)a.eps_rel, adapt || last_check, v);
                     const T nrm_prim = nanmax(v[0], v[1]);
                     const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
                     info.res_prim = (double)v[2];
-                    info.res_dual = (double)v[6];
-                    if (check) {
+                    if (dual) info.res_dual = (double)v[6];  // (otherwise the primal test failed: the solve goes on, and the last check it can reach is a full one)
+                    if (check && dual) {
                         if (v[2] <= a.eps_abs + a.eps_rel * nrm_prim && v[6] <= a.eps_abs + a.eps_rel * nrm_dual) {
                             info.status = SQPH_SOLVED;
                             break;
@@ -1255,6 +1391,7 @@ struct CsbKernel {
                     __syncthreads();
                     if (lead) wv[im] = rhov[im] * (zs[im] - rinvv[im] * ys[im]);
                 }
+                iter++;
             }
             if (!need_factor) break;
         }

@@ -13,6 +13,9 @@ tile = lambda a: np.concatenate([a] * rep)[:B]
 s = QPSolverBatch(n, m, B)
 s.settings.max_iter = iters
 s.settings.check_termination = 0
+if os.environ.get("SQPH_PT_CHECKS"):  # the checking instantiation: a check every 25 iterations that never passes
+    s.settings.check_termination = 25
+    s.settings.eps_abs = s.settings.eps_rel = 1e-300
 args = [tile(a) for a in (P, q, rp, ci, v, l, u)]
 s.setup_solve_csr(*args)
 s.enable_timing(True)
