@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP kernels through the C-ABI
 (libsqp_hip.so via sqp_solver_amd.QPSolverBatch) against the CPU oracle on identical inputs."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -176,6 +177,33 @@ def test_csr_falls_back_when_the_sparse_matrix_does_not_fit_lds():
     x, y, z, info = s.solution()
     xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings))
     assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
+
+
+def test_csr_checking_instantiation_is_not_slower_per_iteration():
+    """a guard, not a benchmark: the block-row kernel's checking instantiation once kept its register-resident slices of A in scratch
+    (7x the no-check kernel's time per iteration, found only by timing it); 100 iterations with four primal-only checks must stay
+    within 1.5x of 100 unchecked iterations"""
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_csr
+
+    B, n, m = 1024, 200, 400
+    P, q, rp, ci, v, l, u, A, nnz = bench_csr.make(B, n, m, 0.05, 5, torch.device("cuda:0"))
+    ms = {}
+    for name, ct in (("fixed", 0), ("checked", 25)):
+        s = make_gpu(n, m, B)
+        s.settings.max_iter = 100
+        s.settings.check_termination = ct
+        s.settings.eps_abs = s.settings.eps_rel = 1e-300  # (no check ever passes)
+        s.setup_solve_csr(P, q, rp, ci, v, l, u, colmajor=True)
+        s.enable_timing(True)
+        for _ in range(3):
+            s.setup_solve_csr(P, q, rp, ci, v, l, u, colmajor=True)
+        ms[name] = float(np.median(s.collect_kernel_ms()[-3:]))
+        assert s.kernel_name().startswith("csb_")
+        s.close()
+    assert ms["checked"] <= 1.5 * ms["fixed"], ms
 
 
 def test_csr_edge_cases():
