@@ -55,6 +55,10 @@
  *     drop-in class qp_solver::QPSolver<Scalar>::solve (include/sqp_hip/qp.hpp) compares its
  *     argument with the A of the preceding setup()/update_qp() and throws
  *     std::invalid_argument on a difference instead of solving another problem silently.
+ *   - reproducibility: repeated calls on the same inputs are bit-identical (no atomics whose order is left to the hardware).
+ *     The kernel is chosen by shape, settings AND, for m <= 4 with the one-QP-per-lane kernel, by the batch size of the call (a
+ *     four-lanes-per-QP form serves batches <= 2,048): the same QP may then differ in its last bits between a small and a large
+ *     batch (another summation order of A'w; both within the parity bar).
  *   - thread safety: distinct handles may be used from distinct host threads concurrently
  *     (tests/cpp/qp_facade_test.cpp: testTwoHostThreadsTwoHandles); one handle must not be.
  *     sqph_global_error() is per thread, sqph_last_error(s) per handle.
