@@ -497,37 +497,153 @@ struct CsbKernel {
         }
         return group_sum(a0 + a1, (mp >> 12) & 3);
     }
-    static __device__ __forceinline__ void load_row_regs(const int *rowptr, const unsigned short *col, const T *val, int mp, T (&sv)[KR],
-                                                         int (&si)[KR / 2]) {
+    // ---------------------------------------------------------------- which register slot each entry of a lane's slice goes to
+    // The two sparse products gather a vector element per entry: 2 x 14 ds_read_b64 per lane and iteration whose addresses are the
+    // matrix's column / row indices, i.e. random over the 32 bank pairs (2.1 - 2.3 LDS passes per half-wavefront and slot instead of
+    // 1; the slots a lane does not fill gathered element 0, one more address on bank 0).  A slot's position in a lane does not matter
+    // to the product, so the entries are PLACED: a lane claims, for each entry, a slot in which no other lane of its half-wavefront
+    // reads the entry's bank.  Rounds in lockstep, wavefront-local: every lane with an entry left proposes one (slot, bank) cell by
+    // ds_min_u32 of its lane number, the lowest proposer wins the cell (recorded in the bank's slot mask by ds_or_b32), the others
+    // propose again.  Minimum and OR commute and a wavefront's LDS operations execute in order: the outcome does not depend on the
+    // order the LDS serves the atomics of one instruction in (repeated solves stay bit-identical).  Unfilled slots gather an element
+    // whose bank no lane of the half-wavefront reads in that slot (one address: a broadcast).  tools/xp/gather_model.py: 470 + 510 ->
+    // 265 + 275 passes per iteration at config 5 (floor 224 + 224), 16 - 18 rounds.
+    // Code words: one byte per slot — the entry's ordinal in the lane's slice, or 0x80 | the element an unfilled slot gathers.
+    struct SlotCode {
+        unsigned long long lo, hi;  // slots 0 - 7, 8 - 13
+    };
+    static constexpr int PLACE_WORDS = 32 + KR * 32 + 16;  // per half-wavefront: slot mask per bank | lowest proposer per cell | pad element per slot
+    static_assert(16 * PLACE_WORDS * 4 <= Lay::WORK * 8, "the placement tables fit the work area");
+    static __device__ __forceinline__ void lds_min_u(unsigned *p, unsigned v) {
+#ifdef SQPH_SIM
+        *p = *p < v ? *p : v;
+#else
+        __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    }
+    static __device__ __forceinline__ void lds_or_u(unsigned *p, unsigned v) {
+#ifdef SQPH_SIM
+        *p |= v;
+#else
+        __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+    }
+    static __device__ __forceinline__ bool wave_any(bool p) {
+#ifdef SQPH_SIM
+        int v = p ? 1 : 0;
+        const int lane = (int)(threadIdx.x & 63);
+        for (int d = 1; d < 64; d <<= 1) v |= shfl_i(v, lane ^ d);
+        return v != 0;
+#else
+        return __builtin_amdgcn_ballot_w64(p) != 0;
+#endif
+    }
+    static __device__ __forceinline__ void code_set(SlotCode &c, int s, unsigned v) {
+        const int sh = 8 * (s & 7);
+        const unsigned long long m = ~(0xffull << sh), w = (unsigned long long)v << sh;
+        if (s < 8) c.lo = (c.lo & m) | w;
+        else c.hi = (c.hi & m) | w;
+    }
+    static __device__ __forceinline__ unsigned code_get(const SlotCode &c, int s) {
+        return (unsigned)((s < 8 ? c.lo : c.hi) >> (8 * (s & 7))) & 0xffu;
+    }
+    // ROWS: the CSR slices (gathering x~, `vlen` = NP elements are defined); otherwise the CSC slices (gathering w, vlen = m)
+    template <bool ROWS>
+    static __device__ __forceinline__ SlotCode place_slots(const int *ptr, const unsigned short *col, const unsigned *csc, int mp, int vlen,
+                                                          unsigned *area, int t) {
+        constexpr unsigned KMASK = (1u << KR) - 1u;
+        const int hw = t >> 5, lh = t & 31;
+        unsigned *taken = area + hw * PLACE_WORDS, *cell = taken + 32, *pad = cell + KR * 32;
+        for (int i = lh; i < PLACE_WORDS; i += 32) taken[i] = (i >= 32 && i < 32 + KR * 32) ? 0xffffffffu : 0u;
+        wave_fence();
         const bool own = (mp & MAP_VALID) != 0;
         const int i = mp & 511, p = 1 << ((mp >> 12) & 3);
-        const int e1 = own ? rowptr[i + 1] : 0;
+        const int e1 = own ? ptr[i + 1] : 0;
+        const int e0 = own ? ptr[i] + ((mp >> 9) & 7) : 0;
+        const int cnt = e1 > e0 ? (e1 - e0 + p - 1) / p : 0;  // <= KR: the orientation is register resident
+        SlotCode c{0x8080808080808080ull, 0x8080808080808080ull};
+        unsigned used = 0;
+        int e = 0;
+#pragma unroll 1
+        for (int round = 0; round < 4 * KR; round++) {
+            const bool active = e < cnt;
+            if (!wave_any(active)) break;
+            int s = -1, b = 0;
+            if (active) {
+                const int pos = e0 + e * p;
+                b = (ROWS ? (int)col[pos] : (int)(csc[pos] >> 16)) & 31;
+                const unsigned avail = ~(taken[b] | used) & KMASK;
+                if (avail) {
+                    const int start = (e + lh) % KR;  // first choices spread over the slots
+                    const unsigned from = (avail >> start) << start;
+                    s = __builtin_ffs((int)(from ? from : avail)) - 1;
+                    lds_min_u(&cell[s * 32 + b], (unsigned)lh);
+                } else {  // the bank is read in every slot this lane has left: any of them
+                    const int f = __builtin_ffs((int)(~used & KMASK)) - 1;
+                    code_set(c, f, (unsigned)e);
+                    used |= 1u << f;
+                    e++;
+                }
+            }
+            wave_fence();
+            if (s >= 0 && cell[s * 32 + b] == (unsigned)lh) {
+                lds_or_u(&taken[b], 1u << s);
+                code_set(c, s, (unsigned)e);
+                used |= 1u << s;
+                e++;
+            }
+            wave_fence();
+        }
+        while (e < cnt) {  // (what the rounds left)
+            const int f = __builtin_ffs((int)(~used & KMASK)) - 1;
+            code_set(c, f, (unsigned)e);
+            used |= 1u << f;
+            e++;
+        }
+        if (lh < KR) {  // an element (< vlen, < 32) whose bank nobody reads in slot lh
+            unsigned freeb = 0;
+#pragma unroll
+            for (int b = 0; b < 32; b++) freeb |= ((~taken[b] >> lh) & 1u) << b;
+            if (vlen < 32) freeb &= (1u << vlen) - 1u;
+            pad[lh] = freeb ? (unsigned)(__builtin_ffs((int)freeb) - 1) : 0u;
+        }
+        wave_fence();
+#pragma unroll
+        for (int k = 0; k < KR; k++)
+            if (!((used >> k) & 1u)) code_set(c, k, 0x80u | pad[k]);
+        wave_fence();
+        return c;
+    }
+    static __device__ __forceinline__ void load_row_regs(const int *rowptr, const unsigned short *col, const T *val, int mp, const SlotCode &sc,
+                                                         T (&sv)[KR], int (&si)[KR / 2]) {
+        const bool own = (mp & MAP_VALID) != 0;
+        const int i = mp & 511, p = 1 << ((mp >> 12) & 3);
         const int e0 = own ? rowptr[i] + ((mp >> 9) & 7) : 0;
 #pragma unroll
         for (int k = 0; k < KR / 2; k++) si[k] = 0;
 #pragma unroll
         for (int k = 0; k < KR; k++) {
-            const int e = e0 + k * p;
-            const bool in = own && e < e1;
+            const unsigned code = code_get(sc, k);
+            const bool in = !(code & 0x80u);
+            const int e = e0 + (int)(code & 15u) * p;
             sv[k] = in ? val[e] : T(0);
-            si[k >> 1] |= (in ? 8 * (int)col[e] : 0) << (16 * (k & 1));
+            si[k >> 1] |= (in ? 8 * (int)col[e] : 8 * (int)(code & 31u)) << (16 * (k & 1));
         }
     }
-    static __device__ __forceinline__ void load_col_regs(const int *colptr, const unsigned *csc, const T *val, int mp, T (&sv)[KR],
-                                                         int (&si)[KR / 2]) {
+    static __device__ __forceinline__ void load_col_regs(const int *colptr, const unsigned *csc, const T *val, int mp, const SlotCode &sc,
+                                                         T (&sv)[KR], int (&si)[KR / 2]) {
         const bool own = (mp & MAP_VALID) != 0;
         const int j = mp & 511, p = 1 << ((mp >> 12) & 3);
-        const int e1 = own ? colptr[j + 1] : 0;
         const int e0 = own ? colptr[j] + ((mp >> 9) & 7) : 0;
 #pragma unroll
         for (int k = 0; k < KR / 2; k++) si[k] = 0;
 #pragma unroll
         for (int k = 0; k < KR; k++) {
-            const int e = e0 + k * p;
-            const bool in = own && e < e1;
-            const unsigned pk = in ? csc[e] : 0u;
+            const unsigned code = code_get(sc, k);
+            const bool in = !(code & 0x80u);
+            const unsigned pk = in ? csc[e0 + (int)(code & 15u) * p] : 0u;
             sv[k] = in ? val[pk & 0xffffu] : T(0);
-            si[k >> 1] |= (int)(8 * (pk >> 16)) << (16 * (k & 1));
+            si[k >> 1] |= (in ? (int)(8 * (pk >> 16)) : 8 * (int)(code & 31u)) << (16 * (k & 1));
         }
     }
 
@@ -932,6 +1048,7 @@ struct CsbKernel {
         int n, rmap, cmap, im, flags;  // flags: 1 lead, 2 rreg, 4 creg
         T alpha, oma, sigma;
         int o_lo, o_up, o_rinv, o_wv, o_zs, o_ys, o_rho, o_val, o_rowptr, o_csc, o_col;
+        SlotCode rsc, csc_;  // this lane's slot codes (place_slots)
     };
     static __device__ __forceinline__ void segment(const sqph_acc4 (&B)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) {
         SQPH_DYN_SMEM(smem);
@@ -951,8 +1068,8 @@ struct CsbKernel {
         // this lane's slices of A (CSR row group, CSC column group) in registers for the segment
         T rv[KR], cv[KR];
         int ri[KR / 2], ci[KR / 2];
-        if (rreg) load_row_regs(rowptr, col, val, rmap, rv, ri);
-        if (creg) load_col_regs(colptr, csc, val, cmap, cv, ci);
+        if (rreg) load_row_regs(rowptr, col, val, rmap, c.rsc, rv, ri);
+        if (creg) load_col_regs(colptr, csc, val, cmap, c.csc_, cv, ci);
 #pragma unroll 1
         for (int seg_i = 0; seg_i < seg; seg_i++) {
                 __syncthreads();
@@ -1309,6 +1426,13 @@ struct CsbKernel {
 #pragma unroll
                     for (int e = 0; e < 4; e++) B[s].v[e] = split_range(B[s].v[e]);
             }
+            SlotCode rsc{0, 0}, csc_{0, 0};
+            {   // slots of the register-resident slices (the work area is idle; per half-wavefront tables, no workgroup barrier inside)
+                unsigned *area = reinterpret_cast<unsigned *>(lds);
+                if (rreg) rsc = place_slots<true>(rowptr, col, csc, rmap, NP, area, t);
+                if (creg) csc_ = place_slots<false>(colptr, col, csc, cmap, m, area, t);
+                __syncthreads();
+            }
             for (int e = t; e < NP * 8; e += NT) xp[e] = T(0);
             if (lead) wv[im] = rhov[im] * (zs[im] - rinvv[im] * ys[im]);
             if (t < NP) ux[t] = nown ? sigma * xv[t] - qv[t] : T(0);
@@ -1317,7 +1441,7 @@ struct CsbKernel {
             // (it streams P and runs both sparse products again) inside the iteration loop the allocator reloaded the blocks from scratch
             // in EVERY iteration (153 scratch loads per iteration; config 5 under the default settings 245 ms against the tile kernel's 97)
             const IterCtx ic{n, rmap, cmap, im, (lead ? 1 : 0) | (rreg ? 2 : 0) | (creg ? 4 : 0), alpha, oma, sigma,
-                             L.o_lo, L.o_up, L.o_rinv, L.o_wv, L.o_zs, L.o_ys, L.o_rho, L.o_val, L.o_rowptr, L.o_csc, L.o_col};
+                             L.o_lo, L.o_up, L.o_rinv, L.o_wv, L.o_zs, L.o_ys, L.o_rho, L.o_val, L.o_rowptr, L.o_csc, L.o_col, rsc, csc_};
             while (iter <= a.max_iter) {
                 int seg = a.max_iter - iter + 1;
                 if constexpr (CHECKS) {
@@ -1401,7 +1525,12 @@ struct CsbKernel {
         }
 #ifdef SQPH_PHASE_TIMING
         tacc[9] = __builtin_amdgcn_s_memtime() - tstart;
-        if (t < 16) xv[t] = (T)tacc[t];  // debug build only: wave 0's phase ticks instead of x[0..16)
+#ifndef SQPH_PT_WAVE
+#define SQPH_PT_WAVE 0
+#endif
+        __syncthreads();
+        if (t >= 64 * SQPH_PT_WAVE && t < 64 * SQPH_PT_WAVE + 16) xv[t - 64 * SQPH_PT_WAVE] = (T)tacc[t - 64 * SQPH_PT_WAVE];  // debug build only: one wavefront's phase ticks instead of x[0..16)
+        __syncthreads();
 #endif
         if (state_dirty) {
             if (nown) sx[t] = xv[t];
