@@ -22,7 +22,7 @@
  *   settings()                    qp.hpp:166-167                   sqph_set_settings / sqph_get_settings
  *   static constr_type_init(l,u,type)  src/qp.cpp:283-294          sqph_constr_type_init (host utility)
  *   legacy sparse QP<n,m> (Eigen::SparseMatrix A), setup/update_qp/solve
- *                                 include/unsupported/qp_solver.hpp:17-32,215-330   sqph_*_csr (sqph_csr_batch: dense P, CSR A)
+ *                                 include/unsupported/qp_solver.hpp:17-32,215-330   sqph_*_csr (sqph_csr_batch: dense P, CSR A), sqph_*_csr_sp (+ sqph_csc_P: P sparse too)
  *   non-const x / y / z accessors (warm starts)  qp.hpp:160-164    sqph_set_state
  *   the SOC re-solve: same P, A, new bounds      src/sqp.cpp:244-276 (TODO :273)   sqph_setup_solve_reuse
  *   settings.verbose / print_status              src/qp.cpp:72-76,113-117,373-383  sqph_set_trace_qp / sqph_get_trace
@@ -146,6 +146,19 @@ typedef struct sqph_csr_batch {
     long long nnz_max;    /* capacity of one QP's colind/val arrays (= nnz for a shared pattern) */
 } sqph_csr_batch;
 
+/* P of a sqph_csr_batch in compressed-column form — the storage of the Eigen::SparseMatrix<Scalar> the legacy sparse class keeps P
+ * in (include/unsupported/qp_solver.hpp:24-25).  The FULL symmetric matrix is given (the reference multiplies by it,
+ * unsupported/qp_solver.hpp:532,568, and inserts all of it into the KKT matrix, :376), n + 1 column pointers, rows strictly
+ * increasing inside a column.  Same memspace as the batch it goes with; strides in elements, 0 = shared by every QP (a shared
+ * pattern with per-QP values is stride_colptr = stride_rowind = 0, stride_val >= nnz_max). */
+typedef struct sqph_csc_P {
+    const int *colptr;   /* n + 1 */
+    const int *rowind;   /* nnz (<= nnz_max) */
+    const void *val;     /* nnz */
+    long long stride_colptr, stride_rowind, stride_val;
+    long long nnz_max;   /* capacity of one QP's rowind / val arrays */
+} sqph_csc_P;
+
 typedef struct sqph_solver sqph_solver;
 
 /* Behaviour flags for sqph_create */
@@ -217,6 +230,15 @@ int sqph_setup_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_update_qp_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_setup_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);
+/* The same four with P sparse as well (qp->P and qp->stride_P are ignored and may be NULL / 0): P is expanded on the device into
+ * the handle's n x n workspace (one scatter pass, 8 n^2 bytes written per QP, one matrix when shared) and the call continues as
+ * its dense-P twin — bit-identical results to passing that dense P.  What crosses the boundary (and PCIe, for host memspace) is
+ * 12 nnz(P) + 4 (n + 1) bytes per QP instead of 8 n^2.  A malformed structure (column pointers not monotone / beyond nnz_max, row
+ * index out of range or not strictly increasing) is SQPH_ERR_INVALID, detected on the device before anything is solved. */
+int sqph_setup_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
+int sqph_update_qp_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
+int sqph_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
+int sqph_setup_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 
 /* Copy out primal x [batch][n], dual y [batch][m], z [batch][m] and info [batch]; any pointer
  * may be NULL. With SQPH_HOST this call synchronises the stream before returning. */

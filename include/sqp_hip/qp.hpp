@@ -198,6 +198,20 @@ class BatchQPSolver {
     void update_qp_csr(const CsrBatch &b) { call_csr(sqph_update_qp_csr, b, "sqph_update_qp_csr"); }
     void solve_csr(const CsrBatch &b) { call_csr(sqph_solve_csr, b, "sqph_solve_csr"); }
     void setup_solve_csr(const CsrBatch &b) { call_csr(sqph_setup_solve_csr, b, "sqph_setup_solve_csr"); }
+    // ... and with P sparse as well (the legacy sparse class keeps P as Eigen::SparseMatrix, unsupported/qp_solver.hpp:24-25): the
+    // full symmetric matrix in compressed-column form, colptr [n+1], rowind / val [nnz_max] per QP; b.P is ignored.
+    struct CscP {
+        const int *colptr, *rowind;
+        const Scalar *val;
+        long long stride_colptr, stride_rowind, stride_val, nnz_max;
+    };
+    CscP packed_csc_P(const int *colptr, const int *rowind, const Scalar *val, long long nnz_max) const {
+        return CscP{colptr, rowind, val, n_ + 1, nnz_max, nnz_max, nnz_max};
+    }
+    void setup_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_setup_csr_sp, b, P, "sqph_setup_csr_sp"); }
+    void update_qp_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_update_qp_csr_sp, b, P, "sqph_update_qp_csr_sp"); }
+    void solve_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_solve_csr_sp, b, P, "sqph_solve_csr_sp"); }
+    void setup_solve_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_setup_solve_csr_sp, b, P, "sqph_setup_solve_csr_sp"); }
 
     // results of the last call (host copies, fetched lazily)
     const Scalar *primal_solution(int b) { fetch(); return &x_[(size_t)b * n_]; }
@@ -243,15 +257,28 @@ class BatchQPSolver {
         st.adaptive_rho_interval = settings_.adaptive_rho_interval; st.verbose = settings_.verbose;
         detail::check(sqph_set_settings(h_, &st), h_, "sqph_set_settings");
     }
-    template <typename F>
-    void call_csr(F fn, const CsrBatch &b, const char *what) {
-        push_settings();
+    static sqph_csr_batch c_csr(const CsrBatch &b) {
         sqph_csr_batch c;
         c.batch = b.batch; c.memspace = b.memspace;
         c.P = b.P; c.q = b.q; c.A_rowptr = b.rowptr; c.A_colind = b.colind; c.A_val = b.val; c.l = b.l; c.u = b.u;
         c.stride_P = b.stride_P; c.stride_q = b.stride_q; c.stride_rowptr = b.stride_rowptr; c.stride_colind = b.stride_colind;
         c.stride_val = b.stride_val; c.stride_l = b.stride_l; c.stride_u = b.stride_u; c.nnz_max = b.nnz_max;
+        return c;
+    }
+    template <typename F>
+    void call_csr(F fn, const CsrBatch &b, const char *what) {
+        push_settings();
+        const sqph_csr_batch c = c_csr(b);
         detail::check(fn(h_, &c), h_, what);
+        last_batch_ = b.batch;
+        fetched_ = false;
+    }
+    template <typename F>
+    void call_csr_sp(F fn, const CsrBatch &b, const CscP &P, const char *what) {
+        push_settings();
+        const sqph_csr_batch c = c_csr(b);
+        const sqph_csc_P sp{P.colptr, P.rowind, P.val, P.stride_colptr, P.stride_rowind, P.stride_val, P.nnz_max};
+        detail::check(fn(h_, &c, &sp), h_, what);
         last_batch_ = b.batch;
         fetched_ = false;
     }
@@ -545,12 +572,21 @@ class QPSolver {
    private:
     enum op_t { OP_SETUP, OP_UPDATE, OP_SOLVE };
 #if defined(SQP_HIP_HAVE_EIGEN) && defined(QP_SOLVER_USE_SPARSE)
-    // Eigen's compressed column-major A -> CSR (rows in order, columns ascending inside a row), P -> dense column-major
+    // Eigen's column-major A -> CSR (rows in order, columns ascending inside a row); P stays sparse: its compressed columns as they
+    // are (sqph_*_csr_sp expands them on the device)
     void dispatch(op_t op, const qp_t &qp) {
         typedef Eigen::SparseMatrix<Scalar> SpMat;
-        std::vector<Scalar> Pd((size_t)n * n, Scalar(0));
-        for (int k = 0; k < (int)qp.P.outerSize(); k++)
-            for (typename SpMat::InnerIterator it(qp.P, k); it; ++it) Pd[(size_t)it.col() * n + it.row()] = it.value();
+        std::vector<int> pcol((size_t)n + 1, 0), prow;
+        std::vector<Scalar> pval;
+        for (int k = 0; k < (int)qp.P.outerSize(); k++) {
+            for (typename SpMat::InnerIterator it(qp.P, k); it; ++it) {
+                prow.push_back((int)it.row());
+                pval.push_back(it.value());
+            }
+            pcol[(size_t)k + 1] = (int)prow.size();
+        }
+        const long long pnnz = (long long)prow.size();
+        if (prow.empty()) { prow.push_back(0); pval.push_back(Scalar(0)); }
         std::vector<int> rowptr((size_t)m + 1, 0);
         for (int k = 0; k < (int)qp.A.outerSize(); k++)
             for (typename SpMat::InnerIterator it(qp.A, k); it; ++it) rowptr[(size_t)it.row() + 1]++;
@@ -564,11 +600,12 @@ class QPSolver {
                 colind[(size_t)e] = (int)it.col();
                 val[(size_t)e] = it.value();
             }
-        const auto b = impl_.packed_csr(1, Pd.data(), detail::ptr(qp.q), rowptr.data(), colind.data(), val.data(), nnz > 0 ? nnz : 1,
+        const auto b = impl_.packed_csr(1, nullptr, detail::ptr(qp.q), rowptr.data(), colind.data(), val.data(), nnz > 0 ? nnz : 1,
                                         detail::ptr(qp.l), detail::ptr(qp.u));
-        if (op == OP_SETUP) impl_.setup_csr(b);
-        else if (op == OP_UPDATE) impl_.update_qp_csr(b);
-        else impl_.solve_csr(b);
+        const auto sp = impl_.packed_csc_P(pcol.data(), prow.data(), pval.data(), pnnz);
+        if (op == OP_SETUP) impl_.setup_csr(b, sp);
+        else if (op == OP_UPDATE) impl_.update_qp_csr(b, sp);
+        else impl_.solve_csr(b, sp);
     }
 #else
     void dispatch(op_t op, const qp_t &qp) {

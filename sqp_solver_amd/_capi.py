@@ -24,6 +24,7 @@ SYMBOLS = [
     "sqph_shard_bounds", "sqph_device_count", "sqph_own_stream", "sqph_gather_create", "sqph_gather_create_ex", "sqph_gather_transport", "sqph_gather_destroy",
     "sqph_gather_post", "sqph_gather_fetch", "sqph_gather_device_ptrs", "sqph_setup_solve_reuse", "sqph_set_trace_qp", "sqph_get_trace",
     "sqph_update_solve", "sqph_gather_post_many",
+    "sqph_setup_csr_sp", "sqph_update_qp_csr_sp", "sqph_solve_csr_sp", "sqph_setup_solve_csr_sp",
 ]
 
 
@@ -82,6 +83,17 @@ class CsrBatch(ctypes.Structure):
     ]
 
 
+class CscP(ctypes.Structure):
+    """sqph_csc_P: P of a CsrBatch in compressed-column form (the Eigen::SparseMatrix P of the legacy sparse class,
+    reference include/unsupported/qp_solver.hpp:24-25)."""
+
+    _fields_ = [
+        ("colptr", ctypes.c_void_p), ("rowind", ctypes.c_void_p), ("val", ctypes.c_void_p),
+        ("stride_colptr", ctypes.c_longlong), ("stride_rowind", ctypes.c_longlong), ("stride_val", ctypes.c_longlong),
+        ("nnz_max", ctypes.c_longlong),
+    ]
+
+
 _lib = None
 
 
@@ -112,6 +124,7 @@ def load(build_if_missing=True):
         getattr(L, name).argtypes = [vp, ctypes.POINTER(QPBatch)]
     for name in ("sqph_setup_csr", "sqph_update_qp_csr", "sqph_solve_csr", "sqph_setup_solve_csr"):
         getattr(L, name).argtypes = [vp, ctypes.POINTER(CsrBatch)]
+        getattr(L, name + "_sp").argtypes = [vp, ctypes.POINTER(CsrBatch), ctypes.POINTER(CscP)]
     L.sqph_get_solution.argtypes = [vp, i, i, vp, vp, vp, vp]
     L.sqph_set_state.argtypes = [vp, i, i, vp, vp, vp]
     L.sqph_device_state.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]

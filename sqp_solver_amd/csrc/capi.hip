@@ -113,6 +113,31 @@ __global__ void csr_expand(int batch, int n, int m, const int *__restrict__ rowp
     }
 }
 
+// Compressed-column P -> dense column-major (sqph_*_csr_sp): one thread per (QP, column); `dst` must be zero-filled.
+// bad: bit 0 = column pointers malformed, bit 1 = row index out of range, bit 2 = rows of a column not strictly increasing.
+template <typename TIN>
+__global__ void csc_expand_P(int batch, int n, const int *__restrict__ colptr, const int *__restrict__ rowind, const TIN *__restrict__ val,
+                             long long s_colptr, long long s_rowind, long long s_val, long long nnz_cap, TIN *__restrict__ dst,
+                             int *__restrict__ bad) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)batch * n) return;
+    const int b = (int)(t / n), j = (int)(t - (long long)b * n);
+    const int *cp = colptr + b * s_colptr;
+    const int *ri = rowind + b * s_rowind;
+    const TIN *v = val + b * s_val;
+    TIN *d = dst + (long long)b * n * n + (long long)j * n;
+    const int e0 = cp[j], e1 = cp[j + 1];
+    if (e0 < 0 || e1 < e0 || e1 > nnz_cap || (j == 0 && e0 != 0)) { atomicOr(bad, 1); return; }
+    int prev = -1;
+    for (int e = e0; e < e1; e++) {
+        const int i = ri[e];
+        if (i < 0 || i >= n) { atomicOr(bad, 2); continue; }
+        if (i <= prev) atomicOr(bad, 4);
+        prev = i;
+        d[i] = v[e];
+    }
+}
+
 // Structural check of a CSR batch for the native sparse kernel: bit 0 = row pointers malformed, bit 1 = column index
 // out of range, bit 2 = a row is not strictly increasing in its column indices (legal, but takes the expand path).
 __global__ void csr_check(int batch, int n, int m, long long nnz_cap, const int *__restrict__ rowptr, const int *__restrict__ colind,
@@ -157,6 +182,9 @@ struct sqph_solver {
     void *cRow = nullptr, *cCol = nullptr, *cVal = nullptr, *cA = nullptr;
     int *cBad = nullptr;
     size_t cCol_cap = 0, cVal_cap = 0;
+    // sqph_*_csr_sp: staged compressed-column arrays of P (host memspace) and the dense P they expand to
+    void *pPtr = nullptr, *pInd = nullptr, *pVal = nullptr, *cP = nullptr;
+    size_t pInd_cap = 0, pVal_cap = 0;
     // small host-memspace calls (the SQP driver's n = 2..50 subproblems): one pinned staging buffer each way, one
     // H2D / D2H per call instead of one per array
     void *hpin = nullptr, *dpin = nullptr, *hout = nullptr, *dout = nullptr;
@@ -306,7 +334,7 @@ void sqph_destroy(sqph_solver *s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     else (void)hipDeviceSynchronize();
     if (s->stream_owned) (void)hipStreamDestroy(s->stream);
-    void *ptrs[] = {s->trace, s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su, s->cRow, s->cCol, s->cVal, s->cA, s->cBad};
+    void *ptrs[] = {s->trace, s->x, s->z, s->y, s->rho_vec, s->rho, s->ctype, s->info, s->Sinv, s->At, s->sP, s->sq, s->sA, s->sl, s->su, s->cRow, s->cCol, s->cVal, s->cA, s->cBad, s->pPtr, s->pInd, s->pVal, s->cP};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->hpin) (void)hipHostFree(s->hpin);
@@ -855,8 +883,100 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
     return rc;
 }
 
+// sqph_*_csr_sp: P in compressed-column form -> the handle's dense workspace.  On return d->P is that workspace; with host memspace
+// q, l, u are staged as well and *d is a device-memspace batch (the CSR arrays of A stay with run_csr).
+static int expand_sparse_P(sqph_solver *s, const sqph_csr_batch *c, const sqph_csc_P *sp, sqph_qp_batch *d, const char *what) {
+    const size_t e = dsize(s->dtype), B = (size_t)c->batch, n = s->n, m = s->m;
+    if (!sp->colptr || (sp->nnz_max > 0 && (!sp->rowind || !sp->val))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null pointer in the sparse P", what);
+    if (sp->stride_colptr < 0 || sp->stride_rowind < 0 || sp->stride_val < 0 || sp->nnz_max < 0)
+        SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: negative stride / nnz_max in the sparse P", what);
+    if ((sp->stride_rowind && sp->stride_rowind < sp->nnz_max) || (sp->stride_val && sp->stride_val < sp->nnz_max))
+        SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: sparse P: stride_rowind/stride_val smaller than nnz_max", what);
+    if ((sp->stride_colptr == 0) != (sp->stride_rowind == 0))
+        SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: sparse P: colptr and rowind must both be shared or both per-QP", what);
+    if (sp->stride_colptr && sp->stride_colptr < (long long)n + 1) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: sparse P: stride_colptr smaller than n+1", what);
+    if (sp->stride_val == 0 && sp->stride_colptr != 0) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: sparse P: shared values need a shared pattern", what);
+    if (c->memspace == SQPH_HOST && (!c->q || (m > 0 && (!c->l || !c->u)))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null problem pointer", what);
+    if (c->stride_q < 0 || c->stride_l < 0 || c->stride_u < 0) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: negative stride", what);
+
+    DeviceGuard g(s->device);
+    const int *colptr = sp->colptr, *rowind = sp->rowind;
+    const void *val = sp->val;
+    long long s_ptr = sp->stride_colptr, s_ind = sp->stride_rowind, s_val = sp->stride_val;
+    if (c->memspace == SQPH_HOST) {
+        const size_t nind = s_ind ? B * (size_t)s_ind : (size_t)sp->nnz_max;
+        const size_t nval = s_val ? B * (size_t)s_val : (size_t)sp->nnz_max;
+        if (!s->pPtr) SQPH_HIP(s, hipMalloc(&s->pPtr, (size_t)s->cap * (n + 1) * sizeof(int)));
+        if (s_ptr && (size_t)s_ptr != n + 1) {
+            SQPH_HIP(s, hipMemcpy2DAsync(s->pPtr, (n + 1) * sizeof(int), colptr, (size_t)s_ptr * sizeof(int), (n + 1) * sizeof(int), B,
+                                         hipMemcpyHostToDevice, s->stream));
+            s_ptr = (long long)(n + 1);
+        } else {
+            SQPH_HIP(s, hipMemcpyAsync(s->pPtr, colptr, (s_ptr ? B * (n + 1) : n + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        }
+        if (nind > s->pInd_cap) {
+            if (s->pInd) (void)hipFree(s->pInd);
+            s->pInd = nullptr;
+            s->pInd_cap = 0;
+            SQPH_HIP(s, hipMalloc(&s->pInd, (nind ? nind : 1) * sizeof(int)));
+            s->pInd_cap = nind;
+        }
+        if (nval > s->pVal_cap) {
+            if (s->pVal) (void)hipFree(s->pVal);
+            s->pVal = nullptr;
+            s->pVal_cap = 0;
+            SQPH_HIP(s, hipMalloc(&s->pVal, (nval ? nval : 1) * e));
+            s->pVal_cap = nval;
+        }
+        if (nind) SQPH_HIP(s, hipMemcpyAsync(s->pInd, rowind, nind * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        if (nval) SQPH_HIP(s, hipMemcpyAsync(s->pVal, val, nval * e, hipMemcpyHostToDevice, s->stream));
+        colptr = (const int *)s->pPtr; rowind = (const int *)s->pInd; val = s->pVal;
+        // q, l, u: the dense remainder, staged by hand (the dense entry would expect a host P)
+        struct Item { const void *src; void **dst; size_t elems; long long stride; const void **out; long long *sout; };
+        Item items[3] = {{c->q, &s->sq, n, c->stride_q, &d->q, &d->stride_q}, {c->l, &s->sl, m, c->stride_l, &d->l, &d->stride_l},
+                         {c->u, &s->su, m, c->stride_u, &d->u, &d->stride_u}};
+        for (auto &it : items) {
+            if (it.elems == 0) continue;
+            if (!*it.dst) SQPH_HIP(s, hipMalloc(it.dst, (size_t)s->cap * it.elems * e));
+            if (it.stride == 0) {
+                SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, it.elems * e, hipMemcpyHostToDevice, s->stream));
+            } else if ((size_t)it.stride == it.elems) {
+                SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, B * it.elems * e, hipMemcpyHostToDevice, s->stream));
+            } else {
+                SQPH_HIP(s, hipMemcpy2DAsync(*it.dst, it.elems * e, it.src, (size_t)it.stride * e, it.elems * e, B, hipMemcpyHostToDevice, s->stream));
+                *it.sout = (long long)it.elems;
+            }
+            *it.out = *it.dst;
+        }
+        d->memspace = SQPH_DEVICE;
+    }
+    const bool shared = s_val == 0;
+    const size_t nexp = shared ? 1 : B;
+    if (!s->cP) SQPH_HIP(s, hipMalloc(&s->cP, (size_t)s->cap * n * n * e));
+    if (!s->cBad) SQPH_HIP(s, hipMalloc((void **)&s->cBad, sizeof(int)));
+    SQPH_HIP(s, hipMemsetAsync(s->cP, 0, nexp * n * n * e, s->stream));
+    SQPH_HIP(s, hipMemsetAsync(s->cBad, 0, sizeof(int), s->stream));
+    const unsigned blocks = (unsigned)((nexp * n + 255) / 256);
+    if (s->dtype == SQPH_F32)
+        hipLaunchKernelGGL((csc_expand_P<float>), dim3(blocks), dim3(256), 0, s->stream, (int)nexp, (int)n, colptr, rowind, (const float *)val,
+                           s_ptr, s_ind, s_val, (long long)sp->nnz_max, (float *)s->cP, s->cBad);
+    else
+        hipLaunchKernelGGL((csc_expand_P<double>), dim3(blocks), dim3(256), 0, s->stream, (int)nexp, (int)n, colptr, rowind, (const double *)val,
+                           s_ptr, s_ind, s_val, (long long)sp->nnz_max, (double *)s->cP, s->cBad);
+    SQPH_HIP(s, hipGetLastError());
+    int bad = 0;
+    SQPH_HIP(s, hipMemcpyAsync(&bad, s->cBad, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    SQPH_HIP(s, hipStreamSynchronize(s->stream));  // (also ends the borrow of the pageable host arrays staged above)
+    if (bad)
+        SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed sparse P (%s)", what,
+                  (bad & 1) ? "column pointers not monotone" : (bad & 2) ? "row index out of range" : "row indices of a column not strictly increasing");
+    d->P = s->cP;
+    d->stride_P = shared ? 0 : (long long)(n * n);
+    return SQPH_OK;
+}
+
 // CSR entry points: expand A on the device, then the dense path.
-int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what) {
+int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what, const sqph_csc_P *sp = nullptr) {
     if (!s) return SQPH_ERR_INVALID;
     if (!c) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: qp is null", what);
     if (c->batch < 0 || c->batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: batch %d exceeds capacity %d", what, c->batch, s->cap);
@@ -866,6 +986,10 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
     d.batch = c->batch; d.memspace = c->memspace;
     d.P = c->P; d.q = c->q; d.l = c->l; d.u = c->u;
     d.stride_P = c->stride_P; d.stride_q = c->stride_q; d.stride_l = c->stride_l; d.stride_u = c->stride_u;
+    if (sp) {  // P sparse as well: expanded into the handle's workspace; host q, l, u staged (d becomes a device-memspace batch)
+        const int rc = expand_sparse_P(s, c, sp, &d, what);
+        if (rc != SQPH_OK) return rc;
+    }
     if (s->m == 0) return run(s, &d, mode, what);
     if (!c->A_rowptr || (c->nnz_max > 0 && (!c->A_colind || !c->A_val))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null CSR pointer", what);
     if (c->stride_rowptr < 0 || c->stride_colind < 0 || c->stride_val < 0 || c->nnz_max < 0)
@@ -970,7 +1094,7 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what)
     if (bad) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed CSR (%s)", what, (bad & 1) ? "row pointers not monotone" : "column index out of range");
 
     // dense remainder of the problem: stage host arrays through the regular path, A is already on the device
-    if (c->memspace == SQPH_HOST) {
+    if (d.memspace == SQPH_HOST) {
         sqph_qp_batch h = d;  // P, q, l, u from the host; a dummy A pointer is staged below
         // stage P,q,l,u by hand (the dense entry would also copy A)
         struct Item { const void *src; void **dst; size_t elems; long long *stride; };
@@ -1302,6 +1426,25 @@ int sqph_solve_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s,
 int sqph_setup_solve_csr(sqph_solver *s, const sqph_csr_batch *qp) {
     return run_csr(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE, "sqph_setup_solve_csr");
 }
+#define SQPH_NEED_SP(what) \
+    if (s && !P) SQPH_FAIL(s, SQPH_ERR_INVALID, what ": P is null")
+int sqph_setup_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P) {
+    SQPH_NEED_SP("sqph_setup_csr_sp");
+    return run_csr(s, qp, sqph::MODE_SETUP, "sqph_setup_csr_sp", P);
+}
+int sqph_update_qp_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P) {
+    SQPH_NEED_SP("sqph_update_qp_csr_sp");
+    return run_csr(s, qp, sqph::MODE_UPDATE, "sqph_update_qp_csr_sp", P);
+}
+int sqph_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P) {
+    SQPH_NEED_SP("sqph_solve_csr_sp");
+    return run_csr(s, qp, sqph::MODE_SOLVE, "sqph_solve_csr_sp", P);
+}
+int sqph_setup_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P) {
+    SQPH_NEED_SP("sqph_setup_solve_csr_sp");
+    return run_csr(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE, "sqph_setup_solve_csr_sp", P);
+}
+#undef SQPH_NEED_SP
 int sqph_setup(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_SETUP, "sqph_setup"); }
 int sqph_update_qp(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_UPDATE, "sqph_update_qp"); }
 int sqph_solve(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_SOLVE, "sqph_solve"); }

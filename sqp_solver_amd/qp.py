@@ -237,8 +237,11 @@ class QPSolverBatch:
     # ------------------------------------------------------------------ CSR-A variants (BASELINE config 5)
     def _csr_desc(self, P, q, rowptr, colind, val, l, u, colmajor=False):
         """P [B,n,n] or [n,n] (row- or column-major is irrelevant only for symmetric P: pass logical P), q [B,n],
-        rowptr int32 [B,m+1] or [m+1], colind int32 [B,nnz_max] or [nnz], val [B,nnz_max] or [nnz], l/u [B,m]."""
+        rowptr int32 [B,m+1] or [m+1], colind int32 [B,nnz_max] or [nnz], val [B,nnz_max] or [nnz], l/u [B,m].
+        P may also be a tuple (colptr int32 [B,n+1] or [n+1], rowind int32 [B,pnnz] or [pnnz], val [B,pnnz] or [pnnz]): the full
+        symmetric matrix in compressed-column form (sqph_csc_P, the sqph_*_csr_sp entry points)."""
         n, m = self.n, self.m
+        sparse_P = P if isinstance(P, tuple) else None
         items = {}
         dev = None
         batch = None
@@ -274,7 +277,10 @@ class QPSolverBatch:
             shared = a.ndim == 1
             return a, a.ctypes.data, 0 if shared else a.shape[-1], False, None if shared else a.shape[0]
 
-        for name, arr, shp in (("P", P, (n, n)), ("q", q, (n,)), ("l", l, (m,)), ("u", u, (m,))):
+        dense = (("q", q, (n,)), ("l", l, (m,)), ("u", u, (m,)))
+        if sparse_P is None:
+            dense = (("P", P, (n, n)),) + dense
+        for name, arr, shp in dense:
             if tuple(arr.shape[-len(shp):]) != tuple(shp):
                 raise ValueError("%s has shape %s, expected [...,%s]" % (name, tuple(arr.shape), shp))
             items[name] = self._prep_one(arr, shp, colmajor)  # colmajor: P is already per-QP column-major (no transposing copy)
@@ -283,6 +289,16 @@ class QPSolverBatch:
         items["val"] = prep_val(val)
         if items["rowptr"][0].shape[-1] != m + 1:
             raise ValueError("rowptr must have m+1 entries per QP")
+        if sparse_P is not None:
+            if len(sparse_P) != 3:
+                raise ValueError("sparse P is (colptr, rowind, val)")
+            items["P_colptr"] = prep_idx(sparse_P[0], n + 1)
+            items["P_rowind"] = prep_idx(sparse_P[1], None)
+            items["P_val"] = prep_val(sparse_P[2])
+            if items["P_colptr"][0].shape[-1] != n + 1:
+                raise ValueError("P colptr must have n+1 entries per QP")
+            if int(items["P_rowind"][0].shape[-1]) != int(items["P_val"][0].shape[-1]):
+                raise ValueError("P rowind and val must have the same per-QP length")
         for name, it in items.items():
             if dev is None:
                 dev = it[3]
@@ -300,9 +316,17 @@ class QPSolverBatch:
         d = _capi.CsrBatch()
         d.batch = batch
         d.memspace = _capi.DEVICE if dev else _capi.HOST
-        for name in ("P", "q", "l", "u"):
+        for name in ("q", "l", "u") if sparse_P is not None else ("P", "q", "l", "u"):
             setattr(d, name, items[name][1])
             setattr(d, "stride_" + name, items[name][2])
+        sp = None
+        if sparse_P is not None:
+            sp = _capi.CscP()
+            sp.colptr, sp.stride_colptr = items["P_colptr"][1], items["P_colptr"][2]
+            sp.rowind, sp.stride_rowind = items["P_rowind"][1], items["P_rowind"][2]
+            sp.val, sp.stride_val = items["P_val"][1], items["P_val"][2]
+            sp.nnz_max = int(items["P_rowind"][0].shape[-1])
+        self._sparse_P = sp
         d.A_rowptr, d.stride_rowptr = items["rowptr"][1], items["rowptr"][2]
         d.A_colind, d.stride_colind = items["colind"][1], items["colind"][2]
         d.A_val, d.stride_val = items["val"][1], items["val"][2]
@@ -320,6 +344,10 @@ class QPSolverBatch:
     def _call_csr(self, fn, what, P, q, rowptr, colind, val, l, u, colmajor=False):
         self._push_settings()
         d = self._csr_desc(P, q, rowptr, colind, val, l, u, colmajor)
+        if self._sparse_P is not None:  # P given as (colptr, rowind, val): the _sp twin of the entry point
+            what += "_sp"
+            self._check(getattr(self._L, what)(self._h, ctypes.byref(d), ctypes.byref(self._sparse_P)), what)
+            return
         self._check(fn(self._h, ctypes.byref(d)), what)
 
     def setup_csr(self, P, q, rowptr, colind, val, l, u, colmajor=False):

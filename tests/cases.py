@@ -791,6 +791,97 @@ def csr_parity(make, n, m, batch, iters=50, density=0.05, seed=3, shared_pattern
     return ex, ey
 
 
+def sparse_spd(batch, n, density, seed, shared_pattern=False):
+    """symmetric, strictly diagonally dominant (hence SPD) matrices with about `density` of the off-diagonal entries present"""
+    rng = np.random.default_rng(seed)
+    mask = np.triu(rng.uniform(size=(1 if shared_pattern else batch, n, n)) < density, 1)
+    U = rng.standard_normal((batch, n, n)) * mask
+    Ps = U + U.transpose(0, 2, 1)
+    d = np.abs(Ps).sum(axis=2) + rng.uniform(0.5, 1.5, size=(batch, n))
+    Ps[:, np.arange(n), np.arange(n)] = d
+    return Ps
+
+
+def csr_sparse_P(make):
+    """P sparse as well (the legacy sparse class keeps P as Eigen::SparseMatrix, include/unsupported/qp_solver.hpp:24-25): the
+    sqph_*_csr_sp entry points give bit-identical results to the dense-P calls on the matrix the compressed columns encode,
+    and match the oracle; malformed structures are rejected."""
+    import pytest
+
+    from sqp_solver_amd.problems import random_csr_qp_batch
+    from sqp_solver_amd.qp import SqphError
+
+    # tests/qp_solver_sparse_test.cpp:34-60 with P as a sparse matrix
+    P, q, A, l, u = simple()
+    rp, ci, v = dense_to_csr(A[0])
+    cp, ri, pv = dense_to_csr(P[0])  # symmetric: compressed rows == compressed columns
+    s = make(2, 3, 1, legacy_cold_start=True)
+    s.settings.max_iter, s.settings.adaptive_rho = 1000, 1
+    s.setup_csr((cp, ri, pv), q, rp, ci, v, l, u)
+    s.solve_csr((cp, ri, pv), q, rp, ci, v, l, u)
+    x, y, z, info = s.solution()
+    assert is_approx(x[0], S["solution"], 1e-2) and info.status[0] == SOLVED
+    for n, m, B, dens, shared in ((200, 400, 4, 0.05, False), (30, 45, 8, 0.3, True), (70, 150, 3, 0.1, False)):
+        _, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=dens, seed=11, shared_pattern=shared)
+        P = sparse_spd(B, n, 0.04, seed=12, shared_pattern=shared)
+        cp, ri, pv = dense_to_csr(P)
+        if shared:
+            rp, ci, cp, ri = rp[0], ci[0], cp[0], ri[0]
+        outs = []
+        for Parg in (P, (cp, ri, pv)):
+            s = make(n, m, B)
+            s.settings.max_iter = 60
+            s.setup_solve_csr(Parg, q, rp, ci, v, l, u)
+            outs.append(tuple(s.solution()) + (s.kernel_name(),))
+        (x0, y0, z0, i0, k0), (x1, y1, z1, i1, k1) = outs
+        assert k0 == k1, (k0, k1)
+        assert np.array_equal(x0, x1) and np.array_equal(y0, y1) and np.array_equal(z0, z1)
+        assert (i0.iter == i1.iter).all() and (i0.status == i1.status).all()
+        s = make(n, m, B)
+        s.settings.max_iter = 60
+        so = oracle_settings(s.settings)
+        xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, so)
+        assert relerr(x1, xo) < TOL_F64 and relerr(y1, yo) < TOL_F64 and (i1.iter == io["iter"]).all()
+        # the stateful calls: setup, solve on new q, update_qp with another sparse P
+        s = make(n, m, B)
+        s.settings.max_iter = 40
+        s.setup_csr((cp, ri, pv), q, rp, ci, v, l, u)
+        s.solve_csr((cp, ri, pv), 0.5 * q, rp, ci, v, l, u)
+        xa = s.solution()[0]
+        s.update_qp_csr((cp, ri, 2.0 * pv), q, rp, ci, v, l, u)
+        s.solve_csr((cp, ri, 2.0 * pv), q, rp, ci, v, l, u)
+        xb, yb = s.solution()[:2]
+        d = make(n, m, B)
+        d.settings.max_iter = 40
+        d.setup_csr(P, q, rp, ci, v, l, u)
+        d.solve_csr(P, 0.5 * q, rp, ci, v, l, u)
+        assert np.array_equal(xa, d.solution()[0])
+        d.update_qp_csr(2.0 * P, q, rp, ci, v, l, u)
+        d.solve_csr(2.0 * P, q, rp, ci, v, l, u)
+        assert np.array_equal(xb, d.solution()[0]) and np.array_equal(yb, d.solution()[1])
+    # malformed structures
+    n, m, B = 30, 45, 2
+    _, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=0.3, seed=11)
+    cp, ri, pv = dense_to_csr(sparse_spd(B, n, 0.2, seed=13))
+    s = make(n, m, B)
+    bad = cp.copy()
+    bad[1, 3], bad[1, 4] = cp[1, 4], cp[1, 3] - 1
+    with pytest.raises(SqphError, match="column pointers"):
+        s.setup_solve_csr((bad, ri, pv), q, rp, ci, v, l, u)
+    bad = ri.copy()
+    bad[0, 2] = n
+    with pytest.raises(SqphError, match="row index out of range"):
+        s.setup_solve_csr((cp, bad, pv), q, rp, ci, v, l, u)
+    bad = ri.copy()
+    e0 = cp[1, 5]
+    assert cp[1, 6] - e0 >= 2
+    bad[1, e0], bad[1, e0 + 1] = ri[1, e0 + 1], ri[1, e0]
+    with pytest.raises(SqphError, match="strictly increasing"):
+        s.setup_solve_csr((cp, bad, pv), q, rp, ci, v, l, u)
+    s.setup_solve_csr((cp, ri, pv), q, rp, ci, v, l, u)  # the handle is usable afterwards
+    assert (s.info().status != UNINITIALIZED).all()
+
+
 def csr_malformed(make):
     import pytest
 

@@ -197,6 +197,27 @@ static void testSparseCsr() {  // tests/qp_solver_sparse_test.cpp:34-98 through 
     prob.update_qp_csr(b2);
     prob.solve_csr(b2);
     CHECK(is_approx(prob.primal_solution(0), sol2, 2, 1e-2) && prob.info(0).status == SOLVED);
+    // P sparse as well (sqph_*_csr_sp): the same problem with P = [[4, 1], [1, 2]] in compressed columns gives the same bits
+    const int pcol[3] = {0, 2, 4}, prow[4] = {0, 1, 0, 1};
+    const double pval[4] = {qp.Pd[0], qp.Pd[1], qp.Pd[2], qp.Pd[3]};
+    BatchQPSolver<double> dense(2, 3, 1, 0, SQPH_FLAG_LEGACY_COLD_START), sparse(2, 3, 1, 0, SQPH_FLAG_LEGACY_COLD_START);
+    dense.settings().max_iter = sparse.settings().max_iter = 1000;
+    dense.setup_csr(b);
+    dense.solve_csr(b);
+    auto bs = sparse.packed_csr(1, nullptr, qp.qd, rowptr, colind, val, 4, qp.ld, qp.ud);
+    const auto sp = sparse.packed_csc_P(pcol, prow, pval, 4);
+    sparse.setup_csr(bs, sp);
+    sparse.solve_csr(bs, sp);
+    CHECK(sparse.info(0).status == SOLVED && sparse.info(0).iter == dense.info(0).iter);
+    CHECK(sparse.primal_solution(0)[0] == dense.primal_solution(0)[0] && sparse.primal_solution(0)[1] == dense.primal_solution(0)[1]);
+    const int bad_row[4] = {0, 2, 0, 1};  // row index out of range: rejected, the message names it
+    bool threw = false;
+    try {
+        sparse.setup_csr(bs, sparse.packed_csc_P(pcol, bad_row, pval, 4));
+    } catch (const std::exception &e) {
+        threw = std::string(e.what()).find("row index out of range") != std::string::npos;
+    }
+    CHECK(threw);
 }
 
 // distinct handles may be driven from distinct host threads.  Two threads, each with a handle of its own (own

@@ -210,6 +210,12 @@ def test_csr_edge_cases():
     cases.csr_edge_cases(make_gpu)
 
 
+def test_csr_sparse_P():
+    """sqph_*_csr_sp: P in compressed-column form, bit-identical to the dense-P twin on every CSR route (block-row kernel, expand +
+    dense), the stateful calls, the reference's sparse test problem, malformed structures"""
+    cases.csr_sparse_P(make_gpu)
+
+
 def test_csr_native_kernel_is_used_and_handles_termination_paths():
     from sqp_solver_amd.problems import random_csr_qp_batch
 
