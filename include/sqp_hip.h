@@ -230,7 +230,8 @@ int sqph_setup_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_update_qp_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_setup_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);
-/* The same four with P sparse as well (qp->P and qp->stride_P are ignored and may be NULL / 0): P is expanded on the device into
+int sqph_update_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);  /* = sqph_update_solve: update_qp() + solve(), iterates kept */
+/* The same five with P sparse as well (qp->P and qp->stride_P are ignored and may be NULL / 0): P is expanded on the device into
  * the handle's n x n workspace (one scatter pass, 8 n^2 bytes written per QP, one matrix when shared) and the call continues as
  * its dense-P twin — bit-identical results to passing that dense P.  What crosses the boundary (and PCIe, for host memspace) is
  * 12 nnz(P) + 4 (n + 1) bytes per QP instead of 8 n^2.  A malformed structure (column pointers not monotone / beyond nnz_max, row
@@ -239,6 +240,7 @@ int sqph_setup_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P
 int sqph_update_qp_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_setup_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
+int sqph_update_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 
 /* Copy out primal x [batch][n], dual y [batch][m], z [batch][m] and info [batch]; any pointer
  * may be NULL. With SQPH_HOST this call synchronises the stream before returning. */

@@ -198,6 +198,7 @@ class BatchQPSolver {
     void update_qp_csr(const CsrBatch &b) { call_csr(sqph_update_qp_csr, b, "sqph_update_qp_csr"); }
     void solve_csr(const CsrBatch &b) { call_csr(sqph_solve_csr, b, "sqph_solve_csr"); }
     void setup_solve_csr(const CsrBatch &b) { call_csr(sqph_setup_solve_csr, b, "sqph_setup_solve_csr"); }
+    void update_solve_csr(const CsrBatch &b) { call_csr(sqph_update_solve_csr, b, "sqph_update_solve_csr"); }
     // ... and with P sparse as well (the legacy sparse class keeps P as Eigen::SparseMatrix, unsupported/qp_solver.hpp:24-25): the
     // full symmetric matrix in compressed-column form, colptr [n+1], rowind / val [nnz_max] per QP; b.P is ignored.
     struct CscP {
@@ -212,6 +213,7 @@ class BatchQPSolver {
     void update_qp_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_update_qp_csr_sp, b, P, "sqph_update_qp_csr_sp"); }
     void solve_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_solve_csr_sp, b, P, "sqph_solve_csr_sp"); }
     void setup_solve_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_setup_solve_csr_sp, b, P, "sqph_setup_solve_csr_sp"); }
+    void update_solve_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_update_solve_csr_sp, b, P, "sqph_update_solve_csr_sp"); }
 
     // results of the last call (host copies, fetched lazily)
     const Scalar *primal_solution(int b) { fetch(); return &x_[(size_t)b * n_]; }

@@ -1426,6 +1426,9 @@ int sqph_solve_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s,
 int sqph_setup_solve_csr(sqph_solver *s, const sqph_csr_batch *qp) {
     return run_csr(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE, "sqph_setup_solve_csr");
 }
+int sqph_update_solve_csr(sqph_solver *s, const sqph_csr_batch *qp) {
+    return run_csr(s, qp, sqph::MODE_UPDATE | sqph::MODE_SOLVE, "sqph_update_solve_csr");
+}
 #define SQPH_NEED_SP(what) \
     if (s && !P) SQPH_FAIL(s, SQPH_ERR_INVALID, what ": P is null")
 int sqph_setup_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P) {
@@ -1443,6 +1446,10 @@ int sqph_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P
 int sqph_setup_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P) {
     SQPH_NEED_SP("sqph_setup_solve_csr_sp");
     return run_csr(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE, "sqph_setup_solve_csr_sp", P);
+}
+int sqph_update_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P) {
+    SQPH_NEED_SP("sqph_update_solve_csr_sp");
+    return run_csr(s, qp, sqph::MODE_UPDATE | sqph::MODE_SOLVE, "sqph_update_solve_csr_sp", P);
 }
 #undef SQPH_NEED_SP
 int sqph_setup(sqph_solver *s, const sqph_qp_batch *qp) { return run(s, qp, sqph::MODE_SETUP, "sqph_setup"); }

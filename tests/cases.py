@@ -859,6 +859,33 @@ def csr_sparse_P(make):
         d.update_qp_csr(2.0 * P, q, rp, ci, v, l, u)
         d.solve_csr(2.0 * P, q, rp, ci, v, l, u)
         assert np.array_equal(xb, d.solution()[0]) and np.array_equal(yb, d.solution()[1])
+    # one P shared by the whole batch (stride 0 everywhere), fp32 interface, and device-resident arrays (torch tensors)
+    n, m, B = 200, 400, 5
+    _, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=0.05, seed=21)
+    P1 = sparse_spd(1, n, 0.03, seed=22)[0]
+    cp, ri, pv = dense_to_csr(P1)
+    for dtype in (np.float64, np.float32):
+        outs = []
+        for Parg in (np.broadcast_to(P1, (B, n, n)).astype(dtype), (cp, ri, pv.astype(dtype))):
+            s = make(n, m, B, dtype=dtype)
+            s.settings.max_iter = 30
+            s.setup_solve_csr(Parg, q.astype(dtype), rp, ci, v.astype(dtype), l.astype(dtype), u.astype(dtype))
+            outs.append(s.solution())
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert (outs[0][3].iter == outs[1][3].iter).all()
+    import torch
+
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    s = make(n, m, B)
+    s.settings.max_iter = 30
+    s.setup_solve_csr((t(cp), t(ri), t(pv)), t(q), t(rp), t(ci), t(v), t(l), t(u))
+    torch.cuda.synchronize()
+    xd, yd = s.solution()[:2]
+    s = make(n, m, B)
+    s.settings.max_iter = 30
+    s.setup_solve_csr((cp, ri, pv), q, rp, ci, v, l, u)
+    assert np.array_equal(xd, s.solution()[0]) and np.array_equal(yd, s.solution()[1])
     # malformed structures
     n, m, B = 30, 45, 2
     _, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=0.3, seed=11)
@@ -880,6 +907,50 @@ def csr_sparse_P(make):
         s.setup_solve_csr((cp, bad, pv), q, rp, ci, v, l, u)
     s.setup_solve_csr((cp, ri, pv), q, rp, ci, v, l, u)  # the handle is usable afterwards
     assert (s.info().status != UNINITIALIZED).all()
+
+
+def csr_update_solve(make, n=200, m=400, batch=4, density=0.05, **kw):
+    """sqph_update_solve_csr = update_qp(); solve() in one launch with the iterates kept (src/qp.cpp:46-62 then 64-157) on the sparse
+    route: bit-identical to the two calls, and equal to the oracle's update_qp + solve sequence (also with P sparse)."""
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    P, q, rp, ci, v, l, u, A = random_csr_qp_batch(batch, n, m, density=density, seed=31)
+    P2, v2, q2 = 0.8 * P + 0.1 * np.eye(n)[None], 1.1 * v, 0.7 * q
+    A2 = 1.1 * A
+    fused, two = make(n, m, batch, **kw), make(n, m, batch, **kw)
+    for s in (fused, two):
+        s.settings.max_iter = 40
+        s.setup_solve_csr(P, q, rp, ci, v, l, u)
+    fused.update_solve_csr(P2, q2, rp, ci, v2, l, u)
+    two.update_qp_csr(P2, q2, rp, ci, v2, l, u)
+    two.solve_csr(P2, q2, rp, ci, v2, l, u)
+    xf, yf, zf, inf_ = fused.solution()
+    xt, yt, zt, int_ = two.solution()
+    assert np.array_equal(xf, xt) and np.array_equal(yf, yt) and np.array_equal(zf, zt)
+    assert (inf_.iter == int_.iter).all() and (inf_.status == int_.status).all() and (inf_.rho_updates == int_.rho_updates).all()
+    for b in range(batch):
+        o = oracle.QPSolver()
+        o.settings.max_iter = 40
+        o.setup(P[b], q[b], A[b], l[b], u[b])
+        o.solve(P[b], q[b], A[b], l[b], u[b])
+        o.update_qp(P2[b], q2[b], A2[b], l[b], u[b])
+        o.solve(P2[b], q2[b], A2[b], l[b], u[b])
+        assert o.info.status == inf_.status[b] and o.info.iter == inf_.iter[b]
+        assert relerr(xf[b], o.primal_solution()) < TOL_F64 and relerr(yf[b], o.dual_solution()) < TOL_F64
+    # the iterates were kept: a cold setup_solve of the second problem ends elsewhere after the same 40 iterations
+    cold = make(n, m, batch, **kw)
+    cold.settings.max_iter = 40
+    cold.setup_solve_csr(P2, q2, rp, ci, v2, l, u)
+    assert not np.array_equal(cold.solution()[0], xf)
+    # P sparse too
+    Ps = sparse_spd(batch, n, 0.04, seed=32)
+    cp, ri, pv = dense_to_csr(Ps)
+    a, b_ = make(n, m, batch, **kw), make(n, m, batch, **kw)
+    for s, Parg, Parg2 in ((a, Ps, 1.5 * Ps), (b_, (cp, ri, pv), (cp, ri, 1.5 * pv))):
+        s.settings.max_iter = 40
+        s.setup_solve_csr(Parg, q, rp, ci, v, l, u)
+        s.update_solve_csr(Parg2, q2, rp, ci, v2, l, u)
+    assert np.array_equal(a.solution()[0], b_.solution()[0]) and np.array_equal(a.solution()[1], b_.solution()[1])
 
 
 def csr_malformed(make):

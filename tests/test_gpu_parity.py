@@ -210,6 +210,12 @@ def test_csr_edge_cases():
     cases.csr_edge_cases(make_gpu)
 
 
+@pytest.mark.parametrize("n,m,density", [(200, 400, 0.05), (30, 45, 0.3), (100, 180, 0.08)])
+def test_csr_update_solve(n, m, density):
+    """sqph_update_solve_csr on the block-row kernel and on the expand + dense route"""
+    cases.csr_update_solve(make_gpu, n=n, m=m, density=density)
+
+
 def test_csr_sparse_P():
     """sqph_*_csr_sp: P in compressed-column form, bit-identical to the dense-P twin on every CSR route (block-row kernel, expand +
     dense), the stateful calls, the reference's sparse test problem, malformed structures"""
