@@ -231,11 +231,14 @@ int sqph_update_qp_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_setup_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);
 int sqph_update_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);  /* = sqph_update_solve: update_qp() + solve(), iterates kept */
-/* The same five with P sparse as well (qp->P and qp->stride_P are ignored and may be NULL / 0): P is expanded on the device into
- * the handle's n x n workspace (one scatter pass, 8 n^2 bytes written per QP, one matrix when shared) and the call continues as
- * its dense-P twin — bit-identical results to passing that dense P.  What crosses the boundary (and PCIe, for host memspace) is
- * 12 nnz(P) + 4 (n + 1) bytes per QP instead of 8 n^2.  A malformed structure (column pointers not monotone / beyond nnz_max, row
- * index out of range or not strictly increasing) is SQPH_ERR_INVALID, detected on the device before anything is solved. */
+/* The same five with P sparse as well (qp->P and qp->stride_P are ignored and may be NULL / 0).  Where the block-row kernel runs
+ * (n <= 224, m <= 512, shapes beyond the dense register-tiled kernels: BASELINE config 5) its sparse-P instantiations read the
+ * compressed columns in place — set-up (lower triangle into S) and dual residual (P x, column i being row i of the symmetric
+ * matrix) — in the summation order of the dense path; on every other route one scatter pass expands P into the handle's n x n
+ * workspace (one matrix when shared) and the call continues as its dense-P twin.  Either way the results are bit-identical to
+ * passing that dense P, and what crosses the boundary (and PCIe, for host memspace) is 12 nnz(P) + 4 (n + 1) bytes per QP instead
+ * of 8 n^2.  P must be symmetric.  A malformed structure (column pointers not monotone / beyond nnz_max, row index out of range or
+ * not strictly increasing) is SQPH_ERR_INVALID, detected on the device before anything is solved. */
 int sqph_setup_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_update_qp_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);

@@ -14,7 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 # kernel's two-chain one: admm_lane_kernel.h)
 FLAGS += os.environ.get("SQPH_HIPCC_FLAGS", "").split()
 # flags of single translation units (csrb.hip says why)
-UNIT_FLAGS = {"csrb.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
+UNIT_FLAGS = {"csrb.hip": ["-mllvm", "-simplifycfg-sink-common=false"], "csrb_sp.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 
 def sources():
@@ -64,7 +64,7 @@ def build_f32_tiles_experiment(verbose=False):
     """Measurement build for SURVEY section 8 row f4 (tests/test_f32_tiles.py, tools/f32_tiles_measure.py): the C2 / C3 kernels with
     their B and W' tiles rounded through fp32 (-DSQPH_F32_TILE_STORAGE).  Never loaded by the package itself."""
     out = os.path.join(LIBDIR, "libsqp_hip_f32tiles.so")
-    srcs = [os.path.join(CSRC, f) for f in ("capi.hip", "wg_nocheck.hip", "csr_nocheck.hip", "wg_f32.hip", "csr_dense.hip", "wg_stack.hip", "csrb.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("capi.hip", "wg_nocheck.hip", "csr_nocheck.hip", "wg_f32.hip", "csr_dense.hip", "wg_stack.hip", "csrb.hip", "csrb_sp.hip")]
     if os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in sources()):
         return out
     cmd = [HIPCC] + FLAGS + ["-DSQPH_SLIM", "-DSQPH_SLIM_C2", "-DSQPH_F32_TILE_STORAGE", "-o", out] + srcs

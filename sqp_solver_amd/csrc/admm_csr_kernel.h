@@ -32,6 +32,10 @@ struct CsrArgs {
     const TIN *val;
     long long s_rowptr, s_colind, s_val;
     int nnz_cap;  // per-QP capacity of colind/val == LDS slots reserved
+    // P in compressed-column form (sqph_csc_P), read by the block-row kernel's sparse-P instantiations only (admm_csrb_kernel.h)
+    const int *p_colptr = nullptr, *p_rowind = nullptr;
+    const TIN *p_val = nullptr;
+    long long s_pcolptr = 0, s_prowind = 0, s_pval = 0;
 };
 
 // LDS map.  Everything whose size depends only on the tile edge TT sits first at compile-time offsets; the arrays

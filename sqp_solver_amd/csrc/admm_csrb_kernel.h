@@ -678,8 +678,22 @@ struct CsbKernel {
             }
         }
     }
-    static __device__ __forceinline__ void form_S(const TIN *__restrict__ gP, int n, T sigma, const Lay &L, unsigned char *smem, int t,
-                                                  int wave, sqph_acc4 (&B)[NB + 1]) {
+    // any lane of this lane's aligned group of 16 (the groups of a wavefront may have diverged)
+    static __device__ __forceinline__ bool group16_any(bool p) {
+#ifdef SQPH_SIM
+        uint64_t v = p ? 1 : 0;
+        for (int d = 1; d < 16; d <<= 1) v |= ::sqph_sim::group16_exchange(v, (int)(threadIdx.x & 15) ^ d);
+        return v != 0;
+#else
+        return ((__builtin_amdgcn_ballot_w64(p) >> (threadIdx.x & 48)) & 0xffffull) != 0;
+#endif
+    }
+    // SP: P in compressed-column form (sqph_csc_P: the symmetric matrix, rows ascending inside a column) — gP is then its value
+    // array, pcol / prow its column pointers and row indices, read from global memory in place of the dense columns.  The sums are
+    // formed in the order of the dense path (an absent entry is a dense zero, whose addition changes nothing): bit-identical S.
+    template <bool SP = false>
+    static __device__ __forceinline__ void form_S(const TIN *__restrict__ gP, const int *__restrict__ pcol, const int *__restrict__ prow, int n,
+                                                  T sigma, const Lay &L, unsigned char *smem, int t, int wave, sqph_acc4 (&B)[NB + 1]) {
         const int c16 = t & 15, g = t >> 4, lr = t & 15, lq = (t >> 4) & 3;
         T *lds = reinterpret_cast<T *>(smem);
         const int *li = reinterpret_cast<const int *>(smem);
@@ -700,14 +714,14 @@ struct CsbKernel {
             }
         };
         T pv[14];
-        load_P(0, pv);
+        if constexpr (!SP) load_P(0, pv);
 #pragma unroll 1
         for (int p = 0; p < (NB + 1) / 2; p++) {
             __syncthreads();
             for (int e = t; e < 32 * LDP; e += NT) Sp[e] = 0;
             __syncthreads();
             T pvn[14];
-            load_P(p + 1 < (NB + 1) / 2 ? p + 1 : p, pvn);
+            if constexpr (!SP) load_P(p + 1 < (NB + 1) / 2 ? p + 1 : p, pvn);
             const int j = 32 * p + g;
             if (j < n) {
                 constexpr int EB = SQPH_CSB_EB;
@@ -747,14 +761,34 @@ struct CsbKernel {
                         }
                 }
                 // + lower triangle of P + sigma I
+#ifdef SQPH_SIM
+                ::sqph_sim::group16_sync();  // (the emulator runs a lane up to its next rendezvous: the hardware's program order of the ds_add_f64 above and below)
+#endif
+                if constexpr (SP) {
+                    const int pe1 = pcol[j + 1];
+                    bool diag = false;
+                    for (int e = pcol[j] + c16; e < pe1; e += 16) {
+                        const int kk = prow[e];
+                        T pe = (T)gP[e];
+                        if (kk == j) {
+                            pe += sigma;
+                            diag = true;
+                        }
+                        if (kk >= j && kk < n) lds_add_f64(&Sp[g * LDP + kk], pe);
+                    }
+                    if (!group16_any(diag) && c16 == 0) lds_add_f64(&Sp[g * LDP + j], sigma);  // (no stored diagonal entry: 0 + sigma)
+                } else {
 #pragma unroll
                 for (int q = 0; q < 14; q++) {
                     const int kk = j + c16 + 16 * q;
                     if (kk < n) lds_add_f64(&Sp[g * LDP + kk], pv[q] + (kk == j ? sigma : T(0)));
                 }
+                }
             }
+            if constexpr (!SP) {
 #pragma unroll
             for (int q = 0; q < 14; q++) pv[q] = pvn[q];
+            }
             __syncthreads();
             pick_up(wave, p, n, Sp, lr, lq, B);
         }
@@ -909,12 +943,13 @@ struct CsbKernel {
 #define SQPH_FTICK_PASS
 #define SQPH_FTICK(k)
 #endif
-    static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, int n, T sigma, const Lay &L, unsigned char *smem, int t,
-                                                  sqph_acc4 (&B)[NB + 1] SQPH_FTICK_ARGS) {
+    template <bool SP = false>
+    static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const int *__restrict__ pcol, const int *__restrict__ prow, int n,
+                                                  T sigma, const Lay &L, unsigned char *smem, int t, sqph_acc4 (&B)[NB + 1] SQPH_FTICK_ARGS) {
         T *lds = reinterpret_cast<T *>(smem);
         T *sj = lds + Lay::o_sj, *flag = lds + Lay::o_flag, *wk = lds;
         const int wave = wave_of(t), l = t & 63, lr = l & 15, lq = l >> 4;
-        form_S(gP, n, sigma, L, smem, t, wave, B);
+        form_S<SP>(gP, pcol, prow, n, sigma, L, smem, t, wave, B);
         SQPH_FTICK(1)
         if (t < 2) flag[t] = T(0);
         if (t < NP) sj[t] = T(1);
@@ -1155,13 +1190,17 @@ struct CsbKernel {
     // PRIMAL FIRST, like the dense kernels: the dual half — A'y and above all P x, 8 n^2 bytes streamed per QP (2.6 GB per batch-wide
     // check at config 5) — only runs when the primal test passes or the caller needs it (rho adaptation; the last check a solve can
     // reach, whose residuals a MAX_ITER_EXCEEDED solve reports).  Returns whether v[3..6] were computed.
+    // SP (P in compressed columns, see form_S): gP_ is the value array and px... = (column pointers, row indices) — a trailing pack,
+    // so that the dense instantiation's signature (a real call) stays what it was.
 #ifdef SQPH_SIM
+    template <bool SP = false, typename... PX>
     static inline bool residuals(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int rmap, int cmap, bool lead, int im,
-                                 bool nown, T eps_abs, T eps_rel, bool force_dual, T (&v)[7]) {
+                                 bool nown, T eps_abs, T eps_rel, bool force_dual, T (&v)[7], PX... px) {
 #else
+    template <bool SP = false, typename... PX>
     static __device__ __attribute__((noinline)) bool residuals(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int rmap,
                                                                 int cmap, bool lead, int im, bool nown, T eps_abs, T eps_rel, bool force_dual,
-                                                                T (&v)[7]) {
+                                                                T (&v)[7], PX... px) {
 #endif
         const int n = uniform_int(n_);
         const TIN *__restrict__ gP = uniform_ptr(gP_);
@@ -1215,6 +1254,19 @@ struct CsbKernel {
         {   // P x with the full P (both triangles, qp.cpp:324), streamed: lane t takes row t & 255 and every second column
             const int i = t & 255, h = t >> 8;
             T acc = 0;
+            if constexpr (SP) {
+                // column i of the symmetric P is its row i; the entries in ascending order, the two lanes of a row taking the even /
+                // odd columns: the dense path's chains without their zero terms
+                const int *const pp[2] = {px...};
+                const int *__restrict__ pcol = uniform_ptr(pp[0]), *__restrict__ prow = uniform_ptr(pp[1]);
+                if (i < n) {
+                    const int e1 = pcol[i + 1];
+                    for (int e = pcol[i]; e < e1; e++) {
+                        const int k = prow[e];
+                        if ((k & 1) == h && k < n) acc = wg_fma((T)gP[e], xt[k], acc);
+                    }
+                }
+            } else
             if (i < n) {
                 const TIN *pr = gP + i;
                 int j = h;
@@ -1257,7 +1309,8 @@ struct CsbKernel {
     }
 
     // CHECKS = false: the instantiation for calls that never look at the residuals (check_termination == 0, no adaptive rho)
-    template <bool CHECKS = true>
+    // SP = true: P comes in compressed columns (CsrArgs::p_*: the sqph_*_csr_sp entry points) instead of the dense a.P
+    template <bool CHECKS = true, bool SP = false>
     static __device__ __forceinline__ void run(const KArgs<T, TIN> &a, const CsrArgs<TIN> &ca, unsigned char *smem) {
         const int qp = blockIdx.x;
         if (qp >= a.batch) return;
@@ -1274,7 +1327,15 @@ struct CsbKernel {
         T *zs = lds + L.o_zs, *ys = lds + L.o_ys, *rhov = lds + L.o_rho;  // z, y, rho of the constraint rows live in LDS (written by a row's lead lane)
         T *pw = lds + Lay::O_PW, *xp = lds + Lay::O_XP, *xv = lds + Lay::o_xv;
 
-        const TIN *gP = a.P + (long)qp * a.sP;
+        const TIN *gP;
+        const int *pcol = nullptr, *prow = nullptr;
+        if constexpr (SP) {
+            gP = ca.p_val + (long)qp * ca.s_pval;
+            pcol = ca.p_colptr + (long)qp * ca.s_pcolptr;
+            prow = ca.p_rowind + (long)qp * ca.s_prowind;
+        } else {
+            gP = a.P + (long)qp * a.sP;
+        }
         const TIN *gq = a.q + (long)qp * a.sq;
         const TIN *gl = a.l + (long)qp * a.sl;
         const TIN *gu = a.u + (long)qp * a.su;
@@ -1386,12 +1447,12 @@ struct CsbKernel {
                     sqph_acc4 Bf[NB + 1];
 #pragma unroll
                     for (int s = 0; s <= NB; s++) Bf[s] = sqph_acc4{{0, 0, 0, 0}};
-                    ok = factor(gP, n, sigma, L, smem, t, Bf SQPH_FTICK_PASS);
+                    ok = factor<SP>(gP, pcol, prow, n, sigma, L, smem, t, Bf SQPH_FTICK_PASS);
                     if (!(mode & MODE_NO_FACTOR_STORE)) store_blocks(wave, gW, n, lr, lq, Bf);  // kept for later solve() calls
 #pragma unroll
                     for (int s = 0; s <= NB; s++) B[s] = Bf[s];
                 } else {
-                    ok = factor(gP, n, sigma, L, smem, t, B SQPH_FTICK_PASS);
+                    ok = factor<SP>(gP, pcol, prow, n, sigma, L, smem, t, B SQPH_FTICK_PASS);
                     if (!(mode & MODE_NO_FACTOR_STORE)) store_blocks(wave, gW, n, lr, lq, B);  // kept for later solve() calls
                 }
                 SQPH_BTICK(11)
@@ -1480,7 +1541,9 @@ struct CsbKernel {
                     // allocation problem, and the register-resident slices of A lived in scratch for the whole solve
                     T v[7];
                     const bool last_check = check && iter + a.check_termination > a.max_iter;
-                    const bool dual = residuals(gP, n, L, smem, rmap, cmap, lead, im, nown, (T)a.eps_abs, (T)a.eps_rel, adapt || last_check, v);
+                    bool dual;
+                    if constexpr (SP) dual = residuals<true>(gP, n, L, smem, rmap, cmap, lead, im, nown, (T)a.eps_abs, (T)a.eps_rel, adapt || last_check, v, pcol, prow);
+                    else dual = residuals(gP, n, L, smem, rmap, cmap, lead, im, nown, (T)a.eps_abs, (T)a.eps_rel, adapt || last_check, v);
                     const T nrm_prim = nanmax(v[0], v[1]);
                     const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
                     info.res_prim = (double)v[2];
@@ -1559,6 +1622,17 @@ __global__ __launch_bounds__(512) void admm_csrb_nocheck_kernel(CsrLaunch<TIN> p
     SQPH_DYN_SMEM(smem_raw);
     CsbKernel<TIN, NB>::template run<false>(p.a, p.ca, smem_raw);
 }
+// ... and the two with P in compressed columns (sqph_*_csr_sp; instantiated in csrb_sp.hip only)
+template <typename TIN, int NB>
+__global__ __launch_bounds__(512) void admm_csrb_sp_kernel(CsrLaunch<TIN> p) {
+    SQPH_DYN_SMEM(smem_raw);
+    CsbKernel<TIN, NB>::template run<true, true>(p.a, p.ca, smem_raw);
+}
+template <typename TIN, int NB>
+__global__ __launch_bounds__(512) void admm_csrb_sp_nocheck_kernel(CsrLaunch<TIN> p) {
+    SQPH_DYN_SMEM(smem_raw);
+    CsbKernel<TIN, NB>::template run<false, true>(p.a, p.ca, smem_raw);
+}
 
 // block-row counts compiled into the library (n <= 16 NB): first fit wins
 #if defined(SQPH_SLIM) && defined(SQPH_SLIM_CSR)
@@ -1577,6 +1651,11 @@ template <typename TIN>
 int csrb_launch(int NB, bool nocheck, int m, int nnz_cap, int batch, hipStream_t stream, const CsrLaunch<TIN> &p);
 extern template int csrb_launch<double>(int, bool, int, int, int, hipStream_t, const CsrLaunch<double> &);
 extern template int csrb_launch<float>(int, bool, int, int, int, hipStream_t, const CsrLaunch<float> &);
+// the same for the sparse-P instantiations (csrb_sp.hip)
+template <typename TIN>
+int csrb_sp_launch(int NB, bool nocheck, int m, int nnz_cap, int batch, hipStream_t stream, const CsrLaunch<TIN> &p);
+extern template int csrb_sp_launch<double>(int, bool, int, int, int, hipStream_t, const CsrLaunch<double> &);
+extern template int csrb_sp_launch<float>(int, bool, int, int, int, hipStream_t, const CsrLaunch<float> &);
 
 #ifdef SQPH_SIM
 template <typename TIN>
@@ -1589,6 +1668,22 @@ inline int sim_run_csrb(const KArgs<double, TIN> &a, const CsrArgs<TIN> &ca) {
             ::sqph_sim::launch(admm_csrb_nocheck_kernel<TIN, NB_>, dim3(a.batch), dim3(512), L.bytes, CsrLaunch<TIN>{a, ca}); \
         else                                                                                                             \
             ::sqph_sim::launch(admm_csrb_kernel<TIN, NB_>, dim3(a.batch), dim3(512), L.bytes, CsrLaunch<TIN>{a, ca});    \
+        return 0;                                                                                                        \
+    }
+    SQPH_CSB_SIM_SHAPES(SQPH_SIM_CASE)
+#undef SQPH_SIM_CASE
+    return -1;
+}
+template <typename TIN>
+inline int sim_run_csrb_sp(const KArgs<double, TIN> &a, const CsrArgs<TIN> &ca) {
+    if (a.m > 512) return -1;
+#define SQPH_SIM_CASE(NB_)                                                                                               \
+    if (a.n <= 16 * NB_) {                                                                                               \
+        const CsbLayout<NB_> L = CsbLayout<NB_>::make(a.m, ca.nnz_cap);                                                  \
+        if (a.check_termination <= 0 && !(a.adaptive_rho && a.adaptive_rho_interval > 0))                                \
+            ::sqph_sim::launch(admm_csrb_sp_nocheck_kernel<TIN, NB_>, dim3(a.batch), dim3(512), L.bytes, CsrLaunch<TIN>{a, ca}); \
+        else                                                                                                             \
+            ::sqph_sim::launch(admm_csrb_sp_kernel<TIN, NB_>, dim3(a.batch), dim3(512), L.bytes, CsrLaunch<TIN>{a, ca}); \
         return 0;                                                                                                        \
     }
     SQPH_CSB_SIM_SHAPES(SQPH_SIM_CASE)

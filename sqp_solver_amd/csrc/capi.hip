@@ -134,7 +134,7 @@ __global__ void csc_expand_P(int batch, int n, const int *__restrict__ colptr, c
         if (i < 0 || i >= n) { atomicOr(bad, 2); continue; }
         if (i <= prev) atomicOr(bad, 4);
         prev = i;
-        d[i] = v[e];
+        if (dst) d[i] = v[e];  // (dst == nullptr: structure check only — the block-row kernel reads the columns in place)
     }
 }
 
@@ -584,6 +584,10 @@ struct CsrDesc {  // device-resident CSR arrays of the native sparse path
     long long s_rowptr, s_colind, s_val;
     int nnz_cap, TT;
     int NB;  // > 0: the block-row kernel (admm_csrb_kernel.h) with this block-row count; 0: the 32 x 32 lane-grid kernel with tile edge TT
+    // P in compressed columns, device-resident (sqph_*_csr_sp on the block-row kernel: read in place by its sparse-P instantiations)
+    const int *p_colptr = nullptr, *p_rowind = nullptr;
+    const void *p_val = nullptr;
+    long long s_pcolptr = 0, s_prowind = 0, s_pval = 0;
 };
 
 template <typename TIN>
@@ -681,13 +685,21 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         CsrLaunch<TIN> p;
         a.mode = for_family('c');
         p.a = a;
-        p.ca = CsrArgs<TIN>{csr->rowptr, csr->colind, (const TIN *)csr->val, csr->s_rowptr, csr->s_colind, csr->s_val, csr->nnz_cap};
+        p.ca = CsrArgs<TIN>{csr->rowptr, csr->colind, (const TIN *)csr->val, csr->s_rowptr, csr->s_colind, csr->s_val, csr->nnz_cap,
+                            csr->p_colptr, csr->p_rowind, (const TIN *)csr->p_val, csr->s_pcolptr, csr->s_prowind, csr->s_pval};
+        const bool sparse_P = csr->p_colptr != nullptr;
         const bool nocheck = st.check_termination <= 0 && !(st.adaptive_rho && st.adaptive_rho_interval > 0);
         if (csr->NB > 0) {  // block-row kernel: 512 lanes per QP, W as MFMA blocks in registers (csrb.hip)
-            const int rc = csrb_launch<TIN>(csr->NB, nocheck, s->m, csr->nnz_cap, qp->batch, s->stream, p);
+            const int rc = sparse_P ? csrb_sp_launch<TIN>(csr->NB, nocheck, s->m, csr->nnz_cap, qp->batch, s->stream, p)
+                                    : csrb_launch<TIN>(csr->NB, nocheck, s->m, csr->nnz_cap, qp->batch, s->stream, p);
             if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "sparse kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
             launched = rc > 0;
-            if (launched) s->kernel_name = csr->NB == 14 ? "csb_nb14" : csr->NB == 13 ? "csb_nb13" : csr->NB == 9 ? "csb_nb9" : csr->NB == 5 ? "csb_nb5" : "csb";
+            if (launched && sparse_P)
+                s->kernel_name = csr->NB == 14 ? "csb_nb14_sp" : csr->NB == 13 ? "csb_nb13_sp" : csr->NB == 9 ? "csb_nb9_sp" : csr->NB == 5 ? "csb_nb5_sp" : "csb_sp";
+            else if (launched) s->kernel_name = csr->NB == 14 ? "csb_nb14" : csr->NB == 13 ? "csb_nb13" : csr->NB == 9 ? "csb_nb9" : csr->NB == 5 ? "csb_nb5" : "csb";
+        }
+        if (!launched && sparse_P) SQPH_FAIL(s, SQPH_ERR_UNSUPPORTED, "internal: sparse P handed to a kernel that reads it dense");
+        {
         }
         // calls that never look at the residuals take the instantiation without the check block (csr_nocheck.hip)
         if (!launched && nocheck) {
@@ -883,9 +895,16 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
     return rc;
 }
 
-// sqph_*_csr_sp: P in compressed-column form -> the handle's dense workspace.  On return d->P is that workspace; with host memspace
-// q, l, u are staged as well and *d is a device-memspace batch (the CSR arrays of A stay with run_csr).
-static int expand_sparse_P(sqph_solver *s, const sqph_csr_batch *c, const sqph_csc_P *sp, sqph_qp_batch *d, const char *what) {
+// sqph_*_csr_sp: P in compressed-column form.  stage_sparse_P validates the descriptor and makes the arrays device-resident (*dv);
+// with host memspace q, l, u are staged as well and *d becomes a device-memspace batch (the CSR arrays of A stay with run_csr).
+// place_sparse_P then either checks the structure only (expand = false: the block-row kernel's sparse-P instantiations read the
+// columns in place) or expands them into the handle's dense workspace, which d->P then points to (every other route).
+struct SparsePDev {
+    const int *colptr, *rowind;
+    const void *val;
+    long long s_ptr, s_ind, s_val, nnz_max;
+};
+static int stage_sparse_P(sqph_solver *s, const sqph_csr_batch *c, const sqph_csc_P *sp, sqph_qp_batch *d, SparsePDev *dv, const char *what) {
     const size_t e = dsize(s->dtype), B = (size_t)c->batch, n = s->n, m = s->m;
     if (!sp->colptr || (sp->nnz_max > 0 && (!sp->rowind || !sp->val))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null pointer in the sparse P", what);
     if (sp->stride_colptr < 0 || sp->stride_rowind < 0 || sp->stride_val < 0 || sp->nnz_max < 0)
@@ -950,19 +969,26 @@ static int expand_sparse_P(sqph_solver *s, const sqph_csr_batch *c, const sqph_c
         }
         d->memspace = SQPH_DEVICE;
     }
-    const bool shared = s_val == 0;
-    const size_t nexp = shared ? 1 : B;
-    if (!s->cP) SQPH_HIP(s, hipMalloc(&s->cP, (size_t)s->cap * n * n * e));
+    *dv = SparsePDev{colptr, rowind, val, s_ptr, s_ind, s_val, sp->nnz_max};
+    return SQPH_OK;
+}
+static int place_sparse_P(sqph_solver *s, int batch, const SparsePDev &dv, bool expand, sqph_qp_batch *d, const char *what) {
+    const size_t e = dsize(s->dtype), B = (size_t)batch, n = s->n;
+    DeviceGuard g(s->device);
+    const bool shared = dv.s_val == 0;
+    const size_t nexp = shared ? 1 : B, ncheck = dv.s_ptr == 0 ? 1 : B;  // (a shared pattern is checked once)
+    if (expand && !s->cP) SQPH_HIP(s, hipMalloc(&s->cP, (size_t)s->cap * n * n * e));
     if (!s->cBad) SQPH_HIP(s, hipMalloc((void **)&s->cBad, sizeof(int)));
-    SQPH_HIP(s, hipMemsetAsync(s->cP, 0, nexp * n * n * e, s->stream));
+    if (expand) SQPH_HIP(s, hipMemsetAsync(s->cP, 0, nexp * n * n * e, s->stream));
     SQPH_HIP(s, hipMemsetAsync(s->cBad, 0, sizeof(int), s->stream));
-    const unsigned blocks = (unsigned)((nexp * n + 255) / 256);
+    const size_t nk = expand ? nexp : ncheck;
+    const unsigned blocks = (unsigned)((nk * n + 255) / 256);
     if (s->dtype == SQPH_F32)
-        hipLaunchKernelGGL((csc_expand_P<float>), dim3(blocks), dim3(256), 0, s->stream, (int)nexp, (int)n, colptr, rowind, (const float *)val,
-                           s_ptr, s_ind, s_val, (long long)sp->nnz_max, (float *)s->cP, s->cBad);
+        hipLaunchKernelGGL((csc_expand_P<float>), dim3(blocks), dim3(256), 0, s->stream, (int)nk, (int)n, dv.colptr, dv.rowind, (const float *)dv.val,
+                           dv.s_ptr, dv.s_ind, dv.s_val, (long long)dv.nnz_max, expand ? (float *)s->cP : (float *)nullptr, s->cBad);
     else
-        hipLaunchKernelGGL((csc_expand_P<double>), dim3(blocks), dim3(256), 0, s->stream, (int)nexp, (int)n, colptr, rowind, (const double *)val,
-                           s_ptr, s_ind, s_val, (long long)sp->nnz_max, (double *)s->cP, s->cBad);
+        hipLaunchKernelGGL((csc_expand_P<double>), dim3(blocks), dim3(256), 0, s->stream, (int)nk, (int)n, dv.colptr, dv.rowind, (const double *)dv.val,
+                           dv.s_ptr, dv.s_ind, dv.s_val, (long long)dv.nnz_max, expand ? (double *)s->cP : (double *)nullptr, s->cBad);
     SQPH_HIP(s, hipGetLastError());
     int bad = 0;
     SQPH_HIP(s, hipMemcpyAsync(&bad, s->cBad, sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -970,8 +996,13 @@ static int expand_sparse_P(sqph_solver *s, const sqph_csr_batch *c, const sqph_c
     if (bad)
         SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed sparse P (%s)", what,
                   (bad & 1) ? "column pointers not monotone" : (bad & 2) ? "row index out of range" : "row indices of a column not strictly increasing");
-    d->P = s->cP;
-    d->stride_P = shared ? 0 : (long long)(n * n);
+    if (expand) {
+        d->P = s->cP;
+        d->stride_P = shared ? 0 : (long long)(n * n);
+    } else {
+        d->P = s->cBad;  // (never read: the kernel takes P from the CsrDesc; run() wants a non-null pointer)
+        d->stride_P = 0;
+    }
     return SQPH_OK;
 }
 
@@ -986,11 +1017,22 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what,
     d.batch = c->batch; d.memspace = c->memspace;
     d.P = c->P; d.q = c->q; d.l = c->l; d.u = c->u;
     d.stride_P = c->stride_P; d.stride_q = c->stride_q; d.stride_l = c->stride_l; d.stride_u = c->stride_u;
-    if (sp) {  // P sparse as well: expanded into the handle's workspace; host q, l, u staged (d becomes a device-memspace batch)
-        const int rc = expand_sparse_P(s, c, sp, &d, what);
+    SparsePDev spd{};
+    bool sp_pending = false;  // P still in compressed columns: placed (checked / expanded) once the route is known
+    if (sp) {  // P sparse as well: device-resident columns; host q, l, u staged (d becomes a device-memspace batch)
+        const int rc = stage_sparse_P(s, c, sp, &d, &spd, what);
         if (rc != SQPH_OK) return rc;
+        sp_pending = true;
     }
-    if (s->m == 0) return run(s, &d, mode, what);
+    auto dense_P = [&]() -> int {  // the routes that read P dense: expand it into the handle's workspace
+        if (!sp_pending) return SQPH_OK;
+        sp_pending = false;
+        return place_sparse_P(s, c->batch, spd, true, &d, what);
+    };
+    if (s->m == 0) {
+        const int rc = dense_P();
+        return rc != SQPH_OK ? rc : run(s, &d, mode, what);
+    }
     if (!c->A_rowptr || (c->nnz_max > 0 && (!c->A_colind || !c->A_val))) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null CSR pointer", what);
     if (c->stride_rowptr < 0 || c->stride_colind < 0 || c->stride_val < 0 || c->nnz_max < 0)
         SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: negative stride / nnz_max", what);
@@ -1070,9 +1112,22 @@ int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what,
             if (bad & 3) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed CSR (%s)", what, (bad & 1) ? "row pointers not monotone" : "column index out of range");
             if (!(bad & 4)) {
                 CsrDesc cd{rowptr, colind, val, s_row, s_col, s_val ? s_val : 0, (int)c->nnz_max, TT, NB};
+                if (sp_pending && NB) {  // the block-row kernel reads the compressed columns in place: structure check only
+                    sp_pending = false;
+                    const int rc = place_sparse_P(s, c->batch, spd, false, &d, what);
+                    if (rc != SQPH_OK) return rc;
+                    cd.p_colptr = spd.colptr; cd.p_rowind = spd.rowind; cd.p_val = spd.val ? spd.val : (const void *)s->cBad;
+                    cd.s_pcolptr = spd.s_ptr; cd.s_prowind = spd.s_ind; cd.s_pval = spd.s_val;
+                }
+                const int rc = dense_P();  // (the 32 x 32 lane-grid kernel)
+                if (rc != SQPH_OK) return rc;
                 return run(s, &d, mode, what, &cd);
             }
         }
+    }
+    {
+        const int rc = dense_P();  // expand + dense route
+        if (rc != SQPH_OK) return rc;
     }
     const bool shared = s_val == 0;
     const size_t nexp = shared ? 1 : B;

@@ -834,7 +834,9 @@ def csr_sparse_P(make):
             s.setup_solve_csr(Parg, q, rp, ci, v, l, u)
             outs.append(tuple(s.solution()) + (s.kernel_name(),))
         (x0, y0, z0, i0, k0), (x1, y1, z1, i1, k1) = outs
-        assert k0 == k1, (k0, k1)
+        assert k1 in (k0, k0 + "_sp"), (k0, k1)  # (the block-row kernel's sparse-P instantiations read the columns in place)
+        if n == 200:
+            assert k1 == "csb_nb13_sp", k1
         assert np.array_equal(x0, x1) and np.array_equal(y0, y1) and np.array_equal(z0, z1)
         assert (i0.iter == i1.iter).all() and (i0.status == i1.status).all()
         s = make(n, m, B)

@@ -117,4 +117,16 @@ int sim_run_csrb(const SimArgs *s, const int *rowptr, const int *colind, const v
     sqph::CsrArgs<double> ca{rowptr, colind, (const double *)val, s_rowptr, s_colind, s_val, nnz_cap};
     return sqph::sim_run_csrb<double>(convert<double>(*s), ca);
 }
+
+// ... with P in compressed columns (the sparse-P instantiations, sqph_*_csr_sp)
+int sim_run_csrb_sp(const SimArgs *s, const int *rowptr, const int *colind, const void *val, long long s_rowptr, long long s_colind,
+                    long long s_val, int nnz_cap, int dtype, const int *pcol, const int *prow, const void *pval, long long s_pcol,
+                    long long s_prow, long long s_pval) {
+    if (dtype == SQPH_F32) {
+        sqph::CsrArgs<float> ca{rowptr, colind, (const float *)val, s_rowptr, s_colind, s_val, nnz_cap, pcol, prow, (const float *)pval, s_pcol, s_prow, s_pval};
+        return sqph::sim_run_csrb_sp<float>(convert<float>(*s), ca);
+    }
+    sqph::CsrArgs<double> ca{rowptr, colind, (const double *)val, s_rowptr, s_colind, s_val, nnz_cap, pcol, prow, (const double *)pval, s_pcol, s_prow, s_pval};
+    return sqph::sim_run_csrb_sp<double>(convert<double>(*s), ca);
+}
 }

@@ -51,6 +51,9 @@ def lib():
         _lib.sim_run_csr.restype = ctypes.c_int
         _lib.sim_run_csrb.argtypes = _lib.sim_run_csr.argtypes
         _lib.sim_run_csrb.restype = ctypes.c_int
+        _lib.sim_run_csrb_sp.argtypes = _lib.sim_run_csr.argtypes + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                                                                     ctypes.c_longlong, ctypes.c_longlong]
+        _lib.sim_run_csrb_sp.restype = ctypes.c_int
     return _lib
 
 
@@ -85,6 +88,11 @@ class SimSolverBatch:
 
     def _run(self, mode, P, q, A, l, u, csr=None):
         n, m = self.n, self.m
+        sparse_P = None
+        if isinstance(P, tuple):  # (colptr, rowind, val): the sparse-P instantiations of the block-row kernel
+            assert csr is not None and self.variant == CSRB
+            sparse_P = P
+            P = np.zeros((np.asarray(q).shape[0], n, n)) if np.asarray(q).ndim == 2 else np.zeros((n, n))
         if csr is not None:
             A = np.zeros((np.asarray(P).shape[0], m, n)) if np.asarray(P).ndim == 3 else np.zeros((m, n))
         if m == 0:
@@ -129,9 +137,17 @@ class SimSolverBatch:
             v = np.ascontiguousarray(v, self.dtype)
             shared = rp.ndim == 1
             fn = lib().sim_run_csrb if self.variant == CSRB else lib().sim_run_csr
+            extra = ()
+            if sparse_P is not None:
+                pc = np.ascontiguousarray(sparse_P[0], np.int32)
+                pr = np.ascontiguousarray(sparse_P[1], np.int32)
+                pv = np.ascontiguousarray(sparse_P[2], self.dtype)
+                fn = lib().sim_run_csrb_sp
+                extra = (pc.ctypes.data, pr.ctypes.data, pv.ctypes.data, 0 if pc.ndim == 1 else pc.shape[-1],
+                         0 if pr.ndim == 1 else pr.shape[-1], 0 if pv.ndim == 1 else pv.shape[-1])
             rc = fn(ctypes.byref(a), rp.ctypes.data, ci.ctypes.data, v.ctypes.data, 0 if shared else rp.shape[-1],
                                    0 if shared else ci.shape[-1], 0 if v.ndim == 1 else v.shape[-1], ci.shape[-1],
-                                   1 if self.dtype == np.float32 else 0)
+                                   1 if self.dtype == np.float32 else 0, *extra)
             if rc != 0:
                 raise RuntimeError("sim_run_csr failed rc=%d" % rc)
             self._last = B

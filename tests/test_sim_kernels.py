@@ -467,3 +467,43 @@ def test_lane_golden_fixtures():
         assert cases.relerr(x, g["x"]) < cases.TOL_F64 and cases.relerr1(y, g["y"]) < cases.TOL_F64, name
         assert (info.status == g["status"]).all() and (info.iter == g["iter"]).all() and (info.rho_updates == g["rho_updates"]).all(), name
     assert seen == 3
+
+
+@pytest.mark.parametrize("n,m,density,pdens,shared", [(12, 20, 0.3, 0.3, False), (40, 60, 0.15, 0.1, True), (70, 90, 0.1, 0.05, False),
+                                                       (200, 400, 0.05, 0.03, False)], ids=["nb1", "nb3", "nb5", "nb13"])
+def test_csrb_kernel_sparse_P_is_bit_identical_to_dense_P(n, m, density, pdens, shared):
+    """the block-row kernel's sparse-P instantiations (P in compressed columns: S phase and dual residual read it in place) against its
+    dense-P ones on the matrix the columns encode: same bits, fixed iterations and under termination checks with adaptive rho; a
+    column without a stored diagonal entry; the oracle"""
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    B = 1 if n >= 200 else 2
+    _, q, rp, ci, v, l, u, A = random_csr_qp_batch(B, n, m, density=density, seed=41, shared_pattern=shared)
+    P = cases.sparse_spd(B, n, pdens, seed=42, shared_pattern=shared)
+    cp, ri, pv = cases.dense_to_csr(P)
+    if shared:
+        rp, ci, cp, ri = rp[0], ci[0], cp[0], ri[0]
+    for fixed in ((True,) if n >= 200 else (True, False)):
+        outs = []
+        for Parg in (P, (cp, ri, pv)):
+            s = make_csrb(n, m, B)
+            if fixed:
+                s.settings.max_iter, s.settings.check_termination = (6 if n >= 200 else 25), 0
+            else:
+                s.settings.adaptive_rho, s.settings.adaptive_rho_interval, s.settings.eps_abs, s.settings.eps_rel = 1, 10, 1e-5, 1e-5
+            s.setup_solve_csr(Parg, q, rp, ci, v, l, u)
+            outs.append(s.solution())
+        (x0, y0, z0, i0), (x1, y1, z1, i1) = outs
+        assert np.array_equal(x0, x1) and np.array_equal(y0, y1) and np.array_equal(z0, z1)
+        assert (i0.iter == i1.iter).all() and (i0.status == i1.status).all() and (i0.rho_updates == i1.rho_updates).all()
+        assert np.array_equal(i0.res_prim, i1.res_prim) and np.array_equal(i0.res_dual, i1.res_dual)
+        xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings))
+        assert cases.relerr(x1, xo) < cases.TOL_F64 and cases.relerr(y1, yo) < cases.TOL_F64 and (i1.iter == io["iter"]).all()
+    if n == 12:  # P = 0 with no stored entry at all (S = sigma I + A'RA), and the stateful calls
+        z = (np.zeros(n + 1, np.int32), np.zeros(1, np.int32), np.zeros(1))
+        a, b = make_csrb(n, m, B), make_csrb(n, m, B)
+        for s, Parg in ((a, np.zeros((n, n))), (b, z)):
+            s.settings.max_iter = 25
+            s.setup_csr(Parg, q, rp, ci, v, l, u)
+            s.solve_csr(Parg, q, rp, ci, v, l, u)
+        assert np.array_equal(a.solution()[0], b.solution()[0]) and np.array_equal(a.solution()[1], b.solution()[1])
