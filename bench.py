@@ -107,7 +107,7 @@ def oracle_settings(st):
         adaptive_rho_interval=st.adaptive_rho_interval)
 
 
-def extra_line(name, n, m, B, mode, data, dev, steps=5, warmup=2, csr=None, nnz_avg=0.0, oracle_k=64, A_dense=None):
+def extra_line(name, n, m, B, mode, data, dev, steps=5, warmup=2, csr=None, nnz_avg=0.0, oracle_k=64, A_dense=None, P_sparse=None, pnnz_avg=0.0):
     """One of the other BASELINE configs, measured like the headline (device-resident inputs, HIP events around every launch on the
     launch stream, wall clock around `steps` launches) on a short run, with the GPU results of the first `oracle_k` QPs checked
     against the CPU oracle.  Returns the record that goes into the JSON line's `extra` object."""
@@ -124,8 +124,8 @@ def extra_line(name, n, m, B, mode, data, dev, steps=5, warmup=2, csr=None, nnz_
     solver.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        if csr is not None:
-            solver.setup_solve_csr(P, q, csr[0], csr[1], csr[2], l, u, colmajor=True)
+        if csr is not None:  # (P_sparse: P handed over in compressed columns as well, sqph_setup_solve_csr_sp)
+            solver.setup_solve_csr(P if P_sparse is None else P_sparse, q, csr[0], csr[1], csr[2], l, u, colmajor=True)
         else:
             solver.setup_solve(P, q, A_cm, l, u, colmajor=True)
 
@@ -152,10 +152,14 @@ def extra_line(name, n, m, B, mode, data, dev, steps=5, warmup=2, csr=None, nnz_
         bytes_per_qp = int(8 * (n * n + n + 2 * m) + 12 * nnz_avg + 4 * (m + 1) + 8 * (n + m) + 40)
         # what the no-check kernel needs: the lower triangle of P only (the full P is read by the residual checks alone)
         rec["needed_bytes_per_qp"] = int(8 * (n * (n + 1) // 2 + n + 2 * m) + 12 * nnz_avg + 4 * (m + 1) + 8 * (n + m) + 40)
+        if P_sparse is not None:  # 12 nnz(P) + 4 (n + 1) bytes of compressed columns instead of 8 n^2
+            bytes_per_qp = int(12 * pnnz_avg + 4 * (n + 1) + 8 * (n + 2 * m) + 12 * nnz_avg + 4 * (m + 1) + 8 * (n + m) + 40)
+            rec["needed_bytes_per_qp"] = bytes_per_qp
+            rec["nnz_P_avg"] = pnnz_avg
     kavg = float(np.mean(kernel_ms))
     achieved = bytes_per_qp * B / (kavg * 1e-3) / 1e9
     rec.update({
-        "workload": "%s: %d x (n=%d, m=%d) %s, %s" % (name, B, n, m, "CSR A" if csr is not None else "dense", mode),
+        "workload": "%s: %d x (n=%d, m=%d) %s, %s" % (name, B, n, m, ("CSR A, CSC P" if P_sparse is not None else "CSR A") if csr is not None else "dense", mode),
         "ms_per_step": elapsed / steps * 1e3, "kernel_ms_avg": kavg, "value": B * steps / elapsed, "unit": "QP/s",
         "admm_iters_per_qp": iters, "kernel": solver.kernel_name(), "steps": steps, "timing": "faster of two repetitions of `steps` launches",
         "algorithmic_bytes_per_qp": bytes_per_qp, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
@@ -207,7 +211,14 @@ def extra_configs(dev, c3_data):
     P, q, rp, ci, v, l, u, A_dense, nnz_avg = bench_csr.make(8192, 200, 400, 0.05, 20250228 + 5, dev)
     out["c5"] = extra_line("configs[4]", 200, 400, 8192, "fixed", (P, q, None, l, u), dev, steps=3, warmup=1, csr=(rp, ci, v),
                            nnz_avg=nnz_avg, oracle_k=64, A_dense=A_dense)
-    del P, q, rp, ci, v, l, u, A_dense
+    # the same shape with P sparse as well (the legacy sparse class keeps P as Eigen::SparseMatrix, unsupported/qp_solver.hpp:24-25):
+    # a 3 %-dense diagonally dominant P in compressed columns, read in place by the block-row kernel's sparse-P instantiations
+    del P
+    torch.cuda.empty_cache()
+    Pd, Psp, pnnz = bench_csr.make_sparse_P(8192, 200, 0.03, 20250228 + 6, dev)
+    out["c5_sparse_P"] = extra_line("configs[4] shape, P sparse too", 200, 400, 8192, "fixed", (Pd, q, None, l, u), dev, steps=3, warmup=1,
+                                    csr=(rp, ci, v), nnz_avg=nnz_avg, oracle_k=64, A_dense=A_dense, P_sparse=Psp, pnnz_avg=pnnz)
+    del Pd, Psp, q, rp, ci, v, l, u, A_dense
     torch.cuda.empty_cache()
     out["c4"] = sqp_driver_line()
     return out

@@ -155,6 +155,11 @@ def test_recorded_round5_default_line_is_the_whole_batch_with_every_config():
     assert d["roofline"]["traffic"] and d["extra"]["c5"]["traffic"] and d["extra"]["c5"]["kernel"].startswith("csb_")
     assert d["pcie_inclusive"]["value"] < d["value"]
     assert d["cpu_baseline"]["threads_over_one_thread"] > 1
+    sp = d["extra"].get("c5_sparse_P")  # configs[4]'s shape with P in compressed columns, read in place by the block-row kernel
+    if sp is not None:
+        assert sp["kernel"].endswith("_sp") and sp["algorithmic_bytes_per_qp"] < d["extra"]["c5"]["algorithmic_bytes_per_qp"] // 3
+        p = sp["parity"]
+        assert p["max_rel_err_x"] < 1e-6 and p["max_rel_err_y"] < 1e-6 and p["status_equal"] and p["iter_equal"], p
 
 
 @pytest.mark.gpu

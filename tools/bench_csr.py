@@ -59,6 +59,31 @@ def make(batch, n, m, density, seed, dev):
     return P, q, rowptr, colind, val, l, u, A, float(nnz.double().mean())
 
 
+def make_sparse_P(batch, n, density, seed, dev):
+    """Symmetric, strictly diagonally dominant P with about `density` of the off-diagonal entries present (one pattern per QP): the dense
+    matrices [batch, n, n] and their compressed columns (colptr [batch, n + 1], rowind / val [batch, nnz_max]; sqph_csc_P), mean nnz."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    mask = torch.triu(torch.rand((batch, n, n), generator=g, device=dev) < density, 1)
+    U = torch.randn((batch, n, n), generator=g, dtype=torch.float64, device=dev) * mask
+    P = U + U.transpose(1, 2)
+    P += torch.diag_embed(P.abs().sum(2) + 0.5 + torch.rand((batch, n), generator=g, dtype=torch.float64, device=dev))
+    nz = P != 0
+    colptr = torch.zeros((batch, n + 1), dtype=torch.int32, device=dev)
+    colptr[:, 1:] = nz.sum(2).cumsum(1).to(torch.int32)  # symmetric: row counts == column counts
+    pn = colptr[:, -1].to(torch.int64)
+    idx = nz.nonzero()
+    start = torch.zeros(batch, dtype=torch.int64, device=dev)
+    start[1:] = pn.cumsum(0)[:-1]
+    pos = torch.arange(idx.shape[0], device=dev) - start[idx[:, 0]]
+    pmax = int(pn.max())
+    rowind = torch.zeros((batch, pmax), dtype=torch.int32, device=dev)
+    pval = torch.zeros((batch, pmax), dtype=torch.float64, device=dev)
+    rowind[idx[:, 0], pos] = idx[:, 2].to(torch.int32)
+    pval[idx[:, 0], pos] = P[idx[:, 0], idx[:, 1], idx[:, 2]]
+    return P, (colptr, rowind, pval), float(pn.double().mean())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8192)

@@ -27,26 +27,7 @@ def main():
     dev = torch.device("cuda:0")
     n, m, B = a.n, a.m, a.batch
     _, q, rp, ci, v, l, u, A, nnz = bench_csr.make(B, n, m, 0.05, 20250233, dev)
-    g = torch.Generator(device=dev)
-    g.manual_seed(7)
-    # symmetric, strictly diagonally dominant, about pdensity of the off-diagonal entries present (one pattern per QP)
-    mask = torch.triu(torch.rand((B, n, n), generator=g, device=dev) < a.pdensity, 1)
-    U = torch.randn((B, n, n), generator=g, dtype=torch.float64, device=dev) * mask
-    P = U + U.transpose(1, 2)
-    P += torch.diag_embed(P.abs().sum(2) + 0.5 + torch.rand((B, n), generator=g, dtype=torch.float64, device=dev))
-    nz = P != 0
-    colptr = torch.zeros((B, n + 1), dtype=torch.int32, device=dev)
-    colptr[:, 1:] = nz.sum(2).cumsum(1).to(torch.int32)  # symmetric: row counts == column counts
-    pn = colptr[:, -1].to(torch.int64)
-    idx = nz.nonzero()
-    start = torch.zeros(B, dtype=torch.int64, device=dev)
-    start[1:] = pn.cumsum(0)[:-1]
-    pos = torch.arange(idx.shape[0], device=dev) - start[idx[:, 0]]
-    pmax = int(pn.max())
-    rowind = torch.zeros((B, pmax), dtype=torch.int32, device=dev)
-    pval = torch.zeros((B, pmax), dtype=torch.float64, device=dev)
-    rowind[idx[:, 0], pos] = idx[:, 2].to(torch.int32)
-    pval[idx[:, 0], pos] = P[idx[:, 0], idx[:, 1], idx[:, 2]]
+    P, (colptr, rowind, pval), pnnz = bench_csr.make_sparse_P(B, n, a.pdensity, 7, dev)
     out = {}
     for name, Parg in (("dense P", P), ("sparse P", (colptr, rowind, pval))):
         s = QPSolverBatch(n, m, B)
@@ -65,7 +46,6 @@ def main():
         print("%-9s kernel %-12s %7.3f ms per batch of %d (min %.3f)  mean iterations %.1f" % (name, s.kernel_name(), float(np.mean(ms)), B, float(np.min(ms)), info.iter.mean()))
     same = np.array_equal(out["dense P"][0], out["sparse P"][0]) and np.array_equal(out["dense P"][1], out["sparse P"][1]) and \
         (out["dense P"][2].iter == out["sparse P"][2].iter).all()
-    pnnz = float(pn.double().mean())
     dense_bytes = 8 * (n * n + n + 2 * m) + 12 * nnz + 4 * (m + 1) + 8 * (n + m) + 40
     sparse_bytes = 12 * pnnz + 4 * (n + 1) + 8 * (n + 2 * m) + 12 * nnz + 4 * (m + 1) + 8 * (n + m) + 40
     print("bit-identical x, y, iterations: %s;  nnz(P) %.0f of %d;  algorithmic bytes per QP %.0f (dense P) -> %.0f (sparse P)" % (same, pnnz, n * n, dense_bytes, sparse_bytes))
