@@ -483,14 +483,14 @@ def test_csrb_kernel_sparse_P_is_bit_identical_to_dense_P(n, m, density, pdens, 
     cp, ri, pv = cases.dense_to_csr(P)
     if shared:
         rp, ci, cp, ri = rp[0], ci[0], cp[0], ri[0]
-    for fixed in ((True,) if n >= 200 else (True, False)):
+    for fixed in ((True, False) if n in (12, 70) else (True,)):
         outs = []
         for Parg in (P, (cp, ri, pv)):
             s = make_csrb(n, m, B)
             if fixed:
                 s.settings.max_iter, s.settings.check_termination = (6 if n >= 200 else 25), 0
             else:
-                s.settings.adaptive_rho, s.settings.adaptive_rho_interval, s.settings.eps_abs, s.settings.eps_rel = 1, 10, 1e-5, 1e-5
+                s.settings.adaptive_rho, s.settings.adaptive_rho_interval, s.settings.eps_abs, s.settings.eps_rel = 1, 10, 1e-4, 1e-4
             s.setup_solve_csr(Parg, q, rp, ci, v, l, u)
             outs.append(s.solution())
         (x0, y0, z0, i0), (x1, y1, z1, i1) = outs
