@@ -875,6 +875,15 @@ def csr_sparse_P(make):
             outs.append(s.solution())
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
         assert (outs[0][3].iter == outs[1][3].iter).all()
+    # P = 0 without a single stored entry (S = sigma I + A'RA) on the block-row kernel's sparse-P instantiation
+    Z = (np.zeros(n + 1, np.int32), np.zeros(1, np.int32), np.zeros(1))
+    outs = []
+    for Parg in (np.zeros((B, n, n)), Z):
+        s = make(n, m, B)
+        s.settings.max_iter = 30
+        s.setup_solve_csr(Parg, q, rp, ci, v, l, u)
+        outs.append(tuple(s.solution()) + (s.kernel_name(),))
+    assert outs[1][4] == "csb_nb13_sp" and np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     import torch
 
     dev = torch.device("cuda", 0)
