@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=-1,
                     help="total batch over all GPUs (strong scaling); 0 = --batch-per-gpu on every GPU (weak); default: 65536 for the "
                          "c3 workload at its BASELINE shape (configs[2] is that batch), weak otherwise")
+    ap.add_argument("--p-density", type=float, default=0.0,
+                    help="with --workload c5: P sparse as well — a diagonally dominant P with this fraction of its off-diagonal entries, handed "
+                         "over in compressed columns (sqph_setup_solve_csr_sp: read in place by the block-row kernel)")
     ap.add_argument("--mode", choices=["fixed", "default", "sqp"], default="fixed")
     ap.add_argument("--iters", type=int, default=200, help="ADMM iterations per QP in --mode fixed")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
@@ -316,6 +319,10 @@ def main():
         P, q, rp, ci, v, l, u, A_dense, nnz_avg = bench_csr.make(B, n, m, 0.05, 20250228 + 5 + 1000 * rank, dev)
         csr = (rp, ci, v)
         A_cm = None
+        P_arg, pnnz_avg = P, 0.0
+        if args.p_density > 0:
+            del P
+            P, P_arg, pnnz_avg = bench_csr.make_sparse_P(B, n, args.p_density, 20250228 + 6 + 1000 * rank, dev)
     else:
         P, q, A_cm, l, u = random_qp_batch_torch(B, n, m, seed=20250228 + 3 + 1000 * rank, dtype=tdt, device=dev)
     torch.cuda.synchronize()
@@ -330,7 +337,7 @@ def main():
 
     def step():
         if csr is not None:
-            solver.setup_solve_csr(P, q, csr[0], csr[1], csr[2], l, u, colmajor=True)  # P handed over as it lies (column-major per QP)
+            solver.setup_solve_csr(P_arg, q, csr[0], csr[1], csr[2], l, u, colmajor=True)  # P handed over as it lies (column-major per QP, or its compressed columns)
         else:
             solver.setup_solve(P, q, A_cm, l, u, colmajor=True)
 
@@ -431,6 +438,8 @@ def main():
         if csr is not None:
             # CSR A: 8(n^2 + n + 2m) + 12 nnz + 4(m+1) read, 8(n+m) + 40 written
             bytes_per_qp = int(8 * (n * n + n + 2 * m) + 12 * nnz_avg + 4 * (m + 1) + 8 * (n + m) + 40)
+            if args.p_density > 0:  # 12 nnz(P) + 4 (n + 1) bytes of compressed columns instead of 8 n^2
+                bytes_per_qp = int(12 * pnnz_avg + 4 * (n + 1) + 8 * (n + 2 * m) + 12 * nnz_avg + 4 * (m + 1) + 8 * (n + m) + 40)
             flops_per_iter = 2.0 * (2 * nnz_avg + n * n)
             kernel_ms = kernel_ms[-args.steps:]  # one solver launch per step (the structural pre-check is not an event pair)
         avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
@@ -441,7 +450,7 @@ def main():
         if args.workload == "c2":
             label = "BASELINE configs[1]"
         elif args.workload == "c5":
-            label = "BASELINE configs[4]"
+            label = "BASELINE configs[4]" if args.p_density <= 0 else "BASELINE configs[4]'s shape with P in compressed columns (%.0f entries per QP)" % pnnz_avg
         elif (n, m) == (50, 100):
             label = "BASELINE configs[2] whole batch" if total_batch >= 65536 else "BASELINE configs[2] shard"
         else:

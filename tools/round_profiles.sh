@@ -21,6 +21,7 @@ run c3_default --workload c3 --global-batch 0 --mode default
 run c3_sqp --workload c3 --global-batch 0 --mode sqp
 run c2 --workload c2
 run c5 --workload c5 --steps 5
+run c5_sp --workload c5 --steps 5 --p-density 0.03          # the same shape with P in compressed columns (read in place)
 run lane --n 2 --m 3 --batch-per-gpu 65536
 [ $PHASE = prof ] && exit 0
 timeout 600 python bench.py --global-batch 65536 --steps 5 --mode default >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
