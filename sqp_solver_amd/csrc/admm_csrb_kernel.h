@@ -27,7 +27,7 @@
 #endif
 
 #ifndef SQPH_CSB_EB
-#define SQPH_CSB_EB 4  // CSC entries of a column accumulated per batch in the S phase
+#define SQPH_CSB_EB 3  // CSC entries of a column accumulated per batch in the S phase (1 / 2 / 3 / 4 measured: 21.95 / 21.55 / 21.51 / 21.60 ms; 6.7 / 6.2 / 6.2 / 6.9 GB of traffic)
 #endif
 
 namespace sqph {
@@ -720,8 +720,7 @@ struct CsbKernel {
             __syncthreads();
             for (int e = t; e < 32 * LDP; e += NT) Sp[e] = 0;
             __syncthreads();
-            T pvn[14];
-            if constexpr (!SP) load_P(p + 1 < (NB + 1) / 2 ? p + 1 : p, pvn);
+
             const int j = 32 * p + g;
             if (j < n) {
                 constexpr int EB = SQPH_CSB_EB;
@@ -785,10 +784,10 @@ struct CsbKernel {
                 }
                 }
             }
-            if constexpr (!SP) {
-#pragma unroll
-            for (int q = 0; q < 14; q++) pv[q] = pvn[q];
-            }
+            // the next panel's share of P, requested as soon as this panel's has been added: in flight across the barrier, the pick-up,
+            // the clearing of the panel and the next accumulation loop, in the ONE array (a second array filled at the top of the panel
+            // measured the same time, 21.55 ms, with 38 more VGPRs spilled: 8.0 against 6.9 GB of HBM traffic per launch)
+            if constexpr (!SP) load_P(p + 1 < (NB + 1) / 2 ? p + 1 : p, pv);
             __syncthreads();
             pick_up(wave, p, n, Sp, lr, lq, B);
         }
