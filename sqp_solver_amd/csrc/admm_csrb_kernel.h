@@ -29,6 +29,9 @@
 #ifndef SQPH_CSB_EB
 #define SQPH_CSB_EB 3  // CSC entries of a column accumulated per batch in the S phase (1 / 2 / 3 / 4 measured: 21.95 / 21.55 / 21.51 / 21.60 ms; 6.7 / 6.2 / 6.2 / 6.9 GB of traffic)
 #endif
+#ifndef SQPH_CSB_EB_SP
+#define SQPH_CSB_EB_SP 4  // ... in the sparse-P instantiations (no prefetch array of P there: the wider batch pays)
+#endif
 
 namespace sqph {
 
@@ -723,7 +726,7 @@ struct CsbKernel {
 
             const int j = 32 * p + g;
             if (j < n) {
-                constexpr int EB = SQPH_CSB_EB;
+                constexpr int EB = SP ? SQPH_CSB_EB_SP : SQPH_CSB_EB;
                 // EB CSC entries of the column at a time: their index / coefficient / row loads are all in flight together, the
                 // products go to the panel by ds_add_f64 (no returned value, so no entry waits for the LDS round trip of the one
                 // before it; additions to one address are issued by this wavefront in program order: deterministic sums).  As a
@@ -749,15 +752,16 @@ struct CsbKernel {
                         k[bb] = col[f];
                         v[bb] = val[f];
                     }
+                    // (entry by entry — a row's first 16 non-zeros, then the rest of a longer row — so that the order of the additions to
+                    // one address does not depend on EB: the dense-P and the sparse-P instantiations batch differently and must agree bit for bit)
 #pragma unroll
-                    for (int bb = 0; bb < EB; bb++)
+                    for (int bb = 0; bb < EB; bb++) {
                         if (in[bb] && k[bb] >= j) lds_add_f64(&Sp[g * LDP + k[bb]], cf[bb] * v[bb]);
-#pragma unroll
-                    for (int bb = 0; bb < EB; bb++)  // (rows of more than 16 entries)
-                        for (int f = f0[bb] + 16; f < f1[bb]; f += 16) {
+                        for (int f = f0[bb] + 16; f < f1[bb]; f += 16) {  // (rows of more than 16 entries)
                             const int kk = col[f];
                             if (kk >= j) lds_add_f64(&Sp[g * LDP + kk], cf[bb] * val[f]);
                         }
+                    }
                 }
                 // + lower triangle of P + sigma I
 #ifdef SQPH_SIM
