@@ -238,7 +238,7 @@ int sqph_update_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);  /* = sqph_
  * workspace (one matrix when shared) and the call continues as its dense-P twin.  Either way the results are bit-identical to
  * passing that dense P, and what crosses the boundary (and PCIe, for host memspace) is 12 nnz(P) + 4 (n + 1) bytes per QP instead
  * of 8 n^2.  P must be symmetric.  A malformed structure (column pointers not monotone / beyond nnz_max, row index out of range or
- * not strictly increasing) is SQPH_ERR_INVALID, detected on the device before anything is solved. */
+ * not strictly increasing, a pattern that is not symmetric — a triangle instead of the full matrix) is SQPH_ERR_INVALID, detected on the device before anything is solved. */
 int sqph_setup_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_update_qp_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);

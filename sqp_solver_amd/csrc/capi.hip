@@ -114,7 +114,8 @@ __global__ void csr_expand(int batch, int n, int m, const int *__restrict__ rowp
 }
 
 // Compressed-column P -> dense column-major (sqph_*_csr_sp): one thread per (QP, column); `dst` must be zero-filled.
-// bad: bit 0 = column pointers malformed, bit 1 = row index out of range, bit 2 = rows of a column not strictly increasing.
+// bad: bit 0 = column pointers malformed, bit 1 = row index out of range, bit 2 = rows of a column not strictly increasing,
+// bit 3 = the pattern is not symmetric (entry (i, j) without (j, i): a triangle was passed instead of the full matrix).
 template <typename TIN>
 __global__ void csc_expand_P(int batch, int n, const int *__restrict__ colptr, const int *__restrict__ rowind, const TIN *__restrict__ val,
                              long long s_colptr, long long s_rowind, long long s_val, long long nnz_cap, TIN *__restrict__ dst,
@@ -134,6 +135,19 @@ __global__ void csc_expand_P(int batch, int n, const int *__restrict__ colptr, c
         if (i < 0 || i >= n) { atomicOr(bad, 2); continue; }
         if (i <= prev) atomicOr(bad, 4);
         prev = i;
+        if (i != j) {  // the mirror entry (j, i): binary search in column i (a malformed column i is reported by its own thread)
+            int lo = cp[i], hi = cp[i + 1];
+            bool found = false;
+            if (lo >= 0 && hi <= nnz_cap) {
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1, r = ri[mid];
+                    if (r == j) { found = true; break; }
+                    if (r < j) lo = mid + 1;
+                    else hi = mid;
+                }
+            }
+            if (!found) atomicOr(bad, 8);
+        }
         if (dst) d[i] = v[e];  // (dst == nullptr: structure check only — the block-row kernel reads the columns in place)
     }
 }
@@ -995,7 +1009,8 @@ static int place_sparse_P(sqph_solver *s, int batch, const SparsePDev &dv, bool 
     SQPH_HIP(s, hipStreamSynchronize(s->stream));  // (also ends the borrow of the pageable host arrays staged above)
     if (bad)
         SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed sparse P (%s)", what,
-                  (bad & 1) ? "column pointers not monotone" : (bad & 2) ? "row index out of range" : "row indices of a column not strictly increasing");
+                  (bad & 1) ? "column pointers not monotone" : (bad & 2) ? "row index out of range"
+                  : (bad & 4) ? "row indices of a column not strictly increasing" : "pattern not symmetric: the full matrix is expected, not a triangle");
     if (expand) {
         d->P = s->cP;
         d->stride_P = shared ? 0 : (long long)(n * n);

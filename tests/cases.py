@@ -916,6 +916,9 @@ def csr_sparse_P(make):
     bad[1, e0], bad[1, e0 + 1] = ri[1, e0 + 1], ri[1, e0]
     with pytest.raises(SqphError, match="strictly increasing"):
         s.setup_solve_csr((cp, bad, pv), q, rp, ci, v, l, u)
+    tri = dense_to_csr(np.triu(sparse_spd(B, n, 0.2, seed=13)))  # the upper triangle alone (another solver's convention) is rejected
+    with pytest.raises(SqphError, match="not symmetric"):
+        s.setup_solve_csr(tri, q, rp, ci, v, l, u)
     s.setup_solve_csr((cp, ri, pv), q, rp, ci, v, l, u)  # the handle is usable afterwards
     assert (s.info().status != UNINITIALIZED).all()
 
