@@ -29,6 +29,9 @@
 #ifndef SQPH_CSB_EB
 #define SQPH_CSB_EB 3  // CSC entries of a column accumulated per batch in the S phase (1 / 2 / 3 / 4 measured: 21.95 / 21.55 / 21.51 / 21.60 ms; 6.7 / 6.2 / 6.2 / 6.9 GB of traffic)
 #endif
+#ifndef SQPH_CSB_PLACE_MIN_ITERS
+#define SQPH_CSB_PLACE_MIN_ITERS 150  // settings.max_iter from which the register-resident slices are placed (CsbKernel::run)
+#endif
 #ifndef SQPH_CSB_EB_SP
 #define SQPH_CSB_EB_SP 4  // ... in the sparse-P instantiations (no prefetch array of P there: the wider batch pays)
 #endif
@@ -552,8 +555,9 @@ struct CsbKernel {
     }
     // ROWS: the CSR slices (gathering x~, `vlen` = NP elements are defined); otherwise the CSC slices (gathering w, vlen = m)
     template <bool ROWS>
+    // place = false (block-uniform): no rounds, the entries keep their storage order (what the loop below leaves is dealt in order)
     static __device__ __forceinline__ SlotCode place_slots(const int *ptr, const unsigned short *col, const unsigned *csc, int mp, int vlen,
-                                                          unsigned *area, int t) {
+                                                          unsigned *area, int t, bool place) {
         constexpr unsigned KMASK = (1u << KR) - 1u;
         const int hw = t >> 5, lh = t & 31;
         unsigned *taken = area + hw * PLACE_WORDS, *cell = taken + 32, *pad = cell + KR * 32;
@@ -568,7 +572,7 @@ struct CsbKernel {
         unsigned used = 0;
         int e = 0;
 #pragma unroll 1
-        for (int round = 0; round < 4 * KR; round++) {
+        for (int round = 0; round < (place ? 4 * KR : 0); round++) {
             const bool active = e < cnt;
             if (!wave_any(active)) break;
             int s = -1, b = 0;
@@ -1493,8 +1497,13 @@ struct CsbKernel {
             SlotCode rsc{0, 0}, csc_{0, 0};
             {   // slots of the register-resident slices (the work area is idle; per half-wavefront tables, no workgroup barrier inside)
                 unsigned *area = reinterpret_cast<unsigned *>(lds);
-                if (rreg) rsc = place_slots<true>(rowptr, col, csc, rmap, NP, area, t);
-                if (creg) csc_ = place_slots<false>(colptr, col, csc, cmap, m, area, t);
+                // ... where the solve is long enough to pay for it: same-box at config 5, placement against storage order — 200 fixed
+                // iterations 21.42 / 22.01 ms, the reference defaults (max_iter 1000) 55.4 / 55.5, the SQP driver's settings (max_iter 100,
+                // a check every 10) 27.4 / 25.7.  The choice depends on settings.max_iter alone (block-uniform, the same for every QP
+                // and every call with these settings: results stay reproducible); the summation order inside a lane follows the slots.
+                const bool place = a.max_iter >= SQPH_CSB_PLACE_MIN_ITERS;
+                if (rreg) rsc = place_slots<true>(rowptr, col, csc, rmap, NP, area, t, place);
+                if (creg) csc_ = place_slots<false>(colptr, col, csc, cmap, m, area, t, place);
                 __syncthreads();
             }
             for (int e = t; e < NP * 8; e += NT) xp[e] = T(0);
