@@ -138,13 +138,14 @@ def extra_line(name, n, m, B, mode, data, dev, steps=5, warmup=2, csr=None, nnz_
     solver.enable_timing(True)
     # two timed repetitions of `steps` launches, the faster one reported (a short run right behind another workload's tear-down
     # has shown one-off host stalls of tens of ms: the kernel events did not move, the wall clock of that repetition did)
-    elapsed = float("inf")
+    reps = []
     for _ in range(2):
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        elapsed = min(elapsed, time.perf_counter() - t0)
+        reps.append(time.perf_counter() - t0)
+    elapsed = min(reps)
     kernel_ms = solver.collect_kernel_ms()[-steps:]
     solver.enable_timing(False)
     info = solver.info()
@@ -164,7 +165,9 @@ def extra_line(name, n, m, B, mode, data, dev, steps=5, warmup=2, csr=None, nnz_
     rec.update({
         "workload": "%s: %d x (n=%d, m=%d) %s, %s" % (name, B, n, m, ("CSR A, CSC P" if P_sparse is not None else "CSR A") if csr is not None else "dense", mode),
         "ms_per_step": elapsed / steps * 1e3, "kernel_ms_avg": kavg, "value": B * steps / elapsed, "unit": "QP/s",
-        "admm_iters_per_qp": iters, "kernel": solver.kernel_name(), "steps": steps, "timing": "faster of two repetitions of `steps` launches",
+        "admm_iters_per_qp": iters, "kernel": solver.kernel_name(), "steps": steps,
+        # both repetitions are printed (the headline is ONE timed run of --steps launches: compare it with ms_per_step_repetitions[0])
+        "timing": "faster of two repetitions of `steps` launches", "ms_per_step_repetitions": [r / steps * 1e3 for r in reps],
         "algorithmic_bytes_per_qp": bytes_per_qp, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
         "traffic": pmc_traffic(solver.kernel_name(), n, m, B, mode),
     })
@@ -200,8 +203,8 @@ def extra_configs(dev, c3_data):
     from sqp_solver_amd.problems import random_qp_batch_torch
 
     out = {}
-    out["c3_default"] = extra_line("configs[2] shard", 50, 100, c3_data[0].shape[0], "default", c3_data, dev, steps=10)
-    out["c3_sqp"] = extra_line("configs[2] shard", 50, 100, c3_data[0].shape[0], "sqp", c3_data, dev, steps=10)
+    out["c3_default"] = extra_line("configs[2] shard", 50, 100, c3_data[0].shape[0], "default", c3_data, dev, steps=10, oracle_k=256)
+    out["c3_sqp"] = extra_line("configs[2] shard", 50, 100, c3_data[0].shape[0], "sqp", c3_data, dev, steps=10, oracle_k=256)
     d = random_qp_batch_torch(4096, 20, 40, seed=20250228 + 2, dtype=torch.float64, device=dev)
     out["c2"] = extra_line("configs[1]", 20, 40, 4096, "fixed", d, dev, steps=20, oracle_k=256)
     del d
@@ -213,14 +216,24 @@ def extra_configs(dev, c3_data):
 
     P, q, rp, ci, v, l, u, A_dense, nnz_avg = bench_csr.make(8192, 200, 400, 0.05, 20250228 + 5, dev)
     out["c5"] = extra_line("configs[4]", 200, 400, 8192, "fixed", (P, q, None, l, u), dev, steps=3, warmup=1, csr=(rp, ci, v),
-                           nnz_avg=nnz_avg, oracle_k=64, A_dense=A_dense)
+                           nnz_avg=nnz_avg, oracle_k=128, A_dense=A_dense)
+    # ... under the reference's default settings (termination checks, 383 iterations per QP here) and under the SQP driver's
+    out["c5_default"] = extra_line("configs[4]", 200, 400, 8192, "default", (P, q, None, l, u), dev, steps=2, warmup=1, csr=(rp, ci, v),
+                                   nnz_avg=nnz_avg, oracle_k=128, A_dense=A_dense)
+    out["c5_sqp"] = extra_line("configs[4]", 200, 400, 8192, "sqp", (P, q, None, l, u), dev, steps=3, warmup=1, csr=(rp, ci, v),
+                               nnz_avg=nnz_avg, oracle_k=128, A_dense=A_dense)
     # the same shape with P sparse as well (the legacy sparse class keeps P as Eigen::SparseMatrix, unsupported/qp_solver.hpp:24-25):
     # a 3 %-dense diagonally dominant P in compressed columns, read in place by the block-row kernel's sparse-P instantiations
     del P
     torch.cuda.empty_cache()
     Pd, Psp, pnnz = bench_csr.make_sparse_P(8192, 200, 0.03, 20250228 + 6, dev)
     out["c5_sparse_P"] = extra_line("configs[4] shape, P sparse too", 200, 400, 8192, "fixed", (Pd, q, None, l, u), dev, steps=3, warmup=1,
-                                    csr=(rp, ci, v), nnz_avg=nnz_avg, oracle_k=64, A_dense=A_dense, P_sparse=Psp, pnnz_avg=pnnz)
+                                    csr=(rp, ci, v), nnz_avg=nnz_avg, oracle_k=128, A_dense=A_dense, P_sparse=Psp, pnnz_avg=pnnz)
+    # (the dual half of a check walks the compressed columns instead of streaming 8 n^2 bytes of P: the check traffic of this route)
+    out["c5_sparse_P_default"] = extra_line("configs[4] shape, P sparse too", 200, 400, 8192, "default", (Pd, q, None, l, u), dev, steps=1, warmup=1,
+                                            csr=(rp, ci, v), nnz_avg=nnz_avg, oracle_k=128, A_dense=A_dense, P_sparse=Psp, pnnz_avg=pnnz)
+    out["c5_sparse_P_sqp"] = extra_line("configs[4] shape, P sparse too", 200, 400, 8192, "sqp", (Pd, q, None, l, u), dev, steps=3, warmup=1,
+                                        csr=(rp, ci, v), nnz_avg=nnz_avg, oracle_k=128, A_dense=A_dense, P_sparse=Psp, pnnz_avg=pnnz)
     del Pd, Psp, q, rp, ci, v, l, u, A_dense
     torch.cuda.empty_cache()
     out["c4"] = sqp_driver_line()

@@ -24,7 +24,7 @@
  *   legacy sparse QP<n,m> (Eigen::SparseMatrix A), setup/update_qp/solve
  *                                 include/unsupported/qp_solver.hpp:17-32,215-330   sqph_*_csr (sqph_csr_batch: dense P, CSR A), sqph_*_csr_sp (+ sqph_csc_P: P sparse too)
  *   non-const x / y / z accessors (warm starts)  qp.hpp:160-164    sqph_set_state
- *   the SOC re-solve: same P, A, new bounds      src/sqp.cpp:244-276 (TODO :273)   sqph_setup_solve_reuse
+ *   the SOC re-solve: same P, A, new bounds      src/sqp.cpp:244-276 (TODO :273)   sqph_setup_solve_reuse (+ _csr, _csr_sp)
  *   settings.verbose / print_status              src/qp.cpp:72-76,113-117,373-383  sqph_set_trace_qp / sqph_get_trace
  *   one solver object per problem, spread over threads (and devices) by the caller
  *                                 qp.hpp:217-247                   sqph_device_count / sqph_shard_bounds / sqph_own_stream /
@@ -58,7 +58,9 @@
  *   - reproducibility: repeated calls on the same inputs are bit-identical (no atomics whose order is left to the hardware).
  *     The kernel is chosen by shape, settings AND, for m <= 4 with the one-QP-per-lane kernel, by the batch size of the call (a
  *     four-lanes-per-QP form serves batches <= 2,048): the same QP may then differ in its last bits between a small and a large
- *     batch (another summation order of A'w; both within the parity bar).
+ *     batch (another summation order of A'w; both within the parity bar).  On the sparse route the block-row kernel places the
+ *     register-resident entries of A by LDS bank where settings.max_iter >= 150 (SQPH_CSB_PLACE_MIN_ITERS) and keeps them in storage
+ *     order below: the per-lane summation order of A x and A'w — the last bits of a solve — therefore also depends on max_iter.
  *   - thread safety: distinct handles may be used from distinct host threads concurrently
  *     (tests/cpp/qp_facade_test.cpp: testTwoHostThreadsTwoHandles); one handle must not be.
  *     sqph_global_error() is per thread, sqph_last_error(s) per handle.
@@ -238,12 +240,19 @@ int sqph_update_solve_csr(sqph_solver *s, const sqph_csr_batch *qp);  /* = sqph_
  * workspace (one matrix when shared) and the call continues as its dense-P twin.  Either way the results are bit-identical to
  * passing that dense P, and what crosses the boundary (and PCIe, for host memspace) is 12 nnz(P) + 4 (n + 1) bytes per QP instead
  * of 8 n^2.  P must be symmetric.  A malformed structure (column pointers not monotone / beyond nnz_max, row index out of range or
- * not strictly increasing, a pattern that is not symmetric — a triangle instead of the full matrix) is SQPH_ERR_INVALID, detected on the device before anything is solved. */
+ * not strictly increasing, a pattern that is not symmetric — a triangle instead of the full matrix — or mirror entries whose values differ) is SQPH_ERR_INVALID, detected on the device before anything is solved. */
 int sqph_setup_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_update_qp_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_setup_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 int sqph_update_solve_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
+/* sqph_setup_solve_reuse on the sparse route: setup()+solve() of QPs whose P and A are those of this handle's previous set-up (the
+ * SQP second-order correction of a sparse subproblem: only q, l, u differ, src/sqp.cpp:244-276, TODO :273).  Results are exactly
+ * sqph_setup_solve_csr's; the factorisation is skipped for every QP whose freshly classified rho vector equals the one the resident
+ * factor was built with (needs SQPH_FLAG_KEEP_FACTOR or a preceding sqph_setup_csr / sqph_update_qp_csr served by the same
+ * kernel family; otherwise — and on routes without the fast path — identical to sqph_setup_solve_csr). */
+int sqph_setup_solve_reuse_csr(sqph_solver *s, const sqph_csr_batch *qp);
+int sqph_setup_solve_reuse_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P);
 
 /* Copy out primal x [batch][n], dual y [batch][m], z [batch][m] and info [batch]; any pointer
  * may be NULL. With SQPH_HOST this call synchronises the stream before returning. */

@@ -77,8 +77,9 @@ class MultiGpuBatchQPSolver {
             offs.push_back(lo_[g]);
             cnts.push_back((int)(hi_[g] - lo_[g]));
         }
-        // every shard's records in ONE grouped post, behind the solves: the root receives on one stream per peer
-        detail::check(sqph_gather_post_many(gather_, srcs.data(), offs.data(), cnts.data(), (int)srcs.size()), srcs[0], "sqph_gather_post_many");
+        // every shard's records in ONE grouped post, behind the solves (one RCCL group, the root receiving on its one stream).
+        // (an error is recorded on the FAILING shard's handle and in the calling thread's global error: the latter is reported)
+        detail::check(sqph_gather_post_many(gather_, srcs.data(), offs.data(), cnts.data(), (int)srcs.size()), nullptr, "sqph_gather_post_many");
         fetched_ = false;
     }
 

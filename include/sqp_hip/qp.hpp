@@ -199,6 +199,7 @@ class BatchQPSolver {
     void solve_csr(const CsrBatch &b) { call_csr(sqph_solve_csr, b, "sqph_solve_csr"); }
     void setup_solve_csr(const CsrBatch &b) { call_csr(sqph_setup_solve_csr, b, "sqph_setup_solve_csr"); }
     void update_solve_csr(const CsrBatch &b) { call_csr(sqph_update_solve_csr, b, "sqph_update_solve_csr"); }
+    void setup_solve_reuse_csr(const CsrBatch &b) { call_csr(sqph_setup_solve_reuse_csr, b, "sqph_setup_solve_reuse_csr"); }  // the SOC re-solve, sparse route
     // ... and with P sparse as well (the legacy sparse class keeps P as Eigen::SparseMatrix, unsupported/qp_solver.hpp:24-25): the
     // full symmetric matrix in compressed-column form, colptr [n+1], rowind / val [nnz_max] per QP; b.P is ignored.
     struct CscP {
@@ -214,6 +215,7 @@ class BatchQPSolver {
     void solve_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_solve_csr_sp, b, P, "sqph_solve_csr_sp"); }
     void setup_solve_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_setup_solve_csr_sp, b, P, "sqph_setup_solve_csr_sp"); }
     void update_solve_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_update_solve_csr_sp, b, P, "sqph_update_solve_csr_sp"); }
+    void setup_solve_reuse_csr(const CsrBatch &b, const CscP &P) { call_csr_sp(sqph_setup_solve_reuse_csr_sp, b, P, "sqph_setup_solve_reuse_csr_sp"); }
 
     // results of the last call (host copies, fetched lazily)
     const Scalar *primal_solution(int b) { fetch(); return &x_[(size_t)b * n_]; }
@@ -604,7 +606,9 @@ class QPSolver {
             }
         const auto b = impl_.packed_csr(1, nullptr, detail::ptr(qp.q), rowptr.data(), colind.data(), val.data(), nnz > 0 ? nnz : 1,
                                         detail::ptr(qp.l), detail::ptr(qp.u));
-        const auto sp = impl_.packed_csc_P(pcol.data(), prow.data(), pval.data(), pnnz);
+        // (an empty P — an LP — hands over one dummy entry that the all-zero column pointers never reference: nnz_max = 0 would turn
+        // the per-QP value / row-index strides into "shared", which the C-ABI rejects next to a per-QP colptr)
+        const auto sp = impl_.packed_csc_P(pcol.data(), prow.data(), pval.data(), pnnz > 0 ? pnnz : 1);
         if (op == OP_SETUP) impl_.setup_csr(b, sp);
         else if (op == OP_UPDATE) impl_.update_qp_csr(b, sp);
         else impl_.solve_csr(b, sp);

@@ -25,7 +25,7 @@ SYMBOLS = [
     "sqph_gather_post", "sqph_gather_fetch", "sqph_gather_device_ptrs", "sqph_setup_solve_reuse", "sqph_set_trace_qp", "sqph_get_trace",
     "sqph_update_solve", "sqph_gather_post_many",
     "sqph_setup_csr_sp", "sqph_update_qp_csr_sp", "sqph_solve_csr_sp", "sqph_setup_solve_csr_sp",
-    "sqph_update_solve_csr", "sqph_update_solve_csr_sp",
+    "sqph_update_solve_csr", "sqph_update_solve_csr_sp", "sqph_setup_solve_reuse_csr", "sqph_setup_solve_reuse_csr_sp",
 ]
 
 
@@ -123,7 +123,7 @@ def load(build_if_missing=True):
     L.sqph_get_settings.argtypes = [vp, ctypes.POINTER(Settings)]
     for name in ("sqph_setup", "sqph_update_qp", "sqph_solve", "sqph_setup_solve", "sqph_update_solve"):
         getattr(L, name).argtypes = [vp, ctypes.POINTER(QPBatch)]
-    for name in ("sqph_setup_csr", "sqph_update_qp_csr", "sqph_solve_csr", "sqph_setup_solve_csr", "sqph_update_solve_csr"):
+    for name in ("sqph_setup_csr", "sqph_update_qp_csr", "sqph_solve_csr", "sqph_setup_solve_csr", "sqph_update_solve_csr", "sqph_setup_solve_reuse_csr"):
         getattr(L, name).argtypes = [vp, ctypes.POINTER(CsrBatch)]
         getattr(L, name + "_sp").argtypes = [vp, ctypes.POINTER(CsrBatch), ctypes.POINTER(CscP)]
     L.sqph_get_solution.argtypes = [vp, i, i, vp, vp, vp, vp]

@@ -848,6 +848,7 @@ struct CsrKernel {
     const bool mown = (mp & MAP_VALID) != 0, lead = mown && ((mp >> 9) & 7) == 0
 
         T x = 0, z = 0, y = 0, rho = T(1);
+        bool rho_differs = false;  // against the vector the resident factor was built with (MODE_SAME_MATRICES)
         {
         SQPH_LANE(t);
         const int jn = t >> 2, ql = t & 3;
@@ -874,6 +875,7 @@ struct CsrKernel {
                     ctype = SQPH_EQUALITY_CONSTRAINT;
                 rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
                 if (lead) {
+                    rho_differs = !(rho == srho[im]);
                     rinvv[im] = T(1) / rho;
                     sct[im] = ctype;
                     srho[im] = rho;
@@ -900,6 +902,20 @@ struct CsrKernel {
 
         T w[NE];
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
+        if ((mode & MODE_SAME_MATRICES) && (mode & (MODE_SETUP | MODE_UPDATE)) && !(mode & MODE_REFACTOR) &&
+            info.status != SQPH_NUMERICAL_ISSUES && info.status != SQPH_UNINITIALIZED) {
+            // sqph_setup_solve_reuse_csr: same P and A as the resident factor, which is the one this set-up would build unless some
+            // row's freshly classified rho differs from the vector it was built with (see admm_csrb_kernel.h)
+            if (threadIdx.x == 0) st[0] = T(0);
+            __syncthreads();
+            if (rho_differs) st[0] = T(1);
+            __syncthreads();
+            if (st[0] == T(0)) {
+                need_factor = false;
+                info.status = SQPH_UNSOLVED;  // qp.cpp:39-43
+            }
+            __syncthreads();
+        }
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         if (!need_factor) {

@@ -36,6 +36,14 @@
 #define SQPH_CSB_EB_SP 4  // ... in the sparse-P instantiations (no prefetch array of P there: the wider batch pays)
 #endif
 
+// keeps the instruction scheduler from moving work across (the unrolled slot loops of the set-up: hoisting every slot's LDS operand
+// loads to the top of the loop needs 8 registers per slot next to the 112 of the blocks)
+#if defined(SQPH_SIM) || !defined(SQPH_CSB_SCHED_FENCE)
+#define SQPH_SLOT_FENCE() (void)0
+#else
+#define SQPH_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace sqph {
 
 template <int NB>
@@ -700,8 +708,9 @@ struct CsbKernel {
     // formed in the order of the dense path (an absent entry is a dense zero, whose addition changes nothing): bit-identical S.
     template <bool SP = false>
     static __device__ __forceinline__ void form_S(const TIN *__restrict__ gP, const int *__restrict__ pcol, const int *__restrict__ prow, int n,
-                                                  T sigma, const Lay &L, unsigned char *smem, int t, int wave, sqph_acc4 (&B)[NB + 1]) {
-        const int c16 = t & 15, g = t >> 4, lr = t & 15, lq = (t >> 4) & 3;
+                                                  T sigma, const Lay &L, unsigned char *smem, int t_, int wave_, sqph_acc4 (&B)[NB + 1]) {
+        int t = t_;
+        const int c16 = t & 15, g = t >> 4;
         T *lds = reinterpret_cast<T *>(smem);
         const int *li = reinterpret_cast<const int *>(smem);
         const int *rowptr = li + L.o_rowptr, *colptr = li + L.o_colptr;
@@ -797,7 +806,13 @@ struct CsbKernel {
             // measured the same time, 21.55 ms, with 38 more VGPRs spilled: 8.0 against 6.9 GB of HBM traffic per launch)
             if constexpr (!SP) load_P(p + 1 < (NB + 1) / 2 ? p + 1 : p, pv);
             __syncthreads();
-            pick_up(wave, p, n, Sp, lr, lq, B);
+            {   // (the lane's coordinates derived again per panel: hoisted out of this loop, the pick-up's per-slot addresses, bounds
+                // tests and identity-padding values of all 14 slots were spilled and reloaded from scratch memory)
+                int tp = t_, wp = wave_;
+                SQPH_OPAQUE_V(tp);
+                SQPH_OPAQUE_S(wp);
+                pick_up(wp, p, n, Sp, tp & 15, (tp >> 4) & 3, B);
+            }
         }
         __syncthreads();
     }
@@ -868,6 +883,7 @@ struct CsbKernel {
             } else if (d.I == J && d.K == J) {
                 ldD(wk + Lay::O_MD + (J & 1) * BS, lr, lq, B[s]);  // W_JJ = Winv_JJ D_J
             }
+            SQPH_SLOT_FENCE();
         }
         // look-ahead: the next diagonal block, updated now (with my own L_J+1,J) and handed to the eliminating wavefront
         wave_fence();
@@ -925,6 +941,7 @@ struct CsbKernel {
 #pragma unroll
                 for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
             }
+            SQPH_SLOT_FENCE();
         }
     }
 #define SQPH_CSB_SWITCH(wave, CALL) \
@@ -977,17 +994,23 @@ struct CsbKernel {
         if (wave == DW) MS::diag_block(wk + Lay::O_MD, wk + Lay::O_TB, sj, flag, l);
 #pragma unroll 1
         for (int J = 0; J < NB; J++) {
+            // the lane's coordinates are derived again in every step: as loop invariants the LDS addresses of all 14 slots' operands
+            // (~40 words) were hoisted out of this loop, spilled, and reloaded from scratch memory in front of every block product
+            int lj = l, wj = wave;
+            SQPH_OPAQUE_V(lj);
+            SQPH_OPAQUE_S(wj);
+            const int lrj = lj & 15, lqj = lj >> 4;
             __syncthreads();
             SQPH_FTICK(12)
-            elim_A(wave, J, B, wk, lr, lq);
+            elim_A(wj, J, B, wk, lrj, lqj);
             SQPH_FTICK(13)
             if (J == NB - 1) break;
             __syncthreads();
             SQPH_FTICK(14)
-            if (wave == DW)
-                MS::diag_block(wk + Lay::O_MD + ((J + 1) & 1) * BS, wk + Lay::O_TB + ((J + 1) & 1) * BS, sj + 16 * (J + 1), flag, l);
+            if (wj == DW)
+                MS::diag_block(wk + Lay::O_MD + ((J + 1) & 1) * BS, wk + Lay::O_TB + ((J + 1) & 1) * BS, sj + 16 * (J + 1), flag, lj);
             else
-                elim_B(wave, J, B, wk, sj, lr, lq);
+                elim_B(wj, J, B, wk, sj, lrj, lqj);
             SQPH_FTICK(15)
         }
         __syncthreads();
@@ -1399,6 +1422,7 @@ struct CsbKernel {
             upv[im] = (T)gu[im];
         }
         __syncthreads();
+        bool rho_differs = false;  // against the vector the resident factor was built with (MODE_SAME_MATRICES)
         if (mode & (MODE_SETUP | MODE_UPDATE)) {
             rho_s = a.rho0;
             if (lead) {
@@ -1409,6 +1433,7 @@ struct CsbKernel {
                 else if (up - lo < a.eq_tol)
                     ctype = SQPH_EQUALITY_CONSTRAINT;
                 const T rho = rho_for_type<T>(ctype, rho_s, a.rho_min, a.rho_eq_factor);
+                rho_differs = !(rho == srho[im]);
                 rhov[im] = rho;
                 rinvv[im] = T(1) / rho;
                 sct[im] = ctype;
@@ -1434,6 +1459,22 @@ struct CsbKernel {
 #pragma unroll
         for (int s = 0; s <= NB; s++) B[s] = sqph_acc4{{0, 0, 0, 0}};  // (defined on every path: the slots a wavefront does not own are never touched)
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
+        if ((mode & MODE_SAME_MATRICES) && (mode & (MODE_SETUP | MODE_UPDATE)) && !(mode & MODE_REFACTOR) &&
+            info.status != SQPH_NUMERICAL_ISSUES && info.status != SQPH_UNINITIALIZED) {  // (a failed set-up left no valid factor)
+            // sqph_setup_solve_reuse_csr (the SQP second-order correction re-solves with new bounds only, src/sqp.cpp:244-276, TODO
+            // :273): P and A are those of the resident factor — which is also the factor this set-up would build unless some row's
+            // freshly classified rho differs from the vector it was built with (workgroup-wide OR through one LDS word)
+            T *same = lds + Lay::o_flag + 2;
+            if (t == 0) *same = T(0);
+            __syncthreads();
+            if (rho_differs) *same = T(1);
+            __syncthreads();
+            if (*same == T(0)) {
+                need_factor = false;
+                info.status = SQPH_UNSOLVED;  // qp.cpp:39-43
+            }
+            __syncthreads();
+        }
         bool solving = false;
         bool state_dirty = (mode & MODE_SETUP) != 0;
         if (!need_factor) {

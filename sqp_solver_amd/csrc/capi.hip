@@ -115,7 +115,8 @@ __global__ void csr_expand(int batch, int n, int m, const int *__restrict__ rowp
 
 // Compressed-column P -> dense column-major (sqph_*_csr_sp): one thread per (QP, column); `dst` must be zero-filled.
 // bad: bit 0 = column pointers malformed, bit 1 = row index out of range, bit 2 = rows of a column not strictly increasing,
-// bit 3 = the pattern is not symmetric (entry (i, j) without (j, i): a triangle was passed instead of the full matrix).
+// bit 3 = the pattern is not symmetric (entry (i, j) without (j, i): a triangle was passed instead of the full matrix),
+// bit 4 = the values are not (P_ij != P_ji bit for bit: the routes that read column i as row i would differ from the dense ones).
 template <typename TIN>
 __global__ void csc_expand_P(int batch, int n, const int *__restrict__ colptr, const int *__restrict__ rowind, const TIN *__restrict__ val,
                              long long s_colptr, long long s_rowind, long long s_val, long long nnz_cap, TIN *__restrict__ dst,
@@ -141,7 +142,11 @@ __global__ void csc_expand_P(int batch, int n, const int *__restrict__ colptr, c
             if (lo >= 0 && hi <= nnz_cap) {
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1, r = ri[mid];
-                    if (r == j) { found = true; break; }
+                    if (r == j) {
+                        found = true;
+                        if (!(v[mid] == v[e])) atomicOr(bad, 16);  // P_ij != P_ji: the in-place route reads column i as row i
+                        break;
+                    }
                     if (r < j) lo = mid + 1;
                     else hi = mid;
                 }
@@ -1010,7 +1015,8 @@ static int place_sparse_P(sqph_solver *s, int batch, const SparsePDev &dv, bool 
     if (bad)
         SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: malformed sparse P (%s)", what,
                   (bad & 1) ? "column pointers not monotone" : (bad & 2) ? "row index out of range"
-                  : (bad & 4) ? "row indices of a column not strictly increasing" : "pattern not symmetric: the full matrix is expected, not a triangle");
+                  : (bad & 4) ? "row indices of a column not strictly increasing"
+                  : (bad & 8) ? "pattern not symmetric: the full matrix is expected, not a triangle" : "values not symmetric: P(i,j) != P(j,i)");
     if (expand) {
         d->P = s->cP;
         d->stride_P = shared ? 0 : (long long)(n * n);
@@ -1022,7 +1028,19 @@ static int place_sparse_P(sqph_solver *s, int batch, const SparsePDev &dv, bool 
 }
 
 // CSR entry points: expand A on the device, then the dense path.
+static int run_csr_impl(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what, const sqph_csc_P *sp);
 int run_csr(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what, const sqph_csc_P *sp = nullptr) {
+    const int rc = run_csr_impl(s, c, mode, what, sp);
+    if (rc != SQPH_OK && s && c && c->memspace == SQPH_HOST) {
+        // an error return ends the borrow of the caller's pageable host arrays like a success does: asynchronous copies out of
+        // them may have been enqueued before the failing check (the error text set by the failing call is kept)
+        DeviceGuard g(s->device);
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+static int run_csr_impl(sqph_solver *s, const sqph_csr_batch *c, int mode, const char *what, const sqph_csc_P *sp) {
     if (!s) return SQPH_ERR_INVALID;
     if (!c) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: qp is null", what);
     if (c->batch < 0 || c->batch > s->cap) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: batch %d exceeds capacity %d", what, c->batch, s->cap);
@@ -1256,10 +1274,11 @@ struct sqph_gather {
     long long total = 0;
     double *x = nullptr, *y = nullptr;
     sqph_info *info = nullptr;
-    hipStream_t stream = nullptr;      // (kept for ABI users of the first version: the receive stream of the root's own device)
-    std::vector<hipStream_t> rstream;  // the root's side of RCCL receives, ONE STREAM PER SOURCE DEVICE: receives from different peers
-                                       // are independent streams of the root (seven xGMI links in parallel), not seven back-to-back
-                                       // receives on one stream
+    hipStream_t stream = nullptr;      // the root's side of the RCCL receives: ONE stream.  All ncclRecv of a post are issued inside one
+                                       // ncclGroupStart / End on the root's communicator: RCCL fuses a group's operations per
+                                       // communicator into ONE kernel (its channels drive the seven xGMI links concurrently) launched
+                                       // on the first stream it saw and makes any other stream wait for it — per-peer receive
+                                       // streams (round 5) bought nothing and cost seven event records per post
     std::mutex mu;                     // shards post from their own host threads (MultiGpuBatchQPSolver::run_host)
     std::vector<hipEvent_t> pending;   // one per posted copy, recorded on the stream it was enqueued on  (guarded by mu)
     std::vector<int> pending_dev;      //                                                                  (guarded by mu)
@@ -1285,9 +1304,7 @@ int sqph_gather_create_ex(sqph_gather **out, int device, int n, int m, long long
     if (e == hipSuccess) e = hipMalloc((void **)&g->y, (size_t)total * mm * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&g->info, (size_t)total * sizeof(sqph_info));
     if (e == hipSuccess) {
-        g->rstream.assign((size_t)ndev, nullptr);
-        for (int d = 0; d < ndev && e == hipSuccess; d++) e = hipStreamCreateWithFlags(&g->rstream[(size_t)d], hipStreamNonBlocking);
-        if (e == hipSuccess) g->stream = g->rstream[(size_t)device];
+        e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     }
     if (e != hipSuccess) {
         g_err = std::string("sqph_gather_create: ") + hipGetErrorString(e);
@@ -1307,8 +1324,7 @@ void sqph_gather_destroy(sqph_gather *g) {
         (void)hipEventDestroy(g->pending[i]);
     }
     DeviceGuard dg(g->device);
-    for (hipStream_t st : g->rstream)
-        if (st) (void)hipStreamDestroy(st);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
     if (g->x) (void)hipFree(g->x);
     if (g->y) (void)hipFree(g->y);
     if (g->info) (void)hipFree(g->info);
@@ -1318,8 +1334,12 @@ void sqph_gather_destroy(sqph_gather *g) {
 const char *sqph_gather_transport(const sqph_gather *g) { return g ? g->transport : "none"; }
 
 // One RCCL group for ALL shards of a call (producer sides on the producers' streams behind their solves, root sides on the root's
-// per-peer receive streams), then one event per stream.  Shards on the root's own device — and everything where RCCL cannot be had —
-// are device-to-device / peer copies on the producer's stream.
+// ONE receive stream), then one event per producer stream and one on the root's.  Shards on the root's own device — and everything
+// where RCCL cannot be had — are device-to-device / peer copies on the producer's stream.
+// Ordering: posts are serialised by the process-wide RcclApi::mu (a communicator must not be entered by two host threads at once), so
+// the groups of concurrent posts reach the root's receive stream one after the other, each complete; on a stream RCCL executes groups in
+// issue order, and every sender's stream orders its send behind its own solve.  Nothing else is needed for correctness: the gather
+// buffers of two posts never overlap (disjoint [offset, offset + count) ranges, checked above per shard).
 int sqph_gather_post_many(sqph_gather *g, sqph_solver *const *srcs, const long long *offsets, const int *counts, int k) {
     if (!g || !srcs || !offsets || !counts || k < 0) return SQPH_ERR_INVALID;
     for (int i = 0; i < k; i++) {
@@ -1348,7 +1368,7 @@ int sqph_gather_post_many(sqph_gather *g, sqph_solver *const *srcs, const long l
                 const size_t c = (size_t)counts[i];
                 const bool eligible = c > 0 && (src->device != g->device || (g->flags & SQPH_GATHER_RCCL_ALWAYS)) && src->device < R.ndev && g->device < R.ndev;
                 if (!eligible) continue;
-                hipStream_t rs = g->rstream[(size_t)src->device];
+                hipStream_t rs = g->stream;
                 const auto xfer = [&](const void *from, void *to, size_t elems, ncclDataType_t dt) {
                     if (r == ncclSuccess) r = R.Send(from, elems, dt, g->device, R.comms[src->device], src->stream);
                     if (r == ncclSuccess) r = R.Recv(to, elems, dt, src->device, R.comms[g->device], rs);
@@ -1393,14 +1413,14 @@ int sqph_gather_post_many(sqph_gather *g, sqph_solver *const *srcs, const long l
         const size_t c = (size_t)counts[i];
         if (!c) continue;
         const bool cross = src->device != g->device;
-        if (via[(size_t)i]) {
+        if (via[(size_t)i] && !any_rccl) {  // ONE event on the root's receive stream covers the whole group
             any_rccl = true;
             DeviceGuard dr(g->device);
             hipEvent_t ev_root = nullptr;
             SQPH_HIP_POST(src, hipEventCreateWithFlags(&ev_root, hipEventDisableTiming));
             evs.push_back(ev_root);
             evdev.push_back(g->device);
-            SQPH_HIP_POST(src, hipEventRecord(ev_root, g->rstream[(size_t)src->device]));
+            SQPH_HIP_POST(src, hipEventRecord(ev_root, g->stream));
         }
         DeviceGuard dg(src->device);
         if (!via[(size_t)i]) {
@@ -1490,6 +1510,14 @@ int sqph_gather_fetch(sqph_gather *g, int dtype, void *x, void *y, sqph_info *in
 }  // extern "C"
 
 extern "C" {
+int sqph_setup_solve_reuse_csr(sqph_solver *s, const sqph_csr_batch *qp) {
+    return run_csr(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE | sqph::MODE_SAME_MATRICES, "sqph_setup_solve_reuse_csr");
+}
+int sqph_setup_solve_reuse_csr_sp(sqph_solver *s, const sqph_csr_batch *qp, const sqph_csc_P *P) {
+    if (!s) return SQPH_ERR_INVALID;
+    if (!P) SQPH_FAIL(s, SQPH_ERR_INVALID, "sqph_setup_solve_reuse_csr_sp: P is null");
+    return run_csr(s, qp, sqph::MODE_SETUP | sqph::MODE_SOLVE | sqph::MODE_SAME_MATRICES, "sqph_setup_solve_reuse_csr_sp", P);
+}
 int sqph_setup_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s, qp, sqph::MODE_SETUP, "sqph_setup_csr"); }
 int sqph_update_qp_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s, qp, sqph::MODE_UPDATE, "sqph_update_qp_csr"); }
 int sqph_solve_csr(sqph_solver *s, const sqph_csr_batch *qp) { return run_csr(s, qp, sqph::MODE_SOLVE, "sqph_solve_csr"); }

@@ -362,6 +362,10 @@ class QPSolverBatch:
     def setup_solve_csr(self, P, q, rowptr, colind, val, l, u, colmajor=False):
         self._call_csr(self._L.sqph_setup_solve_csr, "sqph_setup_solve_csr", P, q, rowptr, colind, val, l, u, colmajor)
 
+    def setup_solve_reuse_csr(self, P, q, rowptr, colind, val, l, u, colmajor=False):
+        """setup()+solve() with the P, A of the previous set-up (sqph_setup_solve_reuse_csr: the SOC re-solve of a sparse subproblem)."""
+        self._call_csr(self._L.sqph_setup_solve_reuse_csr, "sqph_setup_solve_reuse_csr", P, q, rowptr, colind, val, l, u, colmajor)
+
     def update_solve_csr(self, P, q, rowptr, colind, val, l, u, colmajor=False):
         """update_qp(); solve() in one launch with the iterates kept (sqph_update_solve_csr): successive sparse QPs, warm-started."""
         self._call_csr(self._L.sqph_update_solve_csr, "sqph_update_solve_csr", P, q, rowptr, colind, val, l, u, colmajor)

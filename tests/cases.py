@@ -252,7 +252,7 @@ def parity_termination(make, n, m, batch, seed=5, adaptive=False, sqp_settings=F
     rec = {"n": n, "m": m, "batch": batch, "seed": seed, "adaptive": bool(adaptive), "sqp_settings": bool(sqp_settings),
            "kw": {k: str(v) for k, v in kw.items()}, "excused": 0, "widened": 0, "diag_compared": 0, "diag_unstable": 0}
     HATCH_COUNTS.append(rec)
-    hatch_cap = max(1, int(batch * max_hatch_frac))
+    hatch_cap = int(batch * max_hatch_frac)  # no floor: a batch too small for its fraction to reach one QP gets no hatch at all
     P, q, A, l, u = random_qp_batch(batch, n, m, seed=seed)
     s = make(n, m, batch, **kw)
     st = s.settings
@@ -471,6 +471,55 @@ def soc_factor_reuse(make, n=8, m=12, batch=6, **kw):
             assert (info.rho_updates >= info2.rho_updates + 1).all()  # the counter accumulates over setups (qp.cpp:309)
             xo, yo, zo, io = oracle.solve_batch(P, q2, A, l2, u2, oracle_settings(s.settings))
             assert relerr(x, xo) < TOL_F64 and relerr1(y, yo) < TOL_F64
+
+
+def soc_factor_reuse_csr(make, n=200, m=400, batch=3, density=0.05, sparse_P=False, **kw):
+    """soc_factor_reuse on the sparse route (sqph_setup_solve_reuse_csr / _csr_sp): bit-identical to a plain sqph_setup_solve_csr of
+    the second problem — with the factor kept resident (reused where rho did not move; adaptive rho in the first solve leaves some QPs
+    with another rho vector: those refactor) and without (the hint is dropped by the host) — and equal to the oracle."""
+    from sqp_solver_amd.problems import random_csr_qp_batch
+
+    P, q, rp, ci, v, l, u, A = random_csr_qp_batch(batch, n, m, density=density, seed=17)
+    Parg = P
+    if sparse_P:
+        P = sparse_spd(batch, n, 0.1, seed=19)
+        Parg = dense_to_csr(P)  # (symmetric: its CSR arrays are its compressed columns)
+    q2, l2, u2 = q + 0.3, l - 0.2, u + 0.05
+    for keep in (True, False):
+        for adaptive in (0, 1):
+            s = make(n, m, batch, keep_factor=keep, **kw)
+            s.settings.max_iter, s.settings.check_termination = 60, 0
+            s.settings.adaptive_rho, s.settings.adaptive_rho_interval = adaptive, 20
+            s.setup_solve_csr(Parg, q, rp, ci, v, l, u)
+            k1 = s.kernel_name() if hasattr(s, "kernel_name") else ""
+            s.setup_solve_reuse_csr(Parg, q2, rp, ci, v, l2, u2)
+            x, y, z, info = s.solution()
+            s2 = make(n, m, batch, **kw)
+            s2.settings.max_iter, s2.settings.check_termination = 60, 0
+            s2.settings.adaptive_rho, s2.settings.adaptive_rho_interval = adaptive, 20
+            s2.setup_solve_csr(Parg, q2, rp, ci, v, l2, u2)
+            x2, y2, z2, info2 = s2.solution()
+            assert np.array_equal(x, x2) and np.array_equal(y, y2) and np.array_equal(z, z2), (keep, adaptive, k1)
+            assert (info.iter == info2.iter).all() and (info.status == info2.status).all()
+            assert (info.rho_updates >= info2.rho_updates + 1).all()
+            xo, yo, zo, io = oracle.solve_batch(P, q2, A, l2, u2, oracle_settings(s.settings))
+            assert relerr(x, xo) < TOL_F64 and relerr1(y, yo) < TOL_F64
+    # a QP whose set-up failed (indefinite S) refactors on the reuse call and stays NUMERICAL_ISSUES; the others are unaffected
+    if not sparse_P:
+        Pb = P.copy()
+        Pb[0] = -100.0 * np.eye(n)
+        s = make(n, m, batch, keep_factor=True, **kw)
+        s.settings.max_iter, s.settings.check_termination = 40, 0
+        s.setup_solve_csr(Pb, q, rp, ci, v, l, u)
+        assert s.solution()[3].status[0] == 3
+        s.setup_solve_reuse_csr(Pb, q2, rp, ci, v, l2, u2)
+        x, y, z, info = s.solution()
+        s2 = make(n, m, batch, **kw)
+        s2.settings.max_iter, s2.settings.check_termination = 40, 0
+        s2.setup_solve_csr(Pb, q2, rp, ci, v, l2, u2)
+        x2, y2, z2, info2 = s2.solution()
+        assert info.status[0] == 3 and (info.status == info2.status).all() and (info.iter[1:] == info2.iter[1:]).all()
+        assert np.array_equal(x, x2) and np.array_equal(y, y2) and np.array_equal(z, z2)
 
 
 def soc_reuse_after_failed_setup(make, n=8, m=12, batch=4, **kw):
@@ -919,6 +968,12 @@ def csr_sparse_P(make):
     tri = dense_to_csr(np.triu(sparse_spd(B, n, 0.2, seed=13)))  # the upper triangle alone (another solver's convention) is rejected
     with pytest.raises(SqphError, match="not symmetric"):
         s.setup_solve_csr(tri, q, rp, ci, v, l, u)
+    # a symmetric pattern whose mirror VALUES differ: column i is read as row i on the in-place route, so it is rejected as well
+    bad = pv.copy()
+    e_off = next(e for j in range(n) for e in range(cp[1, j], cp[1, j + 1]) if ri[1, e] != j)  # the first off-diagonal entry of QP 1
+    bad[1, e_off] *= 1.0 + 2.0 ** -40
+    with pytest.raises(SqphError, match="values not symmetric"):
+        s.setup_solve_csr((cp, ri, bad), q, rp, ci, v, l, u)
     s.setup_solve_csr((cp, ri, pv), q, rp, ci, v, l, u)  # the handle is usable afterwards
     assert (s.info().status != UNINITIALIZED).all()
 

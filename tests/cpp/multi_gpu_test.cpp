@@ -42,6 +42,8 @@ static void split_arithmetic() {
     CHECK(lo == 3 * 8192 && hi == 4 * 8192);
 }
 
+static int g_cross_device_rccl_runs = 0;  // sharded solves whose gather crossed devices over RCCL (0 on a one-GPU box)
+
 struct Lcg {
     unsigned long long s;
     double uni() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (double)(s >> 11) / 9007199254740992.0; }
@@ -144,6 +146,9 @@ static void sharded_vs_single(int n, int m, int B) {
         bool distinct = true;
         for (size_t i = 0; i < devices.size(); i++) distinct = distinct && devices[i] == (int)i;
         if (pass || (distinct && G > 1)) CHECK(!std::strcmp(multi.gather_transport(), "rccl"));
+        // the first box with two devices tests the real path without edits: placements {0, 1, ...} (distinct devices) MUST have moved
+        // their records over RCCL between devices — asserted above — with the bit-identity checks of this loop behind them
+        if (distinct && G > 1 && !std::strcmp(multi.gather_transport(), "rccl")) g_cross_device_rccl_runs++;
         printf("multi-GPU n=%d m=%d batch=%d over %d shard(s) on %d device(s), gather transport %s: gathered records bit-identical to the single-device solve\n", n, m, B,
                multi.num_devices(), ndev < G ? ndev : G, multi.gather_transport());
     }
@@ -197,6 +202,8 @@ int main(int argc, char **argv) {
         fprintf(stderr, "exception: %s\n", e.what());
         return 2;
     }
-    printf("multi_gpu_test: all passed\n");
+    // with >= 2 devices the cross-device RCCL gather MUST have run (both passes x both shapes x every G in 2..ndev)
+    if (sqph_device_count() >= 2) CHECK(g_cross_device_rccl_runs >= 4 * (sqph_device_count() - 1));
+    printf("multi_gpu_test: all passed (%d device(s); %d sharded solves gathered across devices over RCCL)\n", sqph_device_count(), g_cross_device_rccl_runs);
     return 0;
 }

@@ -187,6 +187,9 @@ class SimSolverBatch:
     def update_solve_csr(self, P, q, rp, ci, v, l, u):
         self._run(MODE_UPDATE | MODE_SOLVE, P, q, None, l, u, csr=(rp, ci, v))
 
+    def setup_solve_reuse_csr(self, P, q, rp, ci, v, l, u):
+        self._run(MODE_SETUP | MODE_SOLVE | MODE_SAME_MATRICES, P, q, None, l, u, csr=(rp, ci, v))
+
     def setup_solve_csr(self, P, q, rp, ci, v, l, u):
         self._run(MODE_SETUP | MODE_SOLVE, P, q, None, l, u, csr=(rp, ci, v))
 

@@ -23,7 +23,7 @@ REFDIR = os.path.join(CPP, "_ref")
 REFERENCE = "/root/reference"
 INC = ["-I" + os.path.join(ROOT, "include", "sqp_hip", "compat"), "-I" + os.path.join(CPP, "eigen_stub")]  # (the stand-ins: Eigen/Dense, Eigen/Sparse,
 # Eigen/Eigenvalues, unsupported/Eigen/AutoDiff)
-OWN = ["qp_dropin_test", "qp_dropin_legacy_test", "sqp_dropin_test"]
+OWN = ["qp_dropin_test", "qp_dropin_legacy_test", "qp_dropin_legacy_sparse_test", "sqp_dropin_test"]
 REF = {  # binary -> reference sources (relative to /root/reference)
     "ref_qp_solver_test": ["tests/qp_solver_test.cpp", "tests/test_main.cpp"],
     "ref_legacy_qp_solver_test": ["tests/unsupported/qp_solver_test.cpp", "tests/test_main.cpp"],

@@ -216,6 +216,33 @@ def test_csr_update_solve(n, m, density):
     cases.csr_update_solve(make_gpu, n=n, m=m, density=density)
 
 
+@pytest.mark.parametrize("n,m,density,sparse_P", [(200, 400, 0.05, False), (200, 400, 0.05, True), (30, 45, 0.3, False), (100, 180, 0.08, False)])
+def test_csr_setup_solve_reuse(n, m, density, sparse_P):
+    """sqph_setup_solve_reuse_csr / _csr_sp (the SOC re-solve of a sparse subproblem, src/sqp.cpp:244-276, TODO :273): bit-identical to
+    sqph_setup_solve_csr on the block-row kernel (nb13 / nb9) and on the expand + dense route ((30, 45): register-tiled kernel)"""
+    cases.soc_factor_reuse_csr(make_gpu, n=n, m=m, batch=3, density=density, sparse_P=sparse_P)
+    if (n, m) == (200, 400) and not sparse_P:
+        # the fast path is taken, not just harmless: with one ADMM iteration per QP a call is its set-up, and the reuse call skips it
+        from sqp_solver_amd.problems import random_csr_qp_batch
+
+        B = 512
+        P, q, rp, ci, v, l, u, A = random_csr_qp_batch(8, n, m, density=density, seed=3)
+        rep = lambda a: np.concatenate([a] * (B // 8))  # noqa: E731
+        args = [rep(a) for a in (P, q, rp, ci, v, l, u)]
+        s = make_gpu(n, m, B, keep_factor=True)
+        s.settings.max_iter, s.settings.check_termination = 1, 0
+        s.setup_solve_csr(*args)
+        s.enable_timing(True)
+        for _ in range(3):
+            s.setup_solve_csr(*args)
+        for _ in range(3):
+            s.setup_solve_reuse_csr(*args)
+        ms = s.collect_kernel_ms()
+        full, reuse = min(ms[-6:-3]), min(ms[-3:])
+        print("setup_solve_csr %.3f ms, setup_solve_reuse_csr %.3f ms (512 x (200, 400), 1 iteration)" % (full, reuse))
+        assert reuse < 0.6 * full, (full, reuse)
+
+
 def test_csr_sparse_P():
     """sqph_*_csr_sp: P in compressed-column form, bit-identical to the dense-P twin on every CSR route (block-row kernel, expand +
     dense), the stateful calls, the reference's sparse test problem, malformed structures"""
@@ -522,6 +549,43 @@ def test_full_size_fixed_iters_c2():
     assert (info.iter == 201).all()
 
 
+def test_full_size_one_launch_c3_65536():
+    """The headline workload itself (BASELINE configs[2]: 65,536 x (n=50, m=100), 200 fixed iterations, ONE launch — 4.1 GB of inputs,
+    1.9 GB of state, per-QP offsets up to 65,535 x 5,000 doubles): (1) the reversed batch reverses the results bit for bit (the
+    last QP of one launch is the first of the other: any 32-bit offset overflow or cross-QP coupling breaks this); (2) a 256-QP
+    sample drawn from the LAST 4,096 QPs of the launch (the largest offsets) agrees with the oracle; (3) every QP ran 200 iterations."""
+    import torch
+
+    from sqp_solver_amd.problems import random_qp_batch_torch
+
+    B, n, m = 65536, 50, 100
+    dev = torch.device("cuda:0")
+    P, q, A_cm, l, u = random_qp_batch_torch(B, n, m, seed=20250228 + 3, dtype=torch.float64, device=dev)
+    s = make_gpu(n, m, B)
+    s.settings.max_iter = 200
+    s.settings.check_termination = 0
+    s.setup_solve(P, q, A_cm, l, u, colmajor=True)
+    assert s.kernel_name().startswith("wg2_16x8"), s.kernel_name()
+    x, y, z, info = s.solution()
+    assert (info.iter == 201).all() and (info.status == cases.MAX_ITER_EXCEEDED).all()
+    assert np.isfinite(x).all() and np.isfinite(y).all()
+    idx = np.sort(np.random.default_rng(7).choice(np.arange(B - 4096, B), size=256, replace=False))
+    ti = torch.from_numpy(idx).to(dev)
+    h = lambda t: t[ti].cpu().numpy()  # noqa: E731
+    xo, yo, zo, io = oracle.solve_batch(h(P).transpose(0, 2, 1), h(q), h(A_cm).transpose(0, 2, 1), h(l), h(u),
+                                        cases.oracle_settings(s.settings), nthreads=0)
+    assert cases.relerr(x[idx], xo) < cases.TOL_F64 and cases.relerr(y[idx], yo) < cases.TOL_F64 and cases.relerr(z[idx], zo) < cases.TOL_F64
+    assert (info.iter[idx] == io["iter"]).all() and (info.status[idx] == io["status"]).all()
+    rev = lambda t: torch.flip(t, dims=[0]).contiguous()  # noqa: E731
+    Pr, qr, Ar, lr, ur = rev(P), rev(q), rev(A_cm), rev(l), rev(u)
+    del P, A_cm
+    s.setup_solve(Pr, qr, Ar, lr, ur, colmajor=True)
+    x2, y2, z2, info2 = s.solution()
+    assert np.array_equal(x2[::-1], x) and np.array_equal(y2[::-1], y) and np.array_equal(z2[::-1], z)
+    assert np.array_equal(info2.iter[::-1], info.iter)
+    s.close()
+
+
 def test_api_misuse_errors():
     from sqp_solver_amd import QPSolverBatch, SqphError
 
@@ -660,7 +724,7 @@ class _CsrFacade:
     def update_qp(self, *a): self._csr(self._s.update_qp_csr, *a)
     def solve(self, *a): self._csr(self._s.solve_csr, *a)
     def setup_solve(self, *a): self._csr(self._s.setup_solve_csr, *a)
-    def setup_solve_reuse(self, *a): self._csr(self._s.setup_solve_csr, *a)  # no CSR variant of the reuse call: a plain fused call
+    def setup_solve_reuse(self, *a): self._csr(self._s.setup_solve_reuse_csr, *a)
     def set_state(self, *a): self._s.set_state(*a)
     def solution(self): return self._s.solution()
     def kernel_name(self): return self._s.kernel_name()

@@ -192,6 +192,18 @@ def test_csrb_kernel_adaptive_rho_refactors_in_kernel():
     assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64
 
 
+@pytest.mark.parametrize("n,m,density,sparse_P", [(30, 44, 0.2, False), (40, 60, 0.15, True)], ids=["nb2", "nb3_sp"])
+def test_csrb_kernel_setup_solve_reuse(n, m, density, sparse_P):
+    """MODE_SAME_MATRICES on the block-row kernel (sqph_setup_solve_reuse_csr / _csr_sp): the resident blocks are loaded instead of
+    factorised where the freshly classified rho vector equals the stored one; a failed set-up refactors"""
+    cases.soc_factor_reuse_csr(make_csrb, n=n, m=m, batch=2, density=density, sparse_P=sparse_P)
+
+
+def test_csr_kernel_setup_solve_reuse():
+    """... and on the 32 x 32 lane-grid sparse kernel"""
+    cases.soc_factor_reuse_csr(make_csr, n=14, m=24, batch=2, density=0.3)
+
+
 def test_csrb_kernel_stateful_calls():
     cases.fused_then_solve(make_csrb_dense_A, n=33, m=40, batch=2)
     cases.warm_start_and_resolve(make_csrb_dense_A, n=20, m=30)
@@ -258,7 +270,10 @@ def test_wg_tall_shapes(n, m):
         cases.parity_termination(mk, n, m, 2)
         # adaptive rho on these constraint-heavy QPs drives rho up: iterates stay inside the bar, the absolute floor of the reported
         # residuals (calibrated on m = 2n problems) does not apply
-        cases.parity_termination(mk, n, m, 2, adaptive=True, diagnostics=False)
+        # (n < 20: a batch of 20 with an explicit 15 % cap on the widened bar instead of the old one-QP floor of a batch of 2 —
+        # with m = 14 n .. 15 n the adapted rho puts 1 of 20 QPs at (16, 224) and 2 of 20 at (10, 150) at 10x their own fp64 noise
+        # floor; counted in the session summary like every hatch)
+        cases.parity_termination(mk, n, m, 20 if n < 20 else 2, adaptive=True, diagnostics=False, **({"max_hatch_frac": 0.15} if n < 20 else {}))
         cases.fused_then_solve(mk, n, m, 2, adaptive=False)  # (adaptive rho on these constraint-heavy QPs sits at the fp64 noise floor)
 
 
