@@ -14,7 +14,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 # kernel's two-chain one: admm_lane_kernel.h)
 FLAGS += os.environ.get("SQPH_HIPCC_FLAGS", "").split()
 # flags of single translation units (csrb.hip says why)
-UNIT_FLAGS = {"csrb.hip": ["-mllvm", "-simplifycfg-sink-common=false"], "csrb_sp.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
+# -structurizecfg-skip-uniform-regions: the block-row kernel's set-up is wave-uniform control flow around 14 eight-register blocks;
+# structurized, every conditional block update left an old and a new copy of ALL blocks live (224 of 256 VGPRs, 56 v_mov_b64 per
+# elimination step and slot, 160 spilled registers); with scalar branches left as they are the same source allocates without a spill
+CSB_FLAGS = ["-mllvm", "-simplifycfg-sink-common=false", "-mllvm", "-structurizecfg-skip-uniform-regions"]
+UNIT_FLAGS = {"csrb.hip": CSB_FLAGS, "csrb_sp.hip": CSB_FLAGS}
 
 
 def sources():

@@ -20,6 +20,8 @@
 // Requirements checked by the host: n <= 16 NB, m <= 512, CSR rows sorted by column without duplicates, everything within LDS.
 // A QP whose rows (columns) need more than KR entries per lane takes the LDS form of that sparse product (block-uniform branch).
 #pragma once
+#include <type_traits>
+
 #include "admm_csr_kernel.h"
 
 #ifndef SQPH_CSB_KR
@@ -106,6 +108,19 @@ struct CsbLayout {
     }
 };
 
+// A 16 x 16 block of W in the accumulator layout (lane l: rows (l >> 4) + 4 e of column l & 15).  On the device the four doubles are
+// ONE 256-bit vector value — the register tuple the matrix instruction reads and writes in place; as four separate doubles
+// (sqph_acc4) every conditional block update of the set-up left the allocator with an old and a new copy of all 14 blocks: 224 of
+// the 256 VGPRs, 56 v_mov_b64 per elimination step and four more for every slot whose condition was false.
+#ifdef SQPH_SIM
+typedef sqph_acc4 csb_blk;
+#else
+struct csb_blk {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 v;
+};
+__device__ __forceinline__ void mfma16(double a, double b, csb_blk &c) { c.v = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c.v, 0, 0, 0); }
+#endif
 // reduce-scatter steps over the four 16-lane rows of a wavefront: one swap instruction per 32-bit half pairs two values
 //   swap_reduce32(a, b): lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l]
 //   swap_reduce16(a, b): even rows get a[row] + a[row + 1], odd rows get b[row - 1] + b[row]
@@ -131,7 +146,7 @@ __device__ __forceinline__ double swap_reduce16(double a, double b) {
 }
 // acc + y(lane N .. N + 3 of my 16-lane row) * b[0 .. 3]: four v_fmac_f64 with the row_newbcast control behind ONE pair of wait states
 template <int N>
-__device__ __forceinline__ double fmac4_bcast16(double acc, double y, const sqph_acc4 &b) {
+__device__ __forceinline__ double fmac4_bcast16(double acc, double y, const csb_blk &b) {
 #ifdef SQPH_SIM
     acc = __builtin_fma(bcast16<N>(y), b.v[0], acc);
     acc = __builtin_fma(bcast16<N + 1>(y), b.v[1], acc);
@@ -162,15 +177,14 @@ struct CsbKernel {
     static constexpr int KR = SQPH_CSB_KR;   // entries of A per lane and orientation held in registers
     static_assert(NH <= DW && NB >= 1 && NB <= 14 && (KR % 2) == 0, "block rows pair up on seven wavefronts");
 
-    // block rows and register slots of wavefront W: slots 0 .. I1 hold row I1 = NB - 1 - W, slots I1 + 1 .. I1 + 1 + I0 row I0 = W
+    // block rows and register slots of wavefront W: slot K <= I1 holds block (I1, K) of row I1 = NB - 1 - W, slot NB - K >= I1 + 1 block
+    // (I0, K) of row I0 = W (the second row is stored from the top down: the block column of a slot is then a compile-time function of
+    // the slot — K = s or NB - s — whatever the wavefront, and a step of the set-up reaches "block (row, K)" through a static index)
     template <int W>
     struct Own {
         static constexpr bool any = W < NH;
         static constexpr int I1 = NB - 1 - W, I0 = W;
         static constexpr bool has0 = any && I0 < I1;
-        static constexpr int nslots = any ? (I1 + 1) + (has0 ? I0 + 1 : 0) : 0;
-        static constexpr int row(int s) { return s <= I1 ? I1 : I0; }
-        static constexpr int col(int s) { return s <= I1 ? s : s - I1 - 1; }
     };
 
     // the same map with the wavefront index a run-time scalar: the set-up is ONE code path for all wavefronts (seven specialised
@@ -181,15 +195,47 @@ struct CsbKernel {
         bool valid;
     };
     static __device__ __forceinline__ Slot slot_of(int W, int s) {
-        const int I1 = NB - 1 - W, n1 = I1 + 1;
-        const bool has0 = W < I1;
+        const int I1 = NB - 1 - W;
         Slot d;
-        d.valid = W < NH && (s < n1 || (has0 && s < n1 + W + 1));
-        d.I = s < n1 ? I1 : W;
-        d.K = s < n1 ? s : s - n1;
+        d.valid = W < NH && (s <= I1 || W < I1);
+        d.I = s <= I1 ? I1 : W;
+        d.K = s <= I1 ? s : NB - s;
         return d;
     }
+    // f(integral_constant<int, K>) for K = LO, LO + 1, ... HI while it returns true (an unrolled loop over compile-time indices that can
+    // be left early: one taken branch ends it)
+    template <int LO, int HI, typename F>
+    static __device__ __forceinline__ void static_while(F &&f) {
+        if constexpr (LO <= HI) {
+            if (f(std::integral_constant<int, LO>{})) static_while<LO + 1, HI>(f);
+        }
+    }
+    // f(integral_constant<int, i>) for a wave-uniform run-time i in [LO, HI]: a binary tree of scalar branches (four taken or untaken
+    // branches for 14 values; a chain of "if (s == i)" over the unrolled slots cost a taken branch — an instruction-buffer refill,
+    // ~100 cycles — for every slot that did not match)
+    template <int LO, int HI, typename F>
+    static __device__ __forceinline__ void dispatch(int i, F &&f) {
+        if constexpr (LO >= HI) {
+            f(std::integral_constant<int, LO>{});
+        } else {
+            constexpr int MID = (LO + HI) / 2;
+            if (i <= MID) dispatch<LO, MID>(i, f);
+            else dispatch<MID + 1, HI>(i, f);
+        }
+    }
     static __device__ __forceinline__ int wave_of(int t) { return MS::wave_of(t); }
+    // this lane's index in its wavefront, computed on the spot (two VALU instructions the compiler can neither hoist nor merge): the
+    // iteration loop derives its lane coordinates from it instead of keeping the thread index live across the loop — spilled, it
+    // was reloaded from scratch memory once per iteration, with a full memory wait behind the dense stages
+    static __device__ __forceinline__ int fresh_lane() {
+#ifdef SQPH_SIM
+        return (int)(threadIdx.x & 63);
+#else
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+#endif
+    }
     template <typename P>
     static __device__ __forceinline__ const P *uniform_ptr(const P *p) {
 #ifdef SQPH_SIM
@@ -202,7 +248,7 @@ struct CsbKernel {
     }
     // a use of every block register (no instruction): placed in the loop's sparse phases, whose many loads in flight would otherwise
     // push the blocks — long live ranges with two uses per iteration, the allocator's favourite victims — out to scratch
-    static __device__ __forceinline__ void pin_blocks(const sqph_acc4 (&B)[NB + 1]) {
+    static __device__ __forceinline__ void pin_blocks(const csb_blk (&B)[NB + 1]) {
 #ifndef SQPH_SIM
 #pragma unroll
         for (int s = 0; s <= NB; s++) asm volatile("" ::"v"(B[s].v[0]), "v"(B[s].v[1]), "v"(B[s].v[2]), "v"(B[s].v[3]));
@@ -232,11 +278,11 @@ struct CsbKernel {
     }
     static __device__ __forceinline__ T opN(const T *b, int kq, int lr, int lq) { return b[lr * 17 + 4 * kq + lq]; }
     static __device__ __forceinline__ T opT(const T *b, int kq, int lr, int lq) { return b[(4 * kq + lq) * 17 + lr]; }
-    static __device__ __forceinline__ void ldD(const T *b, int lr, int lq, sqph_acc4 &a) {
+    static __device__ __forceinline__ void ldD(const T *b, int lr, int lq, csb_blk &a) {
 #pragma unroll
         for (int e = 0; e < 4; e++) a.v[e] = b[(lq + 4 * e) * 17 + lr];
     }
-    static __device__ __forceinline__ void stD(T *b, int lr, int lq, const sqph_acc4 &a) {
+    static __device__ __forceinline__ void stD(T *b, int lr, int lq, const csb_blk &a) {
 #pragma unroll
         for (int e = 0; e < 4; e++) b[(lq + 4 * e) * 17 + lr] = a.v[e];
     }
@@ -675,23 +721,36 @@ struct CsbKernel {
     // column, in row order, its lanes add rho_i A_ij * (row i of A) into the panel column (distinct k per lane: rows are
     // duplicate-free; successive entries are ordered by the wavefront's program order).  Only k >= j is formed (+ the lower triangle
     // of P: what reaches the reference's factor, Eigen::LDLT<.,Lower>, qp.hpp:129); diagonal blocks are mirrored on pick-up.
-    static __device__ __forceinline__ void pick_up(int W, int p, int n, const T *Sp, int lr, int lq, sqph_acc4 (&B)[NB + 1]) {
+    static __device__ __forceinline__ void pick_one(csb_blk &Bs, int I, int K, int n, const T *Sp, int lr, int lq) {
+        const int kk = K & 1;
 #pragma unroll
-        for (int s = 0; s <= NB; s++) {
-            const Slot d = slot_of(W, s);
-            if (d.valid && (d.K >> 1) == p) {
-                const int kk = d.K & 1;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int il = lq + 4 * e, i = 16 * d.I + il, j = 16 * d.K + lr;
-                    const int hi = il > lr ? il : lr, lo = il > lr ? lr : il;
-                    // a diagonal block is mirrored: (lo, hi) of the lower triangle; elsewhere column lr, row il
-                    const int a = d.I == d.K ? (16 * kk + lo) * LDP + 16 * d.I + hi : (16 * kk + lr) * LDP + i;
-                    const T v = Sp[a];
-                    B[s].v[e] = (i < n && j < n) ? v : (i == j ? T(1) : T(0));  // the padding is an identity block
+        for (int e = 0; e < 4; e++) {
+            const int il = lq + 4 * e, i = 16 * I + il, j = 16 * K + lr;
+            const int hi = il > lr ? il : lr, lo = il > lr ? lr : il;
+            // a diagonal block is mirrored: (lo, hi) of the lower triangle; elsewhere column lr, row il
+            const int a = I == K ? (16 * kk + lo) * LDP + 16 * I + hi : (16 * kk + lr) * LDP + i;
+            const T v = Sp[a];
+            Bs.v[e] = (i < n && j < n) ? v : (i == j ? T(1) : T(0));  // the padding is an identity block
+        }
+    }
+    // the blocks of panel p (block columns 2 p and 2 p + 1) of my rows, out of the panel in LDS
+    static __device__ __forceinline__ void pick_up(int W, int p, int n, const T *Sp, int lr, int lq, csb_blk (&B)[NB + 1]) {
+        if (W >= NH) return;
+        const int I1 = NB - 1 - W, I0 = W;
+        const bool has0 = I0 < I1;
+        dispatch<0, (NB - 1) / 2>(p, [&](auto pc) __attribute__((always_inline)) {
+            constexpr int K0 = 2 * decltype(pc)::value, K1 = K0 + 1;
+            if (K0 <= I1) pick_one(B[K0], I1, K0, n, Sp, lr, lq);
+            if constexpr (K1 < NB) {
+                if (K1 <= I1) pick_one(B[K1], I1, K1, n, Sp, lr, lq);
+            }
+            if (has0) {
+                if (K0 <= I0) pick_one(B[NB - K0], I0, K0, n, Sp, lr, lq);
+                if constexpr (K1 < NB) {
+                    if (K1 <= I0) pick_one(B[NB - K1], I0, K1, n, Sp, lr, lq);
                 }
             }
-        }
+        });
     }
     // any lane of this lane's aligned group of 16 (the groups of a wavefront may have diverged)
     static __device__ __forceinline__ bool group16_any(bool p) {
@@ -708,7 +767,7 @@ struct CsbKernel {
     // formed in the order of the dense path (an absent entry is a dense zero, whose addition changes nothing): bit-identical S.
     template <bool SP = false>
     static __device__ __forceinline__ void form_S(const TIN *__restrict__ gP, const int *__restrict__ pcol, const int *__restrict__ prow, int n,
-                                                  T sigma, const Lay &L, unsigned char *smem, int t_, int wave_, sqph_acc4 (&B)[NB + 1]) {
+                                                  T sigma, const Lay &L, unsigned char *smem, int t_, int wave_, csb_blk (&B)[NB + 1]) {
         int t = t_;
         const int c16 = t & 15, g = t >> 4;
         T *lds = reinterpret_cast<T *>(smem);
@@ -825,7 +884,7 @@ struct CsbKernel {
     //   B: E_IK -= L_IJ W_JK (K < J), E_IJ = -L_IJ Winv_JJ D_J, M_IK -= L_IJ L_KJ' (J < K <= I) on my rows I > J, both operands
     //      from LDS, the accumulators in place; meanwhile the last wavefront eliminates M_J+1,J+1 (look-ahead)
     // E is the unit-block-lower inverse in the making, stored in place of the eliminated blocks.
-    static __device__ __forceinline__ void diag_to_sj(int W, const sqph_acc4 (&B)[NB + 1], T *sj, int lr, int lq) {
+    static __device__ __forceinline__ void diag_to_sj(int W, const csb_blk (&B)[NB + 1], T *sj, int lr, int lq) {
 #pragma unroll
         for (int s = 0; s <= NB; s++) {
             const Slot d = slot_of(W, s);
@@ -837,7 +896,7 @@ struct CsbKernel {
             }
         }
     }
-    static __device__ __forceinline__ void scale_blocks(int W, sqph_acc4 (&B)[NB + 1], const T *sj, T *wk, int lr, int lq) {
+    static __device__ __forceinline__ void scale_blocks(int W, csb_blk (&B)[NB + 1], const T *sj, T *wk, int lr, int lq) {
 #pragma unroll
         for (int s = 0; s <= NB; s++) {
             const Slot d = slot_of(W, s);
@@ -849,99 +908,128 @@ struct CsbKernel {
             }
         }
     }
-    static __device__ __forceinline__ void elim_A(int W, int J, sqph_acc4 (&B)[NB + 1], T *wk, int lr, int lq) {
+    // L_IJ = M_IJ Winv_JJ' of my row I > J, through XS[I] (the block is the A-operand of its own product)
+    static __device__ __forceinline__ void panel_block(const csb_blk &Bs, int I, T *XS, const T *Wd, int lr, int lq) {
+        T *x = XS + I * BS;
+        stD(x, lr, lq, Bs);
+        wave_fence();
+        csb_blk a = {{0, 0, 0, 0}};
+        T av[4], bv[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) {
+            av[kq] = opN(x, kq, lr, lq);
+            bv[kq] = opN(Wd, kq, lr, lq);
+        }
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
+        wave_fence();
+        stD(x, lr, lq, a);
+    }
+    // W_JK = Winv_JJ E_JK of the row being finished (K < J), published in XS[K]
+    static __device__ __forceinline__ void finish_block(csb_blk &Bs, int K, T *XS, const T *Wd, int lr, int lq) {
+        csb_blk a = {{0, 0, 0, 0}};
+        T av[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) av[kq] = opN(Wd, kq, lr, lq);
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) mfma16(av[kq], Bs.v[kq], a);  // the D layout of a block is its B-operand layout
+        Bs = a;
+        stD(XS + K * BS, lr, lq, a);
+    }
+    // look-ahead: the next diagonal block, updated now (with my own L_J+1,J) and handed to the eliminating wavefront
+    static __device__ __forceinline__ void lookahead_block(csb_blk &Bs, int J, T *wk, int lr, int lq) {
+        const T *x = wk + Lay::O_XS + (J + 1) * BS;
+        T av[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) av[kq] = opN(x, kq, lr, lq);
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) mfma16(-av[kq], av[kq], Bs);
+        stD(wk + Lay::O_MD + ((J + 1) & 1) * BS, lr, lq, Bs);
+    }
+    static __device__ __forceinline__ void elim_A(int W, int J, csb_blk (&B)[NB + 1], T *wk, int lr, int lq) {
+        if (W >= NH) return;  // (the eliminating wavefront owns no block)
         T *XS = wk + Lay::O_XS;
         const T *Wd = wk + Lay::O_TB + (J & 1) * BS;
-#pragma unroll
-        for (int s = 0; s <= NB; s++) {
-            const Slot d = slot_of(W, s);
-            if (!d.valid) continue;
-            if (d.I > J && d.K == J) {
-                T *x = XS + d.I * BS;
-                stD(x, lr, lq, B[s]);
-                wave_fence();
-                sqph_acc4 a = {{0, 0, 0, 0}};
-                T av[4], bv[4];
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) {
-                    av[kq] = opN(x, kq, lr, lq);
-                    bv[kq] = opN(Wd, kq, lr, lq);
-                }
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
-                wave_fence();
-                stD(x, lr, lq, a);
-            } else if (d.I == J && d.K < J) {
-                sqph_acc4 a = {{0, 0, 0, 0}};
-                T av[4];
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) av[kq] = opN(Wd, kq, lr, lq);
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], B[s].v[kq], a);  // the D layout of a block is its B-operand layout
-                B[s] = a;
-                stD(XS + d.K * BS, lr, lq, a);
-            } else if (d.I == J && d.K == J) {
-                ldD(wk + Lay::O_MD + (J & 1) * BS, lr, lq, B[s]);  // W_JJ = Winv_JJ D_J
-            }
-            SQPH_SLOT_FENCE();
+        const int I1 = NB - 1 - W, I0 = W;
+        const bool has0 = I0 < I1;
+        constexpr int KH = (NB - 1) / 2;  // block columns of a second row: K <= I0 <= KH
+        // my panel blocks (I, J), I > J: slot J of row I1, slot NB - J of row I0
+        if (I1 > J) dispatch<0, NB - 1>(J, [&](auto kc) __attribute__((always_inline)) { panel_block(B[decltype(kc)::value], I1, XS, Wd, lr, lq); });
+        if (has0 && I0 > J) dispatch<0, KH>(J, [&](auto kc) __attribute__((always_inline)) { panel_block(B[NB - decltype(kc)::value], I0, XS, Wd, lr, lq); });
+        // the row J itself, if it is mine: W_JK for K < J, then W_JJ = Winv_JJ D_J from the eliminating wavefront
+        if (I1 == J) {
+            static_while<0, NB - 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                if (K >= J) return false;
+                finish_block(B[K], K, XS, Wd, lr, lq);
+                return true;
+            });
+            dispatch<0, NB - 1>(J, [&](auto kc) __attribute__((always_inline)) { ldD(wk + Lay::O_MD + (J & 1) * BS, lr, lq, B[decltype(kc)::value]); });
+        } else if (has0 && I0 == J) {
+            static_while<0, KH>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                if (K >= J) return false;
+                finish_block(B[NB - K], K, XS, Wd, lr, lq);
+                return true;
+            });
+            dispatch<0, KH>(J, [&](auto kc) __attribute__((always_inline)) { ldD(wk + Lay::O_MD + (J & 1) * BS, lr, lq, B[NB - decltype(kc)::value]); });
         }
-        // look-ahead: the next diagonal block, updated now (with my own L_J+1,J) and handed to the eliminating wavefront
         wave_fence();
+        if (I1 == J + 1) dispatch<0, NB - 1>(J + 1, [&](auto kc) __attribute__((always_inline)) { lookahead_block(B[decltype(kc)::value], J, wk, lr, lq); });
+        else if (has0 && I0 == J + 1) dispatch<0, KH>(J + 1, [&](auto kc) __attribute__((always_inline)) { lookahead_block(B[NB - decltype(kc)::value], J, wk, lr, lq); });
+    }
+    // the trailing update of one block (I, K) of a row I > J: E_IK -= L_IJ W_JK (K < J: W_JK read transposed), E_IJ = -L_IJ Winv_JJ D_J,
+    // M_IK -= L_IJ L_KJ' (K > J); `av` = -L_IJ as the A-operand.  K is a compile-time constant: the operand's block is an immediate offset,
+    // and whether it is read transposed is a select between two lane offsets (no branch between the two common cases)
+    template <int K>
+    static __device__ __forceinline__ void update_block(csb_blk &Bs, int I, int J, const T (&av)[4], const T *XS, const T *Wd, T dc, int lr, int lq) {
+        if (K == J) {
+            csb_blk a = {{0, 0, 0, 0}};
+            T bv[4];
 #pragma unroll
-        for (int s = 0; s <= NB; s++) {
-            const Slot d = slot_of(W, s);
-            if (d.valid && d.I == J + 1 && d.K == J + 1) {
-                const T *x = XS + d.I * BS;
-                T av[4];
+            for (int kq = 0; kq < 4; kq++) bv[kq] = opT(Wd, kq, lr, lq);
 #pragma unroll
-                for (int kq = 0; kq < 4; kq++) av[kq] = opN(x, kq, lr, lq);
+            for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
 #pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(-av[kq], av[kq], B[s]);
-                stD(wk + Lay::O_MD + ((J + 1) & 1) * BS, lr, lq, B[s]);
-            }
+            for (int e = 0; e < 4; e++) Bs.v[e] = a.v[e] * dc;
+        } else if (!(I == J + 1 && K == J + 1)) {  // (that one is the look-ahead's)
+            const bool tr = K < J;
+            const T *b = XS + K * BS + (tr ? lq * 17 + lr : lr * 17 + lq);
+            const int st = tr ? 4 * 17 : 4;
+            T bv[4];
+#pragma unroll
+            for (int kq = 0; kq < 4; kq++) bv[kq] = b[kq * st];  // == opT / opN (XS + K BS, kq, lr, lq)
+#pragma unroll
+            for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], Bs);
         }
     }
-    static __device__ __forceinline__ void elim_B(int W, int J, sqph_acc4 (&B)[NB + 1], const T *wk, const T *sj, int lr, int lq) {
+    static __device__ __forceinline__ void elim_B(int W, int J, csb_blk (&B)[NB + 1], const T *wk, const T *sj, int lr, int lq) {
         const T *XS = wk + Lay::O_XS;
         const T *Wd = wk + Lay::O_TB + (J & 1) * BS;
         const T dc = sj[16 * J + lr];
         const int I1 = NB - 1 - W, I0 = W;
-        T av1[4] = {0, 0, 0, 0}, av0[4] = {0, 0, 0, 0};
+        constexpr int KH = (NB - 1) / 2;
         if (I1 > J) {
+            T av[4];
 #pragma unroll
-            for (int kq = 0; kq < 4; kq++) av1[kq] = -opN(XS + I1 * BS, kq, lr, lq);
+            for (int kq = 0; kq < 4; kq++) av[kq] = -opN(XS + I1 * BS, kq, lr, lq);
+            static_while<0, NB - 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                if (K > I1) return false;
+                update_block<K>(B[K], I1, J, av, XS, Wd, dc, lr, lq);
+                return true;
+            });
         }
         if (I0 < I1 && I0 > J) {
+            T av[4];
 #pragma unroll
-            for (int kq = 0; kq < 4; kq++) av0[kq] = -opN(XS + I0 * BS, kq, lr, lq);
-        }
-#pragma unroll
-        for (int s = 0; s <= NB; s++) {
-            const Slot d = slot_of(W, s);
-            if (!d.valid || d.I <= J) continue;
-            T av[4], bv[4];
-#pragma unroll
-            for (int kq = 0; kq < 4; kq++) av[kq] = s <= I1 ? av1[kq] : av0[kq];  // (a scalar condition)
-            if (d.K < J) {
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) bv[kq] = opT(XS + d.K * BS, kq, lr, lq);
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
-            } else if (d.K == J) {
-                sqph_acc4 a = {{0, 0, 0, 0}};
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) bv[kq] = opT(Wd, kq, lr, lq);
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
-#pragma unroll
-                for (int e = 0; e < 4; e++) B[s].v[e] = a.v[e] * dc;
-            } else if (!(d.I == J + 1 && d.K == J + 1)) {
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) bv[kq] = opN(XS + d.K * BS, kq, lr, lq);
-#pragma unroll
-                for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], B[s]);
-            }
-            SQPH_SLOT_FENCE();
+            for (int kq = 0; kq < 4; kq++) av[kq] = -opN(XS + I0 * BS, kq, lr, lq);
+            static_while<0, KH>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                if (K > I0) return false;
+                update_block<K>(B[NB - K], I0, J, av, XS, Wd, dc, lr, lq);
+                return true;
+            });
         }
     }
 #define SQPH_CSB_SWITCH(wave, CALL) \
@@ -969,7 +1057,7 @@ struct CsbKernel {
 #endif
     template <bool SP = false>
     static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const int *__restrict__ pcol, const int *__restrict__ prow, int n,
-                                                  T sigma, const Lay &L, unsigned char *smem, int t, sqph_acc4 (&B)[NB + 1] SQPH_FTICK_ARGS) {
+                                                  T sigma, const Lay &L, unsigned char *smem, int t, csb_blk (&B)[NB + 1] SQPH_FTICK_ARGS) {
         T *lds = reinterpret_cast<T *>(smem);
         T *sj = lds + Lay::o_sj, *flag = lds + Lay::o_flag, *wk = lds;
         const int wave = wave_of(t), l = t & 63, lr = l & 15, lq = l >> 4;
@@ -993,7 +1081,7 @@ struct CsbKernel {
         SQPH_FTICK(2)
         if (wave == DW) MS::diag_block(wk + Lay::O_MD, wk + Lay::O_TB, sj, flag, l);
 #pragma unroll 1
-        for (int J = 0; J < NB; J++) {
+        for (int J = 0; J < NB - 1; J++) {
             // the lane's coordinates are derived again in every step: as loop invariants the LDS addresses of all 14 slots' operands
             // (~40 words) were hoisted out of this loop, spilled, and reloaded from scratch memory in front of every block product
             int lj = l, wj = wave;
@@ -1004,14 +1092,22 @@ struct CsbKernel {
             SQPH_FTICK(12)
             elim_A(wj, J, B, wk, lrj, lqj);
             SQPH_FTICK(13)
-            if (J == NB - 1) break;
             __syncthreads();
             SQPH_FTICK(14)
             if (wj == DW)
-                MS::diag_block(wk + Lay::O_MD + ((J + 1) & 1) * BS, wk + Lay::O_TB + ((J + 1) & 1) * BS, sj + 16 * (J + 1), flag, lj);
+                MS::template diag_block<true>(wk + Lay::O_MD + ((J + 1) & 1) * BS, wk + Lay::O_TB + ((J + 1) & 1) * BS, sj + 16 * (J + 1), flag, lj);
             else
                 elim_B(wj, J, B, wk, sj, lrj, lqj);
             SQPH_FTICK(15)
+        }
+        {   // the last step has no trailing update (peeled: a loop left from its middle kept an old and a new copy of every block)
+            int lj = l, wj = wave;
+            SQPH_OPAQUE_V(lj);
+            SQPH_OPAQUE_S(wj);
+            __syncthreads();
+            SQPH_FTICK(12)
+            elim_A(wj, NB - 1, B, wk, lj & 15, lj >> 4);
+            SQPH_FTICK(13)
         }
         __syncthreads();
         SQPH_FTICK(7)
@@ -1022,7 +1118,7 @@ struct CsbKernel {
     // y1 = W t for my block rows (partial sums over the 16 lanes of a DPP row through my slice of PW, summed by two lanes per
     // value), then the partial column sums of W' y1 over my rows, reduced over the four DPP rows and written to XP[column][wave].
     template <int W>
-    static __device__ __forceinline__ void stages(const sqph_acc4 (&B)[NB + 1], const T *tv, T *pw, T *xp, int n, int wave, int lr, int lq) {
+    static __device__ __forceinline__ void stages(const csb_blk (&B)[NB + 1], const T *tv, T *pw, T *xp, int n, int wave, int lr, int lq) {
         using O = Own<W>;
         T acc1[4] = {0, 0, 0, 0}, acc0[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1032,7 +1128,7 @@ struct CsbKernel {
             for (int e = 0; e < 4; e++) acc1[e] = wg_fma(B[K].v[e], tk, acc1[e]);
             if (O::has0 && K <= O::I0) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) acc0[e] = wg_fma(B[O::has0 ? O::I1 + 1 + K : 0].v[e], tk, acc0[e]);
+                for (int e = 0; e < 4; e++) acc0[e] = wg_fma(B[O::has0 ? NB - K : 0].v[e], tk, acc0[e]);
             }
         }
         T *mine = pw + wave * Lay::PWW;
@@ -1065,7 +1161,7 @@ struct CsbKernel {
 #pragma unroll
         for (int K = 0; K <= O::I1; K++) {
             cacc[K] = fmac4_bcast16<0>(cacc[K], ytot, B[K]);
-            if (O::has0 && K <= O::I0) cacc[K] = fmac4_bcast16<4>(cacc[K], ytot, B[O::has0 ? O::I1 + 1 + K : 0]);
+            if (O::has0 && K <= O::I0) cacc[K] = fmac4_bcast16<4>(cacc[K], ytot, B[O::has0 ? NB - K : 0]);
         }
         T r[8];
 #pragma unroll
@@ -1082,7 +1178,7 @@ struct CsbKernel {
     }
 
     // tile <-> global workspace (the factor survives between setup() and solve() calls there), canonical col-major n x n, lower part
-    static __device__ __forceinline__ void store_blocks(int W, T *__restrict__ gW, int n, int lr, int lq, const sqph_acc4 (&B)[NB + 1]) {
+    static __device__ __forceinline__ void store_blocks(int W, T *__restrict__ gW, int n, int lr, int lq, const csb_blk (&B)[NB + 1]) {
 #pragma unroll
         for (int s = 0; s <= NB; s++) {
             const Slot d = slot_of(W, s);
@@ -1094,7 +1190,7 @@ struct CsbKernel {
             }
         }
     }
-    static __device__ __forceinline__ void load_blocks(int W, const T *__restrict__ gW, int n, int lr, int lq, sqph_acc4 (&B)[NB + 1]) {
+    static __device__ __forceinline__ void load_blocks(int W, const T *__restrict__ gW, int n, int lr, int lq, csb_blk (&B)[NB + 1]) {
 #pragma unroll
         for (int s = 0; s <= NB; s++) {
             const Slot d = slot_of(W, s);
@@ -1115,7 +1211,7 @@ struct CsbKernel {
         int o_lo, o_up, o_rinv, o_wv, o_zs, o_ys, o_rho, o_val, o_rowptr, o_csc, o_col;
         SlotCode rsc, csc_;  // this lane's slot codes (place_slots)
     };
-    static __device__ __forceinline__ void segment(const sqph_acc4 (&B)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) {
+    static __device__ __forceinline__ void segment(const csb_blk (&B)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) {
         SQPH_DYN_SMEM(smem);
         T *lds = reinterpret_cast<T *>(smem);
         const int *li = reinterpret_cast<const int *>(smem);
@@ -1148,8 +1244,7 @@ struct CsbKernel {
                 }
                 __syncthreads();
                 SQPH_BTICK(3)
-                int li = l;
-                SQPH_OPAQUE_V(li);
+                const int li = fresh_lane();
                 const int lr_i = li & 15, lq_i = li >> 4;
 #define SQPH_CSB_CALL(W_) stages<W_>(B, tv, pw, xp, n, wave, lr_i, lq_i)
                 SQPH_CSB_SWITCH(wave, SQPH_CSB_CALL)
@@ -1157,8 +1252,7 @@ struct CsbKernel {
                 __syncthreads();
                 SQPH_BTICK(4)
                 {   // x~ = W' y1; x relaxation (qp.cpp:96)
-                    int ti = t;
-                    SQPH_OPAQUE_V(ti);  // (addresses derived from the lane index are recomputed per phase: hoisted out of the loop they were spilled)
+                    const int ti = (wave << 6) | fresh_lane();  // (addresses derived from the lane index are recomputed per phase: hoisted out of the loop they were spilled)
                     if (ti < NP) {
                         T p[8];
 #pragma unroll
@@ -1199,16 +1293,16 @@ struct CsbKernel {
     // whatever the source did — both sparse products of every iteration then ran from scratch memory (15 k instead of 1.1 k cycles
     // each).  Behind a call the segment is allocated on its own, like the no-check instantiation's loop.
 #ifdef SQPH_SIM
-    static inline void segment_call(const sqph_acc4 (&Bm)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) { segment(Bm, seg, c SQPH_FTICK_PASS); }
+    static inline void segment_call(const csb_blk (&Bm)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) { segment(Bm, seg, c SQPH_FTICK_PASS); }
 #else
-    static __device__ __attribute__((noinline)) void segment_call(const sqph_acc4 (&Bm)[NB + 1], int seg_, const IterCtx &cm SQPH_FTICK_ARGS) {
+    static __device__ __attribute__((noinline)) void segment_call(const csb_blk (&Bm)[NB + 1], int seg_, const IterCtx &cm SQPH_FTICK_ARGS) {
         IterCtx c = cm;
         c.n = uniform_int(c.n);
         c.o_lo = uniform_int(c.o_lo); c.o_up = uniform_int(c.o_up); c.o_rinv = uniform_int(c.o_rinv); c.o_wv = uniform_int(c.o_wv);
         c.o_zs = uniform_int(c.o_zs); c.o_ys = uniform_int(c.o_ys); c.o_rho = uniform_int(c.o_rho); c.o_val = uniform_int(c.o_val);
         c.o_rowptr = uniform_int(c.o_rowptr); c.o_csc = uniform_int(c.o_csc); c.o_col = uniform_int(c.o_col);
         const int seg = uniform_int(seg_);
-        sqph_acc4 B[NB + 1];
+        csb_blk B[NB + 1];
 #pragma unroll
         for (int s = 0; s <= NB; s++) B[s] = Bm[s];
         segment(B, seg, c SQPH_FTICK_PASS);
@@ -1382,7 +1476,8 @@ struct CsbKernel {
         if (!(mode & (MODE_SETUP | MODE_UPDATE)) && (info.status == SQPH_UNINITIALIZED || info.status == SQPH_NUMERICAL_ISSUES))
             return;  // qp.cpp:68-71 (block-uniform)
 
-        const int t = threadIdx.x, wave = wave_of(t), l = t & 63, lr = l & 15, lq = l >> 4;
+        int t = threadIdx.x;
+        const int wave = wave_of(t), l = t & 63, lr = l & 15, lq = l >> 4;
 #ifdef SQPH_PHASE_TIMING
         unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
         const unsigned long long tstart = tprev;
@@ -1455,9 +1550,9 @@ struct CsbKernel {
             }
         }
 
-        sqph_acc4 B[NB + 1];
+        csb_blk B[NB + 1];
 #pragma unroll
-        for (int s = 0; s <= NB; s++) B[s] = sqph_acc4{{0, 0, 0, 0}};  // (defined on every path: the slots a wavefront does not own are never touched)
+        for (int s = 0; s <= NB; s++) B[s] = csb_blk{{0, 0, 0, 0}};  // (defined on every path: the slots a wavefront does not own are never touched)
         bool need_factor = (mode & (MODE_SETUP | MODE_UPDATE | MODE_REFACTOR)) != 0;
         if ((mode & MODE_SAME_MATRICES) && (mode & (MODE_SETUP | MODE_UPDATE)) && !(mode & MODE_REFACTOR) &&
             info.status != SQPH_NUMERICAL_ISSUES && info.status != SQPH_UNINITIALIZED) {  // (a failed set-up left no valid factor)
@@ -1492,9 +1587,9 @@ struct CsbKernel {
                 if constexpr (CHECKS) {
                     // (in this instantiation B is handed to segment_call by reference and therefore lives in memory: the set-up works on
                     // a register copy of its own)
-                    sqph_acc4 Bf[NB + 1];
+                    csb_blk Bf[NB + 1];
 #pragma unroll
-                    for (int s = 0; s <= NB; s++) Bf[s] = sqph_acc4{{0, 0, 0, 0}};
+                    for (int s = 0; s <= NB; s++) Bf[s] = csb_blk{{0, 0, 0, 0}};
                     ok = factor<SP>(gP, pcol, prow, n, sigma, L, smem, t, Bf SQPH_FTICK_PASS);
                     if (!(mode & MODE_NO_FACTOR_STORE)) store_blocks(wave, gW, n, lr, lq, Bf);  // kept for later solve() calls
 #pragma unroll
@@ -1633,6 +1728,9 @@ struct CsbKernel {
                 }
                 iter++;
             }
+            // the thread index starts a new life here: live across the segments it was the allocator's spill victim, reloaded from
+            // scratch memory inside the iteration loop (the write-back below is its next use)
+            t = (wave << 6) | fresh_lane();
             if (!need_factor) break;
         }
         if (solving) {

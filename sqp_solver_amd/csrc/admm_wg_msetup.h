@@ -233,6 +233,9 @@ struct MSetup {
         M[I] = I > j ? v : (I == j ? rs : T(0));
         if constexpr (I + 1 < 16) scale_rows<I + 1>(M, j, rs);
     }
+    // BRANCHFREE: the failure flag is raised behind a wave-uniform condition (a ballot) instead of a lane-divergent branch: inside the
+    // block-row kernel's elimination loop one divergent branch made the compiler structurize the whole loop (admm_csrb_kernel.h)
+    template <bool BRANCHFREE = false>
     static __device__ __forceinline__ void diag_block(T *Sjj, T *TB, const T *djp, T *flag, int l) {
         const int j = l & 15;
         T M[16];
@@ -249,7 +252,15 @@ struct MSetup {
             TB[ix(i, j)] = M[i];           // unscaled: operand of this step's panel products
             Sjj[ix(i, j)] = M[i] * dj;     // W_JJ = Winv_JJ D_J^-1/2 (columns)
         }
-        if (bad) flag[1] = T(1);
+        if constexpr (BRANCHFREE) {
+#ifdef SQPH_SIM
+            if (bad) flag[1] = T(1);
+#else
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) flag[1] = T(1);  // (wave-uniform condition: every lane stores)
+#endif
+        } else {
+            if (bad) flag[1] = T(1);
+        }
     }
 
     // ------------------------------------------------------------------ factorisation
