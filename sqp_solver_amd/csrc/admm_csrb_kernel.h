@@ -46,6 +46,30 @@
 #define SQPH_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// -DSQPH_PHASE_TIMING (debug builds, tools/phase_timing_csb.py): s_memtime ticks per phase of one wavefront, returned in x[0..16)
+#ifdef SQPH_PHASE_TIMING
+#define SQPH_FTICK_ARGS , unsigned long long (&tacc)[16], unsigned long long &tprev
+#define SQPH_FTICK_PASS , tacc, tprev
+#define SQPH_FTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
+#define SQPH_BTICK(k) SQPH_FTICK(k)
+#else
+#define SQPH_BTICK(k)
+#define SQPH_FTICK_ARGS
+#define SQPH_FTICK_PASS
+#define SQPH_FTICK(k)
+#endif
+// -DSQPH_PT_SETUP=1 / 2 (with -DSQPH_PHASE_TIMING): the per-iteration slots 3-6, 8 count sub-phases of the S phase / of the sparse
+// loading and lane maps instead (tools/phase_timing_csb.py --setup)
+#if defined(SQPH_PHASE_TIMING) && defined(SQPH_PT_SETUP)
+#define SQPH_ITICK(k)
+#define SQPH_STICK1(k) { if (SQPH_PT_SETUP == 1) SQPH_FTICK(k) }
+#define SQPH_STICK2(k) { if (SQPH_PT_SETUP == 2) SQPH_FTICK(k) }
+#else
+#define SQPH_ITICK(k) SQPH_BTICK(k)
+#define SQPH_STICK1(k)
+#define SQPH_STICK2(k)
+#endif
+
 namespace sqph {
 
 template <int NB>
@@ -70,7 +94,7 @@ struct CsbLayout {
     static constexpr int O_PW = 0;
     static constexpr int O_XP = O_PW + 8 * PWW;     // [8 waves][NP] partial sums of x~ = W' y1, wavefront-major (lane-consecutive stores and loads)
     static constexpr int W_ITER = O_XP + NP * 8;
-    static constexpr int W_MAP = (2 * NT * 2 + (544 + 32) * 4 + 7) / 8;
+    static constexpr int W_MAP = (2 * NT * 2 + 2 * (544 + 32) * 4 + 7) / 8;
     static constexpr int WORK = ev(mx(mx(W_PANEL, W_ELIM), mx(W_ITER, W_MAP)));
     static constexpr int o_t = WORK;                // t = sigma x - q + A'w, plain-indexed
     static constexpr int o_xt = o_t + NP;
@@ -320,11 +344,26 @@ struct CsbKernel {
         for (int j = t; j <= NP; j += NT) colptr[j] = 0;
         __syncthreads();
         const int nnz = rowptr[m];
-        for (int e = t; e < nnz; e += NT) {
-            const int j = gci[e];
-            col[e] = (unsigned short)j;
-            val[e] = (T)gv[e];
-            lds_atomic_inc(&colptr[j + 1]);  // integer counts: order-independent
+        // four entries per lane and round, all their loads requested before the first is used: the arrays are read once, cold from HBM,
+        // and entry by entry this loop was nine exposed memory round trips (load_sparse 38 k of the set-up's 420 k cycles)
+        for (int e0 = t; e0 < nnz; e0 += 4 * NT) {
+            int jj[4];
+            T vv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = e0 + k * NT;
+                jj[k] = e < nnz ? gci[e] : 0;
+                vv[k] = e < nnz ? (T)gv[e] : T(0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = e0 + k * NT;
+                if (e < nnz) {
+                    col[e] = (unsigned short)jj[k];
+                    val[e] = vv[k];
+                    lds_atomic_inc(&colptr[jj[k] + 1]);  // integer counts: order-independent
+                }
+            }
         }
         __syncthreads();
         if (t < 64) {  // exclusive scan of the column counts: wave 0, 4 per lane
@@ -394,26 +433,34 @@ struct CsbKernel {
 
     // A row (column) of A gets 1, 2, 4 or 8 lanes by its length such that no lane carries more than K entries, K the smallest bound
     // for which everything fits the NT lanes; groups are laid out by size (aligned for the xor butterfly that adds their partial sums).
-    // Map word (16 bits): element in bits 0-8, part in 9-11, log2(lanes of the element) in 12-13, valid in 15.  Returns K.
-    static __device__ __forceinline__ int build_lane_map(const int *ptr, int count, unsigned short *map, int *hist) {
-        const int t = threadIdx.x;
-        constexpr int NC = 15, HL = 544;  // lengths are <= 512
+    // Map word (16 bits): element in bits 0-8, part in 9-11, log2(lanes of the element) in 12-13, valid in 15.
+    // BOTH maps in one pass — rows (ptr0 / cnt0 -> map[0 .. NT), K0) by wavefront 0, columns (ptr1 / cnt1 -> map[NT .. 2 NT), K1) by
+    // wavefront 1: the scans and the dealing are single-wavefront work, and built one after the other the two maps were 43 k of the
+    // set-up's 420 k cycles with seven wavefronts idle (hist: 2 x (HL + 32) ints).
+    static constexpr int MAP_HL = 544, MAP_HS = MAP_HL + 32;  // lengths are <= 512
+    static __device__ __forceinline__ void build_lane_maps(const int *ptr0, int cnt0, const int *ptr1, int cnt1, unsigned short *map, int *hist,
+                                                            int &K0, int &K1) {
+        const int t = threadIdx.x, w = wave_of(t), lane = t & 63;
+        constexpr int NC = 15, HL = MAP_HL, HS = MAP_HS;
         constexpr int KC[NC] = {4, 5, 6, 7, 8, 10, 12, 14, 16, 24, 32, 48, 64, 128, 256};
-        int *need = hist + HL;
-        for (int e = t; e < HL + 16; e += NT) hist[e] = 0;
+        for (int e = t; e < 2 * HS; e += NT) hist[e] = 0;
         map[t] = 0;
+        map[NT + t] = 0;
         __syncthreads();
-        if (t < count) lds_atomic_inc(&hist[ptr[t + 1] - ptr[t]]);
+        if (t < cnt0) lds_atomic_inc(&hist[ptr0[t + 1] - ptr0[t]]);
+        if (t < cnt1) lds_atomic_inc(&hist[HS + ptr1[t + 1] - ptr1[t]]);
         __syncthreads();
-        if (t < 64) {
+        if (w < 2) {
+            const int *h = hist + w * HS;
+            int *need = hist + w * HS + HL;
             int loc[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) loc[c] = 0;
-            for (int len = t; len < HL; len += 64) {
-                const int h = hist[len];
-                if (h) {
+            for (int len = lane; len < HL; len += 64) {
+                const int hv = h[len];
+                if (hv) {
 #pragma unroll
-                    for (int c = 0; c < NC; c++) loc[c] += h * lanes_for(len, KC[c]);
+                    for (int c = 0; c < NC; c++) loc[c] += hv * lanes_for(len, KC[c]);
                 }
             }
 #pragma unroll
@@ -422,21 +469,26 @@ struct CsbKernel {
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
                     const int o = shfl_up_i(v, d);
-                    if (t >= d) v += o;
+                    if (lane >= d) v += o;
                 }
-                if (t == 63) need[c] = v;
+                if (lane == 63) need[c] = v;
             }
         }
         __syncthreads();
-        int K = KC[NC - 1];
+        K0 = K1 = KC[NC - 1];
 #pragma unroll
-        for (int c = NC - 1; c >= 0; c--)
-            if (need[c] <= NT) K = KC[c];
-        if (t < 64) {  // wave 0: eight consecutive elements per lane, class offsets by a scan over the 64 lanes
+        for (int c = NC - 1; c >= 0; c--) {
+            if (hist[HL + c] <= NT) K0 = KC[c];
+            if (hist[HS + HL + c] <= NT) K1 = KC[c];
+        }
+        if (w < 2) {  // one wavefront per map: eight consecutive elements per lane, class offsets by a scan over the 64 lanes
+            const int *ptr = w ? ptr1 : ptr0;
+            const int count = w ? cnt1 : cnt0, K = w ? K1 : K0;
+            unsigned short *mapw = map + w * NT;
             int cnt[4] = {0, 0, 0, 0}, cls[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = 8 * t + k;
+                const int i = 8 * lane + k;
                 cls[k] = -1;
                 if (i < count) {
                     const int p = lanes_for(ptr[i + 1] - ptr[i], K);
@@ -453,7 +505,7 @@ struct CsbKernel {
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
                     const int o = shfl_up_i(v, d);
-                    if (t >= d) v += o;
+                    if (lane >= d) v += o;
                 }
                 incl[cc] = v;
                 tot[cc] = shfl_i(v, 63);
@@ -481,12 +533,11 @@ struct CsbKernel {
                     }
                     const int p = 1 << c, lane0 = b0 + rn * p;
                     for (int part = 0; part < p; part++)
-                        map[lane0 + part] = (unsigned short)(MAP_VALID | (c << 12) | (part << 9) | (8 * t + k));
+                        mapw[lane0 + part] = (unsigned short)(MAP_VALID | (c << 12) | (part << 9) | (8 * lane + k));
                 }
             }
         }
         __syncthreads();
-        return K;
     }
     static __device__ __forceinline__ T group_sum(T s, int lg) {
         T o = xchg<1>(s);
@@ -767,7 +818,7 @@ struct CsbKernel {
     // formed in the order of the dense path (an absent entry is a dense zero, whose addition changes nothing): bit-identical S.
     template <bool SP = false>
     static __device__ __forceinline__ void form_S(const TIN *__restrict__ gP, const int *__restrict__ pcol, const int *__restrict__ prow, int n,
-                                                  T sigma, const Lay &L, unsigned char *smem, int t_, int wave_, csb_blk (&B)[NB + 1]) {
+                                                  T sigma, const Lay &L, unsigned char *smem, int t_, int wave_, csb_blk (&B)[NB + 1] SQPH_FTICK_ARGS) {
         int t = t_;
         const int c16 = t & 15, g = t >> 4;
         T *lds = reinterpret_cast<T *>(smem);
@@ -793,8 +844,10 @@ struct CsbKernel {
 #pragma unroll 1
         for (int p = 0; p < (NB + 1) / 2; p++) {
             __syncthreads();
+            SQPH_STICK1(6)
             for (int e = t; e < 32 * LDP; e += NT) Sp[e] = 0;
             __syncthreads();
+            SQPH_STICK1(3)
 
             const int j = 32 * p + g;
             if (j < n) {
@@ -835,6 +888,7 @@ struct CsbKernel {
                         }
                     }
                 }
+                SQPH_STICK1(4)
                 // + lower triangle of P + sigma I
 #ifdef SQPH_SIM
                 ::sqph_sim::group16_sync();  // (the emulator runs a lane up to its next rendezvous: the hardware's program order of the ds_add_f64 above and below)
@@ -864,13 +918,16 @@ struct CsbKernel {
             // the clearing of the panel and the next accumulation loop, in the ONE array (a second array filled at the top of the panel
             // measured the same time, 21.55 ms, with 38 more VGPRs spilled: 8.0 against 6.9 GB of HBM traffic per launch)
             if constexpr (!SP) load_P(p + 1 < (NB + 1) / 2 ? p + 1 : p, pv);
+            SQPH_STICK1(5)
             __syncthreads();
+            SQPH_STICK1(6)
             {   // (the lane's coordinates derived again per panel: hoisted out of this loop, the pick-up's per-slot addresses, bounds
                 // tests and identity-padding values of all 14 slots were spilled and reloaded from scratch memory)
                 int tp = t_, wp = wave_;
                 SQPH_OPAQUE_V(tp);
                 SQPH_OPAQUE_S(wp);
                 pick_up(wp, p, n, Sp, tp & 15, (tp >> 4) & 3, B);
+                SQPH_STICK1(8)
             }
         }
         __syncthreads();
@@ -1044,24 +1101,13 @@ struct CsbKernel {
         default: break; \
     }
     // returns false (block-uniform) when S is not positive definite / not finite; leaves W in B
-#ifdef SQPH_PHASE_TIMING
-#define SQPH_FTICK_ARGS , unsigned long long (&tacc)[16], unsigned long long &tprev
-#define SQPH_FTICK_PASS , tacc, tprev
-#define SQPH_FTICK(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; }
-#define SQPH_BTICK(k) SQPH_FTICK(k)
-#else
-#define SQPH_BTICK(k)
-#define SQPH_FTICK_ARGS
-#define SQPH_FTICK_PASS
-#define SQPH_FTICK(k)
-#endif
     template <bool SP = false>
     static __device__ __forceinline__ bool factor(const TIN *__restrict__ gP, const int *__restrict__ pcol, const int *__restrict__ prow, int n,
                                                   T sigma, const Lay &L, unsigned char *smem, int t, csb_blk (&B)[NB + 1] SQPH_FTICK_ARGS) {
         T *lds = reinterpret_cast<T *>(smem);
         T *sj = lds + Lay::o_sj, *flag = lds + Lay::o_flag, *wk = lds;
         const int wave = wave_of(t), l = t & 63, lr = l & 15, lq = l >> 4;
-        form_S<SP>(gP, pcol, prow, n, sigma, L, smem, t, wave, B);
+        form_S<SP>(gP, pcol, prow, n, sigma, L, smem, t, wave, B SQPH_FTICK_PASS);
         SQPH_FTICK(1)
         if (t < 2) flag[t] = T(0);
         if (t < NP) sj[t] = T(1);
@@ -1234,7 +1280,7 @@ struct CsbKernel {
 #pragma unroll 1
         for (int seg_i = 0; seg_i < seg; seg_i++) {
                 __syncthreads();
-                SQPH_BTICK(8)
+                SQPH_ITICK(8)
                 {   // t = (sigma x - q) + A' w
                     pin_blocks(B);
                     const T s = creg ? reg_dot(cv, ci, wv, cmap) : csc_col_dot_lds(colptr, csc, val, wv, cmap);
@@ -1243,14 +1289,14 @@ struct CsbKernel {
                     pin_blocks(B);
                 }
                 __syncthreads();
-                SQPH_BTICK(3)
+                SQPH_ITICK(3)
                 const int li = fresh_lane();
                 const int lr_i = li & 15, lq_i = li >> 4;
 #define SQPH_CSB_CALL(W_) stages<W_>(B, tv, pw, xp, n, wave, lr_i, lq_i)
                 SQPH_CSB_SWITCH(wave, SQPH_CSB_CALL)
 #undef SQPH_CSB_CALL
                 __syncthreads();
-                SQPH_BTICK(4)
+                SQPH_ITICK(4)
                 {   // x~ = W' y1; x relaxation (qp.cpp:96)
                     const int ti = (wave << 6) | fresh_lane();  // (addresses derived from the lane index are recomputed per phase: hoisted out of the loop they were spilled)
                     if (ti < NP) {
@@ -1267,7 +1313,7 @@ struct CsbKernel {
                     }
                 }
                 __syncthreads();
-                SQPH_BTICK(5)
+                SQPH_ITICK(5)
                 {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
                     pin_blocks(B);
                     const T zt = rreg ? reg_dot(rv, ri, xt, rmap) : csr_row_dot_lds(rowptr, col, val, xt, rmap);
@@ -1285,29 +1331,14 @@ struct CsbKernel {
                     }
                     pin_blocks(B);
                 }
-                SQPH_BTICK(6)
+                SQPH_ITICK(6)
                 }
     }
-    // the checking instantiation's segment as a REAL CALL with the blocks handed over through memory: inside the solve loop of that
-    // instantiation (nested in the refactorisation loop, next to the check) the allocator kept this lane's slices of A in scratch
-    // whatever the source did — both sparse products of every iteration then ran from scratch memory (15 k instead of 1.1 k cycles
-    // each).  Behind a call the segment is allocated on its own, like the no-check instantiation's loop.
-#ifdef SQPH_SIM
-    static inline void segment_call(const csb_blk (&Bm)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) { segment(Bm, seg, c SQPH_FTICK_PASS); }
-#else
-    static __device__ __attribute__((noinline)) void segment_call(const csb_blk (&Bm)[NB + 1], int seg_, const IterCtx &cm SQPH_FTICK_ARGS) {
-        IterCtx c = cm;
-        c.n = uniform_int(c.n);
-        c.o_lo = uniform_int(c.o_lo); c.o_up = uniform_int(c.o_up); c.o_rinv = uniform_int(c.o_rinv); c.o_wv = uniform_int(c.o_wv);
-        c.o_zs = uniform_int(c.o_zs); c.o_ys = uniform_int(c.o_ys); c.o_rho = uniform_int(c.o_rho); c.o_val = uniform_int(c.o_val);
-        c.o_rowptr = uniform_int(c.o_rowptr); c.o_csc = uniform_int(c.o_csc); c.o_col = uniform_int(c.o_col);
-        const int seg = uniform_int(seg_);
-        csb_blk B[NB + 1];
-#pragma unroll
-        for (int s = 0; s <= NB; s++) B[s] = Bm[s];
-        segment(B, seg, c SQPH_FTICK_PASS);
-    }
-#endif
+    // (Until round 6 the checking instantiation ran its segments as a REAL CALL with the blocks handed over through memory: inlined, the
+    // allocator had kept this lane's slices of A in scratch.  That was the structurized control flow of this kernel — see build.py's
+    // CSB_FLAGS; with the uniform branches left alone the inlined segment is the faster form: config 5 under the SQP driver's settings
+    // 21.1 -> 19.9 ms, under the reference defaults 48.6 either way.)
+    static __device__ __forceinline__ void segment_call(const csb_blk (&Bm)[NB + 1], int seg, const IterCtx &c SQPH_FTICK_ARGS) { segment(Bm, seg, c SQPH_FTICK_PASS); }
 
     // the seven block-wide maxima of a termination check (|Ax|, |z|, |Ax - z|, |Px|, |A'y|, |q|, |Px + q + A'y|: qp.cpp:316-331, 353-361)
     // with the sparse products read from LDS and P streamed from global memory; every lane of the workgroup calls this.
@@ -1322,6 +1353,7 @@ struct CsbKernel {
                                  bool nown, T eps_abs, T eps_rel, bool force_dual, T (&v)[7], PX... px) {
 #else
     template <bool SP = false, typename... PX>
+    // (stays a real call: inlined, config 5 under the reference defaults gains 3 % and under the SQP driver's settings loses 35 %)
     static __device__ __attribute__((noinline)) bool residuals(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int rmap,
                                                                 int cmap, bool lead, int im, bool nown, T eps_abs, T eps_rel, bool force_dual,
                                                                 T (&v)[7], PX... px) {
@@ -1484,14 +1516,28 @@ struct CsbKernel {
 #endif
         // element owners: lane j < n tracks x_j; the lanes the ROW MAP gives constraint row i track z_i, y_i, rho_i (all of them keep a
         // copy, the one with part 0 writes); the COLUMN MAP's lanes sum the columns of A' w
+        // q, l, u: requested now (plain-indexed, every lane its share), stored behind the sparse loading — their memory latency hides
+        // behind it instead of following the lane maps (l and u are kept per row, whoever leads the row later)
+        T q_early = T(0), l_early[2] = {T(0), T(0)}, u_early[2] = {T(0), T(0)};
+        if (t < n) q_early = (T)gq[t];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = t + k * NT;
+            if (i < m) {
+                l_early[k] = (T)gl[i];
+                u_early[k] = (T)gu[i];
+            }
+        }
         load_sparse(ca, qp, n, m, L, smem);
+        SQPH_STICK2(3)
         int rmap, cmap;
         bool rreg, creg;
         {
             unsigned short *tmap = reinterpret_cast<unsigned short *>(lds);  // the work area is idle
             int *scratch = reinterpret_cast<int *>(tmap + 2 * NT);
-            const int Kr = build_lane_map(rowptr, m, tmap, scratch);
-            const int Kc = build_lane_map(colptr, n, tmap + NT, scratch);
+            int Kr, Kc;
+            build_lane_maps(rowptr, m, colptr, n, tmap, scratch, Kr, Kc);
+            SQPH_STICK2(4)
             rmap = (int)tmap[t];
             cmap = (int)tmap[NT + t];
             rreg = Kr <= KR;
@@ -1507,14 +1553,18 @@ struct CsbKernel {
         // barriers, twice per iteration); each lane touches its own element only
         if (t < NP) xv[t] = T(0);
         if (t < NP) {
-            qv[t] = nown ? (T)gq[t] : T(0);
+            qv[t] = q_early;
             tv[t] = T(0);
             xt[t] = T(0);
             ux[t] = T(0);
         }
-        if (lead) {
-            lov[im] = (T)gl[im];
-            upv[im] = (T)gu[im];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = t + k * NT;
+            if (i < m) {
+                lov[i] = l_early[k];
+                upv[i] = u_early[k];
+            }
         }
         __syncthreads();
         bool rho_differs = false;  // against the vector the resident factor was built with (MODE_SAME_MATRICES)
@@ -1584,20 +1634,8 @@ struct CsbKernel {
                 __syncthreads();
                 SQPH_BTICK(10)
                 bool ok;
-                if constexpr (CHECKS) {
-                    // (in this instantiation B is handed to segment_call by reference and therefore lives in memory: the set-up works on
-                    // a register copy of its own)
-                    csb_blk Bf[NB + 1];
-#pragma unroll
-                    for (int s = 0; s <= NB; s++) Bf[s] = csb_blk{{0, 0, 0, 0}};
-                    ok = factor<SP>(gP, pcol, prow, n, sigma, L, smem, t, Bf SQPH_FTICK_PASS);
-                    if (!(mode & MODE_NO_FACTOR_STORE)) store_blocks(wave, gW, n, lr, lq, Bf);  // kept for later solve() calls
-#pragma unroll
-                    for (int s = 0; s <= NB; s++) B[s] = Bf[s];
-                } else {
-                    ok = factor<SP>(gP, pcol, prow, n, sigma, L, smem, t, B SQPH_FTICK_PASS);
-                    if (!(mode & MODE_NO_FACTOR_STORE)) store_blocks(wave, gW, n, lr, lq, B);  // kept for later solve() calls
-                }
+                ok = factor<SP>(gP, pcol, prow, n, sigma, L, smem, t, B SQPH_FTICK_PASS);
+                if (!(mode & MODE_NO_FACTOR_STORE)) store_blocks(wave, gW, n, lr, lq, B);  // kept for later solve() calls
                 SQPH_BTICK(11)
                 __syncthreads();
                 need_factor = false;
@@ -1638,9 +1676,11 @@ struct CsbKernel {
                 // a check every 10) 27.4 / 25.7.  The choice depends on settings.max_iter alone (block-uniform, the same for every QP
                 // and every call with these settings: results stay reproducible); the summation order inside a lane follows the slots.
                 const bool place = a.max_iter >= SQPH_CSB_PLACE_MIN_ITERS;
+                SQPH_STICK2(6)
                 if (rreg) rsc = place_slots<true>(rowptr, col, csc, rmap, NP, area, t, place);
                 if (creg) csc_ = place_slots<false>(colptr, col, csc, cmap, m, area, t, place);
                 __syncthreads();
+                SQPH_STICK2(8)
             }
             for (int e = t; e < NP * 8; e += NT) xp[e] = T(0);
             if (lead) wv[im] = rhov[im] * (zs[im] - rinvv[im] * ys[im]);

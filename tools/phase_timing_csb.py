@@ -22,8 +22,17 @@ s.enable_timing(True)
 s.setup_solve_csr(*args)
 ms = s.collect_kernel_ms()
 x, y, z, info = s.solution()
+if os.environ.get("SQPH_PT_SETUP") == "1":  # a -DSQPH_PT_SETUP=1 build: slots 3-6, 8 = sub-phases of the S phase
+    sub = {3: "S: clear panel", 4: "S: A'RA accumulate", 5: "S: P add + prefetch", 6: "S: barrier waits", 8: "S: pick-up"}
+elif os.environ.get("SQPH_PT_SETUP") == "2":  # -DSQPH_PT_SETUP=2: sub-phases of the sparse loading and the lane maps
+    sub = {3: "load_sparse", 4: "row lane map", 5: "column lane map", 6: "(before placement)", 8: "slot placement"}
+else:
+    sub = None
 names = ["load+maps", "form_S", "jacobi", "A'w", "stages", "x~", "A x~ + upd", "eliminate", "barrier", "total", "misc", "factor tail", "el: wait A", "el: phase A", "el: wait B", "el: phase B"]
 per_iter = ("A'w", "stages", "x~", "A x~ + upd", "barrier")
+if sub:
+    names = [sub.get(i, nm) for i, nm in enumerate(names)]
+    per_iter = ()
 t = x[:, :16].mean(axis=0)
 print(s.kernel_name(), "kernel ms", ms, "ticks of wave 0:")
 for nm, val in zip(names, t):
