@@ -9,15 +9,17 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.environ.get("SQPH_LIB") or os.path.join(LIBDIR, "libsqp_hip.so")  # SQPH_LIB: A/B-test another build
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+# Wave-uniform branches stay scalar branches (StructurizeCFG skips uniform regions).  Every kernel here is control flow on block-uniform
+# conditions around large register tiles; structurized, a conditional update of a tile keeps its old and its new copy live up to the
+# join.  Block-row sparse kernel: 160 spilled registers -> 0 and 21.4 -> 19.2 ms at config 5; C2 no-check kernel: 18 spilled registers
+# -> 0 (HBM traffic 88 -> 63 MB per launch); C3 kernels -1 % (profiles/r06_ab.txt)
+FLAGS += ["-mllvm", "-structurizecfg-skip-uniform-regions"]
 # extra compiler flags from the environment, e.g. SQPH_HIPCC_FLAGS=-DSQPH_LANE_NO_FMA for users who want the one-QP-per-lane kernel's
 # unfused multiplies / adds back (closer to the reference's unfused CPU arithmetic; the summation order of A'w is still the
 # kernel's two-chain one: admm_lane_kernel.h)
 FLAGS += os.environ.get("SQPH_HIPCC_FLAGS", "").split()
 # flags of single translation units (csrb.hip says why)
-# -structurizecfg-skip-uniform-regions: the block-row kernel's set-up is wave-uniform control flow around 14 eight-register blocks;
-# structurized, every conditional block update left an old and a new copy of ALL blocks live (224 of 256 VGPRs, 56 v_mov_b64 per
-# elimination step and slot, 160 spilled registers); with scalar branches left as they are the same source allocates without a spill
-CSB_FLAGS = ["-mllvm", "-simplifycfg-sink-common=false", "-mllvm", "-structurizecfg-skip-uniform-regions"]
+CSB_FLAGS = ["-mllvm", "-simplifycfg-sink-common=false"]
 UNIT_FLAGS = {"csrb.hip": CSB_FLAGS, "csrb_sp.hip": CSB_FLAGS}
 
 
