@@ -1278,10 +1278,10 @@ extern template int csr_nocheck_launch<float>(int, int, int, int, hipStream_t, c
 #ifdef SQPH_SLIM
 #define SQPH_CSRD_SHAPES(X) X(7)
 #else
-#define SQPH_CSRD_SHAPES(X) X(4) X(7)
+#define SQPH_CSRD_SHAPES(X) X(4) X(7) X(8)
 #endif
 // additional small edges for the host SIMT emulation in the CPU test-suite
-#define SQPH_CSR_SIM_SHAPES(X) X(1) X(2) X(4) X(7)
+#define SQPH_CSR_SIM_SHAPES(X) X(1) X(2) X(4) X(7) X(8)
 
 #ifdef SQPH_SIM
 template <typename TIN>

@@ -113,7 +113,7 @@ def test_grid_selection():
     """the lane grid each shape region takes (first fit in SQPH_WG_SHAPES; the stacked operator where m leaves room for W')"""
     for (n, m, name) in ((20, 40, "wg1_8x8_5x3"), (24, 96, "wg2_16x8_8x4_w3"), (32, 128, "wg2_16x8_8x4_w3"), (50, 100, "wg2_16x8_7x7s"), (56, 112, "wg2_16x8_7x7_"),
                          (60, 120, "wg4_16x16_8x4"), (100, 30, "wg4_16x16_2x7_w2"), (100, 100, "wg4_16x16_8x7_w2"), (100, 200, "wg8_32x16_7x7"), (50, 200, "wg4_32x8_7x7"),
-                         (50, 400, "wg8_64x8_7x7"), (130, 150, "cud_t7")):
+                         (50, 400, "wg8_64x8_7x7"), (130, 150, "cud_t7"), (250, 300, "cud_t8"), (256, 512, "cud_t8"), (257, 300, "generic"), (200, 513, "generic")):
         s = make_gpu(n, m, 2)
         s.settings.max_iter, s.settings.check_termination = 5, 0
         s.setup_solve(*[a[:2] for a in cases.random_qp_batch(2, n, m, seed=3)])
@@ -127,7 +127,7 @@ def test_dense_shapes_beyond_the_register_tiled_kernels():
     from sqp_solver_amd.problems import random_qp_batch
 
     for (n, m, b, kern) in ((120, 260, 4, "cud_t4"), (200, 400, 3, "cud_t7"), (50, 500, 3, "cud_t4"), (224, 512, 2, "cud_t7"), (113, 1, 3, "cud_t4"),
-                            (230, 100, 2, "generic"), (100, 520, 2, "generic")):
+                            (230, 100, 2, "cud_t8"), (250, 300, 3, "cud_t8"), (256, 512, 2, "cud_t8"), (260, 100, 2, "generic"), (100, 520, 2, "generic")):
         cases.parity_fixed_iters(make_gpu, n, m, b, iters=40)
         s = make_gpu(n, m, b)
         s.settings.max_iter, s.settings.check_termination = 5, 0
@@ -139,6 +139,41 @@ def test_dense_shapes_beyond_the_register_tiled_kernels():
     cases.warm_start_and_resolve(make_gpu, n=130, m=200)
     log, kernels = cases.api_sequence_fuzz(make_gpu, 224, 512, 2, seed=77, steps=6)
     assert any(k.startswith("cud_t7") for k in kernels), kernels
+    # 224 < n <= 256 (round 6: the tile edge 8 of the same kernel; before, these shapes fell to the generic kernel)
+    cases.parity_termination(make_gpu, 250, 300, 4, adaptive=True)
+    cases.parity_termination(make_gpu, 256, 512, 3, sqp_settings=True)
+    log, kernels = cases.api_sequence_fuzz(make_gpu, 256, 512, 2, seed=78, steps=6)
+    assert any(k.startswith("cud_t8") for k in kernels), kernels
+
+
+def test_dense_250_300_is_off_the_generic_kernel():
+    """The reference class is Eigen::Dynamic (include/solvers/qp.hpp:118-131): 64 x (n=250, m=300), 100 fixed iterations — 16.7 ms on the
+    generic kernel in round 5 (the CPU's rate), now the CU-wide kernel at tile edge 8: a generous bound on the kernel time guards the
+    route (measured 3.4 ms), the whole batch is compared with the oracle."""
+    from sqp_solver_amd.problems import random_qp_batch
+
+    n, m, B = 250, 300, 64
+    P, q, A, l, u = random_qp_batch(B, n, m, seed=41)
+    s = make_gpu(n, m, B)
+    s.settings.max_iter, s.settings.check_termination = 100, 0
+    s.setup_solve(P, q, A, l, u)
+    s.enable_timing(True)
+    for _ in range(3):
+        s.setup_solve(P, q, A, l, u)
+    ms = min(s.collect_kernel_ms()[-3:])
+    assert s.kernel_name().startswith("cud_t8"), s.kernel_name()
+    x, y, z, info = s.solution()
+    xo, yo, zo, io = oracle.solve_batch(P, q, A, l, u, cases.oracle_settings(s.settings), nthreads=0)
+    assert cases.relerr(x, xo) < cases.TOL_F64 and cases.relerr(y, yo) < cases.TOL_F64 and cases.relerr(z, zo) < cases.TOL_F64
+    print("64 x (250, 300), 100 iterations: %.2f ms" % ms)
+    assert ms < 6.0, ms
+
+
+def test_dense_300_600_on_the_generic_kernel():
+    """beyond n = 256 or m = 512 the generic kernel (matrices in global memory): 64 x (300, 600) against the oracle at a fixed iteration
+    count and under the default termination with adaptive rho"""
+    cases.parity_fixed_iters(make_gpu, 300, 600, 64, iters=50)
+    cases.parity_termination(make_gpu, 300, 600, 16, adaptive=True)
 
 
 def test_csr_reference_cases():
