@@ -86,7 +86,8 @@ struct CsbLayout {
     static constexpr int O_XS = 0;                  // [NB][BS] step J: L_IJ at I > J, W_JK at K < J
     static constexpr int O_TB = O_XS + NB * BS;     // [2][BS]  unscaled inverse of the current / next diagonal block
     static constexpr int O_MD = O_TB + 2 * BS;      // [2][BS]  the diagonal block handed to the eliminating wavefront, W_JJ on return
-    static constexpr int W_ELIM = O_MD + 2 * BS;
+    static constexpr int O_LP = O_MD + 2 * BS;      // [NW][BS] per wavefront: -L_IJ Winv_JJ on its way from the D layout to the A-operand layout
+    static constexpr int W_ELIM = O_LP + NW * BS;
     // [8 waves][8 values x 4 DPP rows][PWS] partial sums of y1 = W t.  Element j of row (v, lq) sits at (j + 4 v) mod 16 of a row of
     // PWS = 18 doubles: with plain rows of 16 the four ds_read_b128 of the reduction were 4-way bank conflicted (64 instead of 16 LDS
     // cycles; tools/xp/lds_bank_model.py finds this rotation + stride conflict-free for the reads and the eight ds_write_b64)
@@ -268,24 +269,6 @@ struct CsbKernel {
         const unsigned long long v = reinterpret_cast<unsigned long long>(p);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return reinterpret_cast<const P *>(((unsigned long long)hi << 32) | lo);
-#endif
-    }
-    // a use of every block register (no instruction): placed in the loop's sparse phases, whose many loads in flight would otherwise
-    // push the blocks — long live ranges with two uses per iteration, the allocator's favourite victims — out to scratch
-    static __device__ __forceinline__ void pin_blocks(const csb_blk (&B)[NB + 1]) {
-#ifndef SQPH_SIM
-#pragma unroll
-        for (int s = 0; s <= NB; s++) asm volatile("" ::"v"(B[s].v[0]), "v"(B[s].v[1]), "v"(B[s].v[2]), "v"(B[s].v[3]));
-#endif
-    }
-    // a copy the register coalescer cannot see through (an empty asm with a tied operand is joined into one live range again)
-    static __device__ __forceinline__ T split_range(T v) {
-#ifdef SQPH_SIM
-        return v;
-#else
-        T o;
-        asm volatile("v_mov_b64 %0, %1" : "=v"(o) : "v"(v));
-        return o;
 #endif
     }
     // orders the LDS operations of ONE wavefront for the compiler (the hardware executes a wavefront's LDS operations in order).
@@ -982,16 +965,15 @@ struct CsbKernel {
         wave_fence();
         stD(x, lr, lq, a);
     }
-    // W_JK = Winv_JJ E_JK of the row being finished (K < J), published in XS[K]
-    static __device__ __forceinline__ void finish_block(csb_blk &Bs, int K, T *XS, const T *Wd, int lr, int lq) {
+    // W_JK = Winv_JJ E_JK of the row being finished (K < J), in place (the D layout of a block is its B-operand layout)
+    static __device__ __forceinline__ void finish_block(csb_blk &Bs, const T *Wd, int lr, int lq) {
         csb_blk a = {{0, 0, 0, 0}};
         T av[4];
 #pragma unroll
         for (int kq = 0; kq < 4; kq++) av[kq] = opN(Wd, kq, lr, lq);
 #pragma unroll
-        for (int kq = 0; kq < 4; kq++) mfma16(av[kq], Bs.v[kq], a);  // the D layout of a block is its B-operand layout
+        for (int kq = 0; kq < 4; kq++) mfma16(av[kq], Bs.v[kq], a);
         Bs = a;
-        stD(XS + K * BS, lr, lq, a);
     }
     // look-ahead: the next diagonal block, updated now (with my own L_J+1,J) and handed to the eliminating wavefront
     static __device__ __forceinline__ void lookahead_block(csb_blk &Bs, int J, T *wk, int lr, int lq) {
@@ -1013,12 +995,14 @@ struct CsbKernel {
         // my panel blocks (I, J), I > J: slot J of row I1, slot NB - J of row I0
         if (I1 > J) dispatch<0, NB - 1>(J, [&](auto kc) __attribute__((always_inline)) { panel_block(B[decltype(kc)::value], I1, XS, Wd, lr, lq); });
         if (has0 && I0 > J) dispatch<0, KH>(J, [&](auto kc) __attribute__((always_inline)) { panel_block(B[NB - decltype(kc)::value], I0, XS, Wd, lr, lq); });
-        // the row J itself, if it is mine: W_JK for K < J, then W_JJ = Winv_JJ D_J from the eliminating wavefront
+        // the row J itself, if it is mine: its blocks E_JK (K < J) are published AS THEY ARE — the other rows multiply by
+        // (L_IJ Winv_JJ) E_JK instead of L_IJ (Winv_JJ E_JK), so that the J products W_JK = Winv_JJ E_JK of this row are not on every
+        // wavefront's way to the trailing update: they follow in elim_B — and W_JJ = Winv_JJ D_J comes from the eliminating wavefront
         if (I1 == J) {
             static_while<0, NB - 1>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int K = decltype(kc)::value;
                 if (K >= J) return false;
-                finish_block(B[K], K, XS, Wd, lr, lq);
+                stD(XS + K * BS, lr, lq, B[K]);
                 return true;
             });
             dispatch<0, NB - 1>(J, [&](auto kc) __attribute__((always_inline)) { ldD(wk + Lay::O_MD + (J & 1) * BS, lr, lq, B[decltype(kc)::value]); });
@@ -1026,7 +1010,7 @@ struct CsbKernel {
             static_while<0, KH>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int K = decltype(kc)::value;
                 if (K >= J) return false;
-                finish_block(B[NB - K], K, XS, Wd, lr, lq);
+                stD(XS + K * BS, lr, lq, B[NB - K]);
                 return true;
             });
             dispatch<0, KH>(J, [&](auto kc) __attribute__((always_inline)) { ldD(wk + Lay::O_MD + (J & 1) * BS, lr, lq, B[NB - decltype(kc)::value]); });
@@ -1035,56 +1019,84 @@ struct CsbKernel {
         if (I1 == J + 1) dispatch<0, NB - 1>(J + 1, [&](auto kc) __attribute__((always_inline)) { lookahead_block(B[decltype(kc)::value], J, wk, lr, lq); });
         else if (has0 && I0 == J + 1) dispatch<0, KH>(J + 1, [&](auto kc) __attribute__((always_inline)) { lookahead_block(B[NB - decltype(kc)::value], J, wk, lr, lq); });
     }
-    // the trailing update of one block (I, K) of a row I > J: E_IK -= L_IJ W_JK (K < J: W_JK read transposed), E_IJ = -L_IJ Winv_JJ D_J,
-    // M_IK -= L_IJ L_KJ' (K > J); `av` = -L_IJ as the A-operand.  K is a compile-time constant: the operand's block is an immediate offset,
-    // and whether it is read transposed is a select between two lane offsets (no branch between the two common cases)
+    // Trailing update of a row I > J.  First its block in column J: a = -L_IJ Winv_JJ, E_IJ = a D_J; `a` also goes through the wavefront's
+    // private LDS block from the D layout to the A-operand layout (avp).  Then block by block, K a compile-time constant (the operand's
+    // block is an immediate offset; which operands a block takes are selects, no branch between the two common cases):
+    //   K < J:  E_IK += (-L_IJ Winv_JJ) E_JK     (A-operand avp, E_JK read transposed from XS[K] where row J's owner left it)
+    //   K > J:  M_IK += (-L_IJ) L_KJ'            (A-operand av = -L_IJ)
+    static __device__ __forceinline__ void pivot_block(csb_blk &Bs, const T (&av)[4], T (&avp)[4], const T *Wd, T *xp, T dc, int lr, int lq) {
+        csb_blk a = {{0, 0, 0, 0}};
+        T bv[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) bv[kq] = opT(Wd, kq, lr, lq);
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
+#pragma unroll
+        for (int e = 0; e < 4; e++) Bs.v[e] = a.v[e] * dc;
+        wave_fence();
+        stD(xp, lr, lq, a);
+        wave_fence();
+#pragma unroll
+        for (int kq = 0; kq < 4; kq++) avp[kq] = opN(xp, kq, lr, lq);
+    }
     template <int K>
-    static __device__ __forceinline__ void update_block(csb_blk &Bs, int I, int J, const T (&av)[4], const T *XS, const T *Wd, T dc, int lr, int lq) {
-        if (K == J) {
-            csb_blk a = {{0, 0, 0, 0}};
-            T bv[4];
-#pragma unroll
-            for (int kq = 0; kq < 4; kq++) bv[kq] = opT(Wd, kq, lr, lq);
-#pragma unroll
-            for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], a);
-#pragma unroll
-            for (int e = 0; e < 4; e++) Bs.v[e] = a.v[e] * dc;
-        } else if (!(I == J + 1 && K == J + 1)) {  // (that one is the look-ahead's)
+    static __device__ __forceinline__ void update_block(csb_blk &Bs, int I, int J, const T (&av)[4], const T (&avp)[4], const T *XS, int lr, int lq) {
+        if (K != J && !(I == J + 1 && K == J + 1)) {  // (column J was pivot_block's; block (J + 1, J + 1) is the look-ahead's)
             const bool tr = K < J;
             const T *b = XS + K * BS + (tr ? lq * 17 + lr : lr * 17 + lq);
             const int st = tr ? 4 * 17 : 4;
-            T bv[4];
+            T bv[4], aa[4];
 #pragma unroll
-            for (int kq = 0; kq < 4; kq++) bv[kq] = b[kq * st];  // == opT / opN (XS + K BS, kq, lr, lq)
+            for (int kq = 0; kq < 4; kq++) {
+                bv[kq] = b[kq * st];  // == opT / opN (XS + K BS, kq, lr, lq)
+                aa[kq] = tr ? avp[kq] : av[kq];
+            }
 #pragma unroll
-            for (int kq = 0; kq < 4; kq++) mfma16(av[kq], bv[kq], Bs);
+            for (int kq = 0; kq < 4; kq++) mfma16(aa[kq], bv[kq], Bs);
         }
     }
-    static __device__ __forceinline__ void elim_B(int W, int J, csb_blk (&B)[NB + 1], const T *wk, const T *sj, int lr, int lq) {
+    static __device__ __forceinline__ void elim_B(int W, int J, csb_blk (&B)[NB + 1], T *wk, const T *sj, int lr, int lq) {
         const T *XS = wk + Lay::O_XS;
         const T *Wd = wk + Lay::O_TB + (J & 1) * BS;
+        T *xp = wk + Lay::O_LP + W * BS;
         const T dc = sj[16 * J + lr];
         const int I1 = NB - 1 - W, I0 = W;
         constexpr int KH = (NB - 1) / 2;
         if (I1 > J) {
-            T av[4];
+            T av[4], avp[4];
 #pragma unroll
             for (int kq = 0; kq < 4; kq++) av[kq] = -opN(XS + I1 * BS, kq, lr, lq);
+            dispatch<0, NB - 1>(J, [&](auto kc) __attribute__((always_inline)) { pivot_block(B[decltype(kc)::value], av, avp, Wd, xp, dc, lr, lq); });
             static_while<0, NB - 1>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int K = decltype(kc)::value;
                 if (K > I1) return false;
-                update_block<K>(B[K], I1, J, av, XS, Wd, dc, lr, lq);
+                update_block<K>(B[K], I1, J, av, avp, XS, lr, lq);
+                return true;
+            });
+        } else if (I1 == J) {  // my row J is finished here, off the other rows' way: W_JK = Winv_JJ E_JK
+            static_while<0, NB - 1>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                if (K >= J) return false;
+                finish_block(B[K], Wd, lr, lq);
                 return true;
             });
         }
         if (I0 < I1 && I0 > J) {
-            T av[4];
+            T av[4], avp[4];
 #pragma unroll
             for (int kq = 0; kq < 4; kq++) av[kq] = -opN(XS + I0 * BS, kq, lr, lq);
+            dispatch<0, KH>(J, [&](auto kc) __attribute__((always_inline)) { pivot_block(B[NB - decltype(kc)::value], av, avp, Wd, xp, dc, lr, lq); });
             static_while<0, KH>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int K = decltype(kc)::value;
                 if (K > I0) return false;
-                update_block<K>(B[NB - K], I0, J, av, XS, Wd, dc, lr, lq);
+                update_block<K>(B[NB - K], I0, J, av, avp, XS, lr, lq);
+                return true;
+            });
+        } else if (I0 < I1 && I0 == J) {
+            static_while<0, KH>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value;
+                if (K >= J) return false;
+                finish_block(B[NB - K], Wd, lr, lq);
                 return true;
             });
         }
@@ -1153,6 +1165,15 @@ struct CsbKernel {
             __syncthreads();
             SQPH_FTICK(12)
             elim_A(wj, NB - 1, B, wk, lj & 15, lj >> 4);
+            {   // (no trailing update behind the last step: the last row's W_JK = Winv_JJ E_JK here)
+                const T *Wd = wk + Lay::O_TB + ((NB - 1) & 1) * BS;
+                if (wj == 0) {  // row NB - 1 is wavefront 0's first row
+                    static_while<0, NB - 2>([&](auto kc) __attribute__((always_inline)) {
+                        finish_block(B[decltype(kc)::value], Wd, lj & 15, lj >> 4);
+                        return true;
+                    });
+                }
+            }
             SQPH_FTICK(13)
         }
         __syncthreads();
@@ -1282,11 +1303,9 @@ struct CsbKernel {
                 __syncthreads();
                 SQPH_ITICK(8)
                 {   // t = (sigma x - q) + A' w
-                    pin_blocks(B);
                     const T s = creg ? reg_dot(cv, ci, wv, cmap) : csc_col_dot_lds(colptr, csc, val, wv, cmap);
                     const int j = cmap & 511;
                     if ((cmap & MAP_VALID) && ((cmap >> 9) & 7) == 0) tv[j] = ux[j] + s;
-                    pin_blocks(B);
                 }
                 __syncthreads();
                 SQPH_ITICK(3)
@@ -1315,7 +1334,6 @@ struct CsbKernel {
                 __syncthreads();
                 SQPH_ITICK(5)
                 {   // z~ = A x~ ; z, y updates (qp.cpp:99-103, 278-281)
-                    pin_blocks(B);
                     const T zt = rreg ? reg_dot(rv, ri, xt, rmap) : csr_row_dot_lds(rowptr, col, val, xt, rmap);
                     if (lead) {
                         const T z = zs[im], y = ys[im], rho = rhov[im], rinv = rinvv[im];
@@ -1329,7 +1347,6 @@ struct CsbKernel {
                         ys[im] = yn;
                         wv[im] = rho * (zn - rinv * yn);  // next iteration's w (read after the loop-top barrier)
                     }
-                    pin_blocks(B);
                 }
                 SQPH_ITICK(6)
                 }
@@ -1660,14 +1677,6 @@ struct CsbKernel {
             }
             // (re)load the sparse slices: the work area they border on was used by the set-up; w, u of the first iteration
             __syncthreads();
-            // the blocks start new live ranges here: whatever the set-up's register pressure made the allocator do with them, the
-            // iteration loop gets them in registers
-            if constexpr (!CHECKS) {
-#pragma unroll
-                for (int s = 0; s <= NB; s++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) B[s].v[e] = split_range(B[s].v[e]);
-            }
             SlotCode rsc{0, 0}, csc_{0, 0};
             {   // slots of the register-resident slices (the work area is idle; per half-wavefront tables, no workgroup barrier inside)
                 unsigned *area = reinterpret_cast<unsigned *>(lds);
