@@ -31,6 +31,21 @@ __device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int
         for (int r = tid; r < R; r += nt) {
             T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             int k = 0;
+            // eight loads requested before the first is used (the matrices of these shapes stream from L2 / the Infinity Cache: with
+            // four in flight per lane a 1,024-lane workgroup moved 15 GB/s); the chains a0 .. a3 and their order are unchanged
+            for (; k + 7 < K; k += 8) {
+                T mv[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) mv[e] = (T)M[(long)(k + e) * ld + r];
+                a0 += mv[0] * v[k];
+                a1 += mv[1] * v[k + 1];
+                a2 += mv[2] * v[k + 2];
+                a3 += mv[3] * v[k + 3];
+                a0 += mv[4] * v[k + 4];
+                a1 += mv[5] * v[k + 5];
+                a2 += mv[6] * v[k + 6];
+                a3 += mv[7] * v[k + 7];
+            }
             for (; k + 3 < K; k += 4) {
                 a0 += (T)M[(long)k * ld + r] * v[k];
                 a1 += (T)M[(long)(k + 1) * ld + r] * v[k + 1];
@@ -50,6 +65,16 @@ __device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int
     T a0 = 0, a1 = 0;
     if (g < G) {
         int k = g;
+        for (; k + 7 * G < K; k += 8 * G) {  // (eight loads in flight; the two chains keep their terms and order)
+            T mv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) mv[e] = (T)M[(long)(k + e * G) * ld + r];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                a0 += mv[e] * v[k + e * G];
+                a1 += mv[e + 1] * v[k + (e + 1) * G];
+            }
+        }
         for (; k + G < K; k += 2 * G) {
             a0 += (T)M[(long)k * ld + r] * v[k];
             a1 += (T)M[(long)(k + G) * ld + r] * v[k + G];
@@ -76,13 +101,83 @@ __device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int
 // column k holds -l_ik, later steps apply their row operations to it as well; the "+1" on the pivot
 // position of the broadcast row makes the generic rank-1 update write that entry (pivots are <= 1
 // after the scaling, so there is no cancellation).
-// Wm: n*n col-major result W; Wt: n*n row-major copy (W' with coalesced rows). row/sj/dsv: LDS [n].
+// Wm: n*n col-major result W; Wt: n*n row-major copy (W' with coalesced rows). row/sj/dsv: LDS [n]; stage: LDS [8 nt].
 // Returns false (block-uniform) on a non-positive / non-finite pivot  => NUMERICAL_ISSUES.
+#ifdef SQPH_SIM
+#define SQPH_GENERIC_NOINLINE
+#else
+#define SQPH_GENERIC_NOINLINE __attribute__((noinline))  // (three call sites; a real call keeps the set-up's registers out of the iteration loop's allocation)
+#endif
 template <typename T, typename TIN>
-__device__ bool factor_schur(int n, int m, const TIN *__restrict__ P, const T *__restrict__ At, const T *rho, T sigma,
-                             T *__restrict__ Wm, T *__restrict__ Wt, T *row, T *sj, T *dsv) {
+__device__ SQPH_GENERIC_NOINLINE bool factor_schur(int n, int m, const TIN *__restrict__ P, const T *__restrict__ At, const T *rho, T sigma,
+                             T *__restrict__ Wm, T *__restrict__ Wt, T *row, T *sj, T *dsv, T *stage) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int nn = n * n;
+    // S through LDS: KB rows of At at a time in `stage` (the idle reduction scratch, 8 nt elements); a thread owns row i of a block of four
+    // columns (a "unit": one LDS read of At[k][i] and four broadcast reads of At[k][j..j+3] per four products) and up to U = 2 units per
+    // pass, all of a pass's sums in registers across the whole k range — every entry is still the two chains s0 (even k) + s1 (odd k) of
+    // (At[k][i] rho_k) At[k][j], bit for bit what the entry-by-entry loop over global memory computed (13 of this set-up's 18 ms at n = 300)
+    int KB = (8 * nt) / (n > 0 ? n : 1);
+    KB = KB > 16 ? 16 : (KB & ~1);
+    if (KB >= 2) {
+        constexpr int U = 2;  // (two units = 16 sums per pass: the kernel is compiled for 1,024 lanes, 128 VGPRs)
+        const int JB = (n + 3) >> 2;
+        const long units = (long)n * JB;
+        for (long u0 = 0; u0 < units; u0 += (long)nt * U) {
+            int ui[U], uj[U];
+            T s0[U][4], s1[U][4];
+#pragma unroll
+            for (int q = 0; q < U; q++) {
+                const long u = u0 + (long)q * nt + tid;
+                const bool ok = u < units;
+                const int jb = ok ? (int)(u / n) : 0;
+                ui[q] = ok ? (int)(u - (long)jb * n) : -1;
+                uj[q] = 4 * jb;
+#pragma unroll
+                for (int c = 0; c < 4; c++) s0[q][c] = s1[q][c] = T(0);
+            }
+            for (int k0 = 0; k0 < m; k0 += KB) {
+                __syncthreads();
+                for (int e = tid; e < KB * n; e += nt) {
+                    const int kk = e / n, c = e - kk * n;
+                    stage[e] = (k0 + kk < m) ? At[(long)(k0 + kk) * n + c] : T(0);
+                }
+                __syncthreads();
+                const int kb = (m - k0 < KB) ? m - k0 : KB;
+                for (int kk = 0; kk < kb; kk += 2) {  // (a row beyond m is staged as zeros: its products add +0 to s1)
+                    const T *r0 = stage + kk * n, *r1 = r0 + n;
+                    const T rh0 = rho[k0 + kk];
+                    const T rh1 = kk + 1 < kb ? rho[k0 + kk + 1] : T(0);
+#pragma unroll
+                    for (int q = 0; q < U; q++) {
+                        const int iq = ui[q] >= 0 ? ui[q] : 0;
+                        const T a0 = r0[iq] * rh0, a1 = r1[iq] * rh1;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const int jj = uj[q] + c < n ? uj[q] + c : n - 1;
+                            s0[q][c] += a0 * r0[jj];
+                            s1[q][c] += a1 * r1[jj];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < U; q++) {
+                if (ui[q] >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int i = ui[q], jj = uj[q] + c;
+                        if (jj < n) {
+                            const int lo = i > jj ? i : jj, hi = i > jj ? jj : i;
+                            // only the lower triangle of P reaches the reference's factor (Eigen::LDLT<.,Lower>, qp.hpp:129)
+                            const T acc = (T)P[(long)hi * n + lo] + (i == jj ? sigma : T(0));
+                            Wm[(long)jj * n + i] = acc + (s0[q][c] + s1[q][c]);
+                        }
+                    }
+                }
+            }
+        }
+    } else
     for (int e = tid; e < nn; e += nt) {
         const int j = e / n, i = e - j * n;
         const int lo = i > j ? i : j, hi = i > j ? j : i;
@@ -121,11 +216,27 @@ __device__ bool factor_schur(int n, int m, const TIN *__restrict__ P, const T *_
         if (!(d > T(0)) || !(d * T(0) == T(0))) return false;
         const T dinv = T(1) / d;
         if (tid == 0) dsv[k] = d;
-        for (int e = tid; e < nn; e += nt) {
-            const int j = e / n, i = e - j * n;
-            if (i > k) {
-                const T g = (j == k) ? d + T(1) : row[j];
-                Wm[e] = Wm[e] - (row[i] * dinv) * g;
+        // rows i > k of every column, 64 lanes down a column (the same update entry by entry as a sweep over all n^2 entries with a
+        // division and a test each — which was most of this kernel's set-up: 20 ms at n = 300)
+        {
+            const int jl = tid >> 6, JS = nt >> 6;
+            for (int i0 = k + 1; i0 < n; i0 += 64) {
+                const int i = i0 + (tid & 63);
+                const bool iok = i < n;
+                const T li = iok ? row[i] * dinv : T(0);
+                for (int j0 = jl; j0 < n; j0 += 4 * JS) {  // four columns' entries requested before the first is updated
+                    T v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int j = j0 + c * JS;
+                        v[c] = (iok && j < n) ? Wm[(long)j * n + i] : T(0);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int j = j0 + c * JS;
+                        if (iok && j < n) Wm[(long)j * n + i] = v[c] - li * ((j == k) ? d + T(1) : row[j]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -238,7 +349,7 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
             At[e] = (T)gA[(long)j * m + i];
         }
         __syncthreads();
-        const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, a.sigma, Wm, Wt, gjrow, gjcol, Px);
+        const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, a.sigma, Wm, Wt, gjrow, gjcol, Px, part);
         __syncthreads();
         info.status = ok ? SQPH_UNSOLVED : SQPH_NUMERICAL_ISSUES;
     } else {
@@ -258,7 +369,7 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
                 At[e] = (T)gA[(long)j * m + i];
             }
             __syncthreads();
-            const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, a.sigma, Wm, Wt, gjrow, gjcol, Px);
+            const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, a.sigma, Wm, Wt, gjrow, gjcol, Px, part);
             __syncthreads();
             if (!ok) info.status = SQPH_NUMERICAL_ISSUES;
         }
@@ -362,7 +473,7 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
                         }
                         info.rho_updates += 1;
                         __syncthreads();
-                        const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, sigma, Wm, Wt, gjrow, gjcol, Px);
+                        const bool ok = factor_schur<T, TIN>(n, m, gP, At, rho, sigma, Wm, Wt, gjrow, gjcol, Px, part);
                         __syncthreads();
                         if (!ok) {
                             info.status = SQPH_NUMERICAL_ISSUES;
