@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(1024) void admm_csrd_nocheck_kernel(CsrLaunch<TIN> 
     SQPH_DYN_SMEM(smem_raw);
     CsrKernel<TIN, TT>::template run<false, true>(p.a, p.ca, smem_raw);
 }
-// > 0 launched, 0 shape not covered (n > 224 or m > 512), < 0 HIP error
+// > 0 launched, 0 shape not covered (n > 256 or m > 512), < 0 HIP error
 template <typename TIN>
 int csrd_try_launch(const KArgs<double, TIN> &a, hipStream_t stream, const char **name);
 extern template int csrd_try_launch<double>(const KArgs<double, double> &, hipStream_t, const char **);
@@ -1274,7 +1274,7 @@ extern template int csr_nocheck_launch<float>(int, int, int, int, hipStream_t, c
 #else
 #define SQPH_CSR_SHAPES(X) X(4) X(7)
 #endif
-// tile edges of the dense-A mode (csr_dense.hip): problems with n <= 128 that the register-tiled kernels do not take (m too large) and n <= 224
+// tile edges of the dense-A mode (csr_dense.hip): problems with n <= 128 that the register-tiled kernels do not take (m too large), n <= 224 and n <= 256
 #ifdef SQPH_SLIM
 #define SQPH_CSRD_SHAPES(X) X(7)
 #else

@@ -16,6 +16,11 @@
 //     per entry instead of an index load and two gathers.
 // Iteration (reference src/qp.cpp:84-103 on the Schur-ordered system; four workgroup barriers):
 //     t = (sigma x - q) + A' w  |  y1 = W t ; x~ partials = W' y1  |  x~, x  |  z~ = A x~ ; z, y ; w = rho z - y
+// Code generation (round 6): csrb.hip / csrb_sp.hip are compiled with -mllvm -structurizecfg-skip-uniform-regions (build.py: CSB_FLAGS).
+// All control flow of the set-up is wave-uniform; structurized, every conditional update of a block kept an old and a new copy of all
+// NB + 1 blocks live (224 of 256 VGPRs, 160 spilled registers, 56 v_mov_b64 per slot and elimination step).  A block's column is a
+// compile-time function of its slot (Own / slot_of), and a step reaches its blocks through dispatch() / static_while() — a taken branch
+// per skipped slot body was ~100 cycles.  The no-check instantiation has no scratch access; profiles/r06_ab.txt has the steps.
 // Numerics: the formulas of admm_csr_kernel.h / admm_generic.h, fp64 arithmetic, TIN inputs.
 // Requirements checked by the host: n <= 16 NB, m <= 512, CSR rows sorted by column without duplicates, everything within LDS.
 // A QP whose rows (columns) need more than KR entries per lane takes the LDS form of that sparse product (block-uniform branch).
@@ -29,7 +34,7 @@
 #endif
 
 #ifndef SQPH_CSB_EB
-#define SQPH_CSB_EB 3  // CSC entries of a column accumulated per batch in the S phase (1 / 2 / 3 / 4 measured: 21.95 / 21.55 / 21.51 / 21.60 ms; 6.7 / 6.2 / 6.2 / 6.9 GB of traffic)
+#define SQPH_CSB_EB 3  // CSC entries of a column accumulated per batch in the S phase (round 6: 3 / 4 / 6 / 8 measured 19.43 / 19.42 / 19.58 / 19.55 ms)
 #endif
 #ifndef SQPH_CSB_PLACE_MIN_ITERS
 #define SQPH_CSB_PLACE_MIN_ITERS 150  // settings.max_iter from which the register-resident slices are placed (CsbKernel::run)

@@ -766,7 +766,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
         if (launched) launched_by('t', a.mode);
     }
     if (!launched && !verbose && !(s->flags & SQPH_FLAG_FORCE_GENERIC)) {
-        // dense problems beyond the register-tiled shapes, n <= 224 and m <= 512: W in the CU's registers, A streamed (csr_dense.hip)
+        // dense problems beyond the register-tiled shapes, n <= 256 and m <= 512: W in the CU's registers, A streamed (csr_dense.hip)
         a.mode = for_family('c');
         const int rc = csrd_try_launch<TIN>(a, s->stream, &s->kernel_name);
         if (rc < 0) SQPH_FAIL(s, SQPH_ERR_HIP, "dense CU-wide kernel launch failed: %s", hipGetErrorString(hipGetLastError()));

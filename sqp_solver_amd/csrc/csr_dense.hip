@@ -1,5 +1,5 @@
 // The CU-wide kernel (admm_csr_kernel.h) in its dense-A mode, CsrKernel::run<CHECKS, DENSE = true>: dense problems beyond the
-// register-tiled kernels' shapes — 112 < n <= 224, or m beyond their row counts, m <= 512 — keep the factor W in the CU's register file
+// register-tiled kernels' shapes — 112 < n <= 256 (tile edge 8 since round 6: 224 < n <= 256), or m beyond their row counts, m <= 512 — keep the factor W in the CU's register file
 // and stream the column-major A from global memory twice per iteration.  A translation unit of its own: the code generated for the
 // sparse kernels does not depend on these being instantiated next to them.
 #include <hip/hip_runtime.h>

@@ -2,7 +2,8 @@
 // compiled with -mllvm -simplifycfg-sink-common=false (sqp_solver_amd/build.py: UNIT_FLAGS): the kernel switches on its wavefront index
 // into per-wavefront specialisations that update different slots of the block register array; sinking the specialisations' last
 // stores into their common successor turns them into stores through a selected ADDRESS, which keeps those slots in scratch memory
-// for the whole kernel (ten doubles per lane, reloaded twice per iteration: 62 instead of 30 ms at BASELINE config 5).
+// for the whole kernel (ten doubles per lane, reloaded twice per iteration: 62 instead of 30 ms at BASELINE config 5).  And with
+// -mllvm -structurizecfg-skip-uniform-regions: the wave-uniform branches of the set-up stay scalar branches (admm_csrb_kernel.h).
 #include <hip/hip_runtime.h>
 
 #include "admm_csrb_kernel.h"
