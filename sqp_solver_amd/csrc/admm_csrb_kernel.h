@@ -1366,34 +1366,20 @@ struct CsbKernel {
     // with the sparse products read from LDS and P streamed from global memory; every lane of the workgroup calls this.
     // PRIMAL FIRST, like the dense kernels: the dual half — A'y and above all P x, 8 n^2 bytes streamed per QP (2.6 GB per batch-wide
     // check at config 5) — only runs when the primal test passes or the caller needs it (rho adaptation; the last check a solve can
-    // reach, whose residuals a MAX_ITER_EXCEEDED solve reports).  Returns whether v[3..6] were computed.
-    // SP (P in compressed columns, see form_S): gP_ is the value array and px... = (column pointers, row indices) — a trailing pack,
-    // so that the dense instantiation's signature (a real call) stays what it was.
-#ifdef SQPH_SIM
-    template <bool SP = false, typename... PX>
-    static inline bool residuals(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int rmap, int cmap, bool lead, int im,
-                                 bool nown, T eps_abs, T eps_rel, bool force_dual, T (&v)[7], PX... px) {
-#else
-    template <bool SP = false, typename... PX>
-    // (stays a real call: inlined, config 5 under the reference defaults gains 3 % and under the SQP driver's settings loses 35 %)
-    static __device__ __attribute__((noinline)) bool residuals(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int rmap,
-                                                                int cmap, bool lead, int im, bool nown, T eps_abs, T eps_rel, bool force_dual,
-                                                                T (&v)[7], PX... px) {
-#endif
-        const int n = uniform_int(n_);
-        const TIN *__restrict__ gP = uniform_ptr(gP_);
+    // reach, whose residuals a MAX_ITER_EXCEEDED solve reports): primal_part() then dual_part().
+    // SP (P in compressed columns, see form_S): gP_ is the value array and px... = (column pointers, row indices) — a trailing pack.
+    // The primal half, inline in the solve loop (a sparse product from LDS and three maxima: a dozen registers): most checks of a solve fail
+    // the primal test, and the call of the dual half costs its caller the registers that are live across it (~0.9 GB of scratch traffic
+    // per batch-wide check at config 5).  Leaves x in xt and y in wv for the dual half; v[0..2] = |Ax|, |z|, |Ax - z|.
+    static __device__ __forceinline__ void primal_part(const Lay &L, unsigned char *smem, int rmap, bool lead, int im, bool nown, T (&v)[7]) {
         const int t = threadIdx.x, wave = wave_of(t), l = t & 63;
-        (void)smem;
-        SQPH_DYN_SMEM(smem_l);  // (the LDS-qualified base: through the pointer argument the accesses would be flat ones)
-        T *lds = reinterpret_cast<T *>(smem_l);
-        const int *li = reinterpret_cast<const int *>(smem_l);
-        const int *rowptr = li + uniform_int(L.o_rowptr), *colptr = li + Lay::o_colptr;
-        const unsigned *csc = reinterpret_cast<const unsigned *>(li + uniform_int(L.o_csc));
-        const unsigned short *col = reinterpret_cast<const unsigned short *>(li + uniform_int(L.o_col));
-        const T *val = lds + uniform_int(L.o_val);
-        T *tv = lds + Lay::o_t, *xt = lds + Lay::o_xt, *qv = lds + Lay::o_qv, *wv = lds + uniform_int(L.o_wv), *xv = lds + Lay::o_xv;
-        T *zs = lds + uniform_int(L.o_zs), *ys = lds + uniform_int(L.o_ys), *pw = lds + Lay::O_PW;
-        T *red = lds + Lay::o_red;
+        T *lds = reinterpret_cast<T *>(smem);
+        const int *li = reinterpret_cast<const int *>(smem);
+        const int *rowptr = li + L.o_rowptr;
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(li + L.o_col);
+        const T *val = lds + L.o_val;
+        T *xt = lds + Lay::o_xt, *wv = lds + L.o_wv, *xv = lds + Lay::o_xv;
+        T *zs = lds + L.o_zs, *ys = lds + L.o_ys, *red = lds + Lay::o_red;
         __syncthreads();
         if (t < NP) xt[t] = nown ? xv[t] : T(0);
         if (lead) wv[im] = ys[im];
@@ -1421,10 +1407,30 @@ struct CsbKernel {
             for (int k = 1; k < 8; k++) mval = nanmax(mval, red[e * 8 + k]);
             v[e] = mval;
         }
-        if (!force_dual && !(v[2] <= eps_abs + eps_rel * nanmax(v[0], v[1]))) {  // (block-uniform)
-            __syncthreads();
-            return false;
-        }
+    }
+    // The dual half (a real call): v[3..6] = |Px|, |A'y|, |q|, |Px + q + A'y|
+#ifdef SQPH_SIM
+    template <bool SP = false, typename... PX>
+    static inline void dual_part(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int cmap, bool nown, T (&v)[7], PX... px) {
+#else
+    template <bool SP = false, typename... PX>
+    // (stays a real call: inlined, config 5 under the reference defaults gains 3 % and under the SQP driver's settings loses 35 %)
+    static __device__ __attribute__((noinline)) void dual_part(const TIN *__restrict__ gP_, int n_, const Lay &L, unsigned char *smem, int cmap,
+                                                                bool nown, T (&v)[7], PX... px) {
+#endif
+        const int n = uniform_int(n_);
+        const TIN *__restrict__ gP = uniform_ptr(gP_);
+        const int t = threadIdx.x, wave = wave_of(t), l = t & 63;
+        (void)smem;
+        SQPH_DYN_SMEM(smem_l);  // (the LDS-qualified base: through the pointer argument the accesses would be flat ones)
+        T *lds = reinterpret_cast<T *>(smem_l);
+        const int *li = reinterpret_cast<const int *>(smem_l);
+        const int *colptr = li + Lay::o_colptr;
+        const unsigned *csc = reinterpret_cast<const unsigned *>(li + uniform_int(L.o_csc));
+        const T *val = lds + uniform_int(L.o_val);
+        T *tv = lds + Lay::o_t, *xt = lds + Lay::o_xt, *qv = lds + Lay::o_qv, *wv = lds + uniform_int(L.o_wv);
+        T *pw = lds + Lay::O_PW;
+        T *red = lds + Lay::o_red;
         {   // A' y by the column map's lanes, handed to the lanes that track x through tv
             const T sATy = csc_col_dot_lds(colptr, csc, val, wv, cmap);
             if ((cmap & MAP_VALID) && ((cmap >> 9) & 7) == 0) tv[cmap & 511] = sATy;
@@ -1483,7 +1489,6 @@ struct CsbKernel {
             v[e] = mval;
         }
         __syncthreads();
-        return true;
     }
 
     // CHECKS = false: the instantiation for calls that never look at the residuals (check_termination == 0, no adaptive rho)
@@ -1738,14 +1743,18 @@ struct CsbKernel {
                     }
                 }
                 if (CHECKS && (check || adapt)) {
-                    // update_state + residuals, qp.cpp:316-331, 353-361 — OUT OF LINE (residuals() is a real call): inlined, the block's
-                    // registers (P streamed eight loads deep, both sparse products, seven reductions) were part of the iteration loop's
-                    // allocation problem, and the register-resident slices of A lived in scratch for the whole solve
+                    // update_state + residuals, qp.cpp:316-331, 353-361: the primal half inline, the dual half (P streamed eight loads
+                    // deep, A'y, four more reductions) OUT OF LINE — a real call, only when the primal test passes or the caller needs it
                     T v[7];
                     const bool last_check = check && iter + a.check_termination > a.max_iter;
-                    bool dual;
-                    if constexpr (SP) dual = residuals<true>(gP, n, L, smem, rmap, cmap, lead, im, nown, (T)a.eps_abs, (T)a.eps_rel, adapt || last_check, v, pcol, prow);
-                    else dual = residuals(gP, n, L, smem, rmap, cmap, lead, im, nown, (T)a.eps_abs, (T)a.eps_rel, adapt || last_check, v);
+                    primal_part(L, smem, rmap, lead, im, nown, v);
+                    const bool dual = adapt || last_check || (v[2] <= (T)a.eps_abs + (T)a.eps_rel * nanmax(v[0], v[1]));  // (block-uniform)
+                    if (dual) {
+                        if constexpr (SP) dual_part<true>(gP, n, L, smem, cmap, nown, v, pcol, prow);
+                        else dual_part(gP, n, L, smem, cmap, nown, v);
+                    } else {
+                        __syncthreads();
+                    }
                     const T nrm_prim = nanmax(v[0], v[1]);
                     const T nrm_dual = nanmax(v[3], nanmax(v[4], v[5]));
                     info.res_prim = (double)v[2];

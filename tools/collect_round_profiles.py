@@ -9,11 +9,14 @@ if phase == "bench":
     print("bench lines copied")
     sys.exit(0)
 KERNELS = {"c3": "wg2_16x8_7x7s_w2", "c3_default": "wg2_16x8_7x7s_w2", "c3_sqp": "wg2_16x8_7x7s_w2", "c2": "wg1_8x8_5x3_w3", "c5": "csb_nb13", "c5_sp": "csb_nb13_sp", "lane": "lane_2x3_exact",
-           "c3_full": "wg2_16x8_7x7s_w2", "c3_f32": "wg2_16x8_7x7s_w2_f32", "c2_f32": "wg1_8x8_5x3_w3_f32"}
+           "c3_full": "wg2_16x8_7x7s_w2", "c3_f32": "wg2_16x8_7x7s_w2_f32", "c2_f32": "wg1_8x8_5x3_w3_f32",
+           "c5_default": "csb_nb13", "c5_sqp": "csb_nb13", "c5_sp_default": "csb_nb13_sp", "c5_sp_sqp": "csb_nb13_sp", "c3_fixed98": "wg2_16x8_7x7s_w2"}
 W = {  # name -> (n, m, batch, mode)
     "c3": (50, 100, 8192, "fixed"), "c3_default": (50, 100, 8192, "default"), "c3_sqp": (50, 100, 8192, "sqp"),
     "c2": (20, 40, 4096, "fixed"), "c5": (200, 400, 8192, "fixed"), "c5_sp": (200, 400, 8192, "fixed"), "lane": (2, 3, 65536, "fixed"),
     "c3_full": (50, 100, 65536, "fixed"), "c3_f32": (50, 100, 8192, "fixed"), "c2_f32": (20, 40, 4096, "fixed"),
+    "c5_default": (200, 400, 8192, "default"), "c5_sqp": (200, 400, 8192, "sqp"), "c5_sp_default": (200, 400, 8192, "default"), "c5_sp_sqp": (200, 400, 8192, "sqp"),
+    "c3_fixed98": (50, 100, 8192, "fixed98"),
 }
 W = {k: v for k, v in W.items() if os.path.isdir(os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, k)))}  # (the workloads this round profiled)
 for name, (n, m, batch, mode) in W.items():

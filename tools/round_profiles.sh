@@ -22,6 +22,11 @@ run c3_sqp --workload c3 --global-batch 0 --mode sqp
 run c2 --workload c2
 run c5 --workload c5 --steps 5
 run c5_sp --workload c5 --steps 5 --p-density 0.03          # the same shape with P in compressed columns (read in place)
+run c5_default --workload c5 --steps 3 --mode default        # config 5 under the reference defaults / the SQP driver's settings
+run c5_sqp --workload c5 --steps 5 --mode sqp
+run c5_sp_default --workload c5 --steps 2 --p-density 0.03 --mode default
+run c5_sp_sqp --workload c5 --steps 5 --p-density 0.03 --mode sqp
+run c3_fixed98 --workload c3 --global-batch 0 --iters 98      # (what the SQP-settings call of the C3 shard would stream without its checks: 98 iterations, no check)
 run lane --n 2 --m 3 --batch-per-gpu 65536
 [ $PHASE = prof ] && exit 0
 timeout 600 python bench.py --global-batch 65536 --steps 5 --mode default >> gpurun_out/${TAG}_bench_lines.new 2>/dev/null
