@@ -393,6 +393,15 @@ def test_wg_stacked_operator():
     cases.failing_pivots(make_wg, n=90, m=60, batch=3)  # ... with seven block columns in swizzled blocks (56 < n <= 112)
 
 
+def test_csr_dense_tile_edge_8():
+    """the CU-wide kernel's dense mode at tile edge 8 (224 < n <= 256, round 6) under the emulator: fixed iterations and the default
+    termination with adaptive rho at (250, 300) — the shape whose checking instantiation the GPU miscompiles with
+    -structurizecfg-skip-uniform-regions (sqp_solver_amd/build.py): the emulator says the source is right"""
+    mk = lambda n, m, b, **kw: simlib.SimSolverBatch(n, m, b, variant=11, keep_factor=kw.get("keep_factor", False))  # noqa: E731
+    cases.parity_fixed_iters(mk, 250, 300, 1, iters=10)
+    cases.parity_termination(mk, 250, 300, 1, adaptive=True)
+
+
 def make_csr_dense(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw):
     return simlib.SimSolverBatch(n, m, batch, dtype=dtype, variant=simlib.CSR_DENSE, legacy_cold_start=legacy_cold_start, keep_factor=kw.get("keep_factor", False))
 
