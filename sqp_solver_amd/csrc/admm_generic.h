@@ -108,11 +108,17 @@ __device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int
 #else
 #define SQPH_GENERIC_NOINLINE __attribute__((noinline))  // (three call sites; a real call keeps the set-up's registers out of the iteration loop's allocation)
 #endif
+}  // namespace sqph
+#include "admm_generic_msetup.h"
+namespace sqph {
 template <typename T, typename TIN>
 __device__ SQPH_GENERIC_NOINLINE bool factor_schur(int n, int m, const TIN *__restrict__ P, const T *__restrict__ At, const T *rho, T sigma,
                              T *__restrict__ Wm, T *__restrict__ Wt, T *row, T *sj, T *dsv, T *stage) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int nn = n * n;
+    if constexpr (sizeof(T) == 8) {  // the blocked set-up on the matrix pipe where the blocks fit the workspace (admm_generic_msetup.h)
+        if (GenericBlocked::fits(n, nt)) return GenericBlocked::factor<TIN>(n, m, P, At, rho, sigma, Wm, Wt, stage);
+    }
     // S through LDS: KB rows of At at a time in `stage` (the idle reduction scratch, 8 nt elements); a thread owns row i of a block of four
     // columns (a "unit": one LDS read of At[k][i] and four broadcast reads of At[k][j..j+3] per four products) and up to U = 2 units per
     // pass, all of a pass's sums in registers across the whole k range — every entry is still the two chains s0 (even k) + s1 (odd k) of

@@ -393,6 +393,26 @@ def test_wg_stacked_operator():
     cases.failing_pivots(make_wg, n=90, m=60, batch=3)  # ... with seven block columns in swizzled blocks (56 < n <= 112)
 
 
+def test_generic_blocked_setup():
+    """the generic kernel's blocked MFMA set-up on global-memory blocks (admm_generic_msetup.h: n >= 48, >= 4 wavefronts): fixed
+    iterations, termination with adaptive rho (in-kernel refactorisation), a non-SPD Schur complement, solve() on a kept factor"""
+    def mk(nt):
+        return lambda n, m, b, **kw: simlib.SimSolverBatch(n, m, b, variant=simlib.GENERIC, nt=nt, keep_factor=kw.get("keep_factor", False))
+    cases.parity_fixed_iters(mk(256), 60, 80, 2, iters=30)
+    cases.parity_fixed_iters(mk(512), 100, 50, 1, iters=20)
+    cases.parity_fixed_iters(mk(256), 49, 7, 2, iters=20)
+    cases.parity_termination(mk(256), 70, 120, 2, adaptive=True)
+    cases.fused_then_solve(mk(256), n=64, m=40, batch=2)
+    P, q, A, l, u = cases.random_qp_batch(2, 60, 80, seed=23)
+    P = P.copy()
+    P[0] = -100.0 * np.eye(60)  # S = P + sigma I + A'RA indefinite
+    s = mk(256)(60, 80, 2)
+    s.settings.max_iter, s.settings.check_termination = 20, 0
+    s.setup_solve(P, q, A, l, u)
+    x, y, z, info = s.solution()
+    assert info.status[0] == cases.NUMERICAL_ISSUES and info.status[1] == cases.MAX_ITER_EXCEEDED
+
+
 def test_csr_dense_tile_edge_8():
     """the CU-wide kernel's dense mode at tile edge 8 (224 < n <= 256, round 6) under the emulator: fixed iterations and the default
     termination with adaptive rho at (250, 300) — the shape whose checking instantiation the GPU miscompiles with

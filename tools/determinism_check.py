@@ -30,3 +30,6 @@ run(100, 200, 1024, 100, 20, "fixed")
 run(30, 60, 8192, 100, 30, "default")
 run(8, 12, 65536, 100, 30, "default")
 run(2, 3, 65536, 100, 30, "adaptive")
+run(250, 300, 512, 0, 12, "adaptive")   # the CU-wide kernel's dense mode at tile edge 8 (round 6), full occupancy
+run(240, 500, 512, 100, 12, "fixed")
+run(200, 400, 512, 0, 12, "default")
