@@ -23,14 +23,18 @@ __host__ __device__ inline size_t generic_lds_elems(int n, int m, int nt) {
 
 // out[r] = sum_k M[k*ld + r] * v[k]   (outputs contiguous in memory => coalesced across lanes).
 // v, out, part in LDS. Ends with a barrier; callers must have synchronised v beforehand.
+// tri (block-uniform): 0 = full; 1 = M[k ld + r] is zero for k > r (W, column-major), 2 = zero for k < r (W' from the row-major copy):
+// the structural zeros are not streamed (a quarter of an iteration's bytes at m = 2 n).  The terms that remain keep their chains (the
+// skipped ones added exact zeros): results bit for bit those of the full product.
 template <typename T, typename TM>
-__device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int R, int K, const T *v, T *out, T *part) {
+__device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int R, int K_, const T *v, T *out, T *part, int tri = 0) {
     const int tid = threadIdx.x, nt = blockDim.x;
     if (R <= 0) return;  // m == 0 (unconstrained QP): block-uniform
     if (R >= nt) {
         for (int r = tid; r < R; r += nt) {
             T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            int k = 0;
+            const int K = (tri == 1 && r + 1 < K_) ? r + 1 : K_;
+            int k = tri == 2 ? (r & ~3) : 0;
             // eight loads requested before the first is used (the matrices of these shapes stream from L2 / the Infinity Cache: with
             // four in flight per lane a 1,024-lane workgroup moved 15 GB/s); the chains a0 .. a3 and their order are unchanged
             for (; k + 7 < K; k += 8) {
@@ -64,7 +68,12 @@ __device__ __forceinline__ void matvec_cm(const TM *__restrict__ M, long ld, int
     const int r = tid - g * R;
     T a0 = 0, a1 = 0;
     if (g < G) {
+        const int K = (tri == 1 && r + 1 < K_) ? r + 1 : K_;
         int k = g;
+        if (tri == 2 && r > g) {  // the first k >= r of this group's sequence g, g + G, ... whose position in it is even
+            const int idx = (r - g + G - 1) / G;
+            k = g + (idx & ~1) * G;
+        }
         for (; k + 7 * G < K; k += 8 * G) {  // (eight loads in flight; the two chains keep their terms and order)
             T mv[8];
 #pragma unroll
@@ -402,8 +411,8 @@ __global__ void admm_generic_kernel(KArgs<T, TIN> a) {
             matvec_cm<T>(At, n, n, m, w, b, part);  // b = A' w
             for (int j = tid; j < n; j += nt) b[j] = (sigma * x[j] - q[j]) + b[j];
             __syncthreads();
-            matvec_cm<T>(Wm, n, n, n, b, Px, part);   // W b      (Px is scratch outside the checks)
-            matvec_cm<T>(Wt, n, n, n, Px, xt, part);  // x~ = W' (W b)
+            matvec_cm<T>(Wm, n, n, n, b, Px, part, 1);   // W b      (Px is scratch outside the checks)
+            matvec_cm<T>(Wt, n, n, n, Px, xt, part, 2);  // x~ = W' (W b)
             matvec_cm<T>(gA, m, m, n, xt, zt, part);   // z~ = A x~
             for (int j = tid; j < n; j += nt) x[j] = alpha * xt[j] + one_m_alpha * x[j];
             for (int i = tid; i < m; i += nt) {
