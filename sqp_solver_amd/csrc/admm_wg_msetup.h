@@ -515,6 +515,16 @@ struct MSetup {
             // up B[R s + r][16 k + c] = D_k[c][r & 15]
             static_assert(!STACK && (C == 16 || C == 8), "tile column k is column 8 (k & 1) + c or c of result block k / 2 or k");
             T *DS = lds + O_DS;
+            // the k-loop below runs whole 16-column blocks: the columns of the staged block between the tile's width and the block
+            // boundary are never written by the tiles, and a solve() that LOADED its factor finds whatever the CU's previous workgroup
+            // left there (after a factorisation it is the finite L panel) — W is zero in those columns, but 0 x NaN is NaN
+            if constexpr (16 * NB > C * TC) {
+                constexpr int PADC = 16 * NB - C * TC;
+                for (int e = t; e < 16 * PADC; e += NT) {
+                    const int j = C * TC + e % PADC;
+                    XS[(j >> 4) * BS + ix(e / PADC, j & 15)] = T(0);
+                }
+            }
 #pragma unroll
             for (int sh = 0; sh < TR * RH; sh++) {
                 const int s = sh / RH, h = sh % RH;

@@ -576,11 +576,14 @@ def api_sequence_fuzz(make, n, m, batch, seed, steps=12, adaptive_ok=True, **kw)
         if hasattr(s, "kernel_name"):
             kernels.add(s.kernel_name())
         for b, o in enumerate(orc):
-            assert info.status[b] == o.info.status and info.iter[b] == o.info.iter and info.rho_updates[b] == o.info.rho_updates, (log, tag, b)
+            got = (int(info.status[b]), int(info.iter[b]), int(info.rho_updates[b]))
+            assert got == (o.info.status, o.info.iter, o.info.rho_updates), (log, tag, b, "status/iter/rho_updates", got, (o.info.status, o.info.iter, o.info.rho_updates))
             xo, yo, zo = o.primal_solution(), o.dual_solution(), o.z()
-            assert relerr(x[b][None], xo[None]) < TOL_F64, (log, tag, b)
+            ex = relerr(x[b][None], xo[None])
+            assert ex < TOL_F64, (log, tag, b, "x", ex)
             if m > 0:
-                assert relerr1(y[b][None], yo[None]) < TOL_F64 and relerr1(z[b][None], zo[None]) < TOL_F64, (log, tag, b)
+                ey, ez = relerr1(y[b][None], yo[None]), relerr1(z[b][None], zo[None])
+                assert ey < TOL_F64 and ez < TOL_F64, (log, tag, b, "y,z", ey, ez)
 
     ops = ["setup", "update", "solve", "solve", "setup_solve", "reuse", "set_state", "flip_check", "flip_verbose", "flip_warm", "flip_adaptive", "flip_iters"]
     for k in range(steps):

@@ -33,6 +33,13 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_sessionstart(session):
+    if _has_gpu():
+        import lds_poison
+
+        lds_poison.install()  # (SQPH_TEST_POISON_LDS=0 turns it off)
+
+
 def _hatch_summary():
     try:
         import cases
@@ -48,6 +55,10 @@ def _hatch_summary():
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """Parity escape hatches taken in this session (tests/cases.py::parity_termination), so that a green run says how green."""
+    import lds_poison
+
+    if lds_poison.STATE["lib"] is not None:
+        terminalreporter.write_line("LDS of every CU poisoned with NaN before each of %d solver calls (tests/lds_poison.hip)" % lds_poison.STATE["calls"])
     s = _hatch_summary()
     if s is None:
         return

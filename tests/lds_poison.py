@@ -1,0 +1,41 @@
+"""GPU suite and soak tools: every solver call of the Python facade finds the LDS of all CUs filled with NaN (tests/lds_poison.hip), so
+that a kernel reading LDS it did not write fails deterministically instead of depending on which kernel ran on the CU before.
+LDS is cleared neither between kernels nor between processes.  SQPH_TEST_POISON_LDS=0 turns it off."""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STATE = {"lib": None, "calls": 0}
+
+
+def install():
+    if STATE["lib"] is not None or os.environ.get("SQPH_TEST_POISON_LDS", "1") == "0":
+        return False
+    src, so = os.path.join(HERE, "lds_poison.hip"), os.path.join(HERE, "_lds_poison.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.lds_poison.argtypes = [ctypes.c_uint, ctypes.c_int]
+    from sqp_solver_amd import qp as _qp
+
+    def wrap(name):
+        inner = getattr(_qp.QPSolverBatch, name)
+
+        def call(self, *a, **k):
+            import torch
+
+            if torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing():  # (a device-wide synchronisation would invalidate the capture)
+                return inner(self, *a, **k)
+            self.synchronize()
+            rc = lib.lds_poison(0xFFFFFFFF, 160 * 1024)
+            assert rc == 0, "lds_poison: hip error %d" % rc
+            STATE["calls"] += 1
+            return inner(self, *a, **k)
+
+        setattr(_qp.QPSolverBatch, name, call)
+
+    wrap("_call")
+    wrap("_call_csr")
+    STATE["lib"] = lib
+    return True

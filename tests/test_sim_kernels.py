@@ -274,7 +274,10 @@ def test_wg_tall_shapes(n, m):
         # with m = 14 n .. 15 n the adapted rho puts 1 of 20 QPs at (16, 224) and 2 of 20 at (10, 150) at 10x their own fp64 noise
         # floor; counted in the session summary like every hatch)
         cases.parity_termination(mk, n, m, 20 if n < 20 else 2, adaptive=True, diagnostics=False, **({"max_hatch_frac": 0.15} if n < 20 else {}))
-        cases.fused_then_solve(mk, n, m, 2, adaptive=False)  # (adaptive rho on these constraint-heavy QPs sits at the fp64 noise floor)
+    # every shape: solve() on a LOADED factor — n = 50 and 56 are the tiles whose width is not a multiple of the 16-column blocks of
+    # the MFMA set-up (round 6: build_B read the never-written pad columns of the staged A block, NaN under the emulator's LDS poison
+    # and on the GPU whenever the CU's previous workgroup had left NaN / inf there)
+    cases.fused_then_solve(mk, n, m, 2, adaptive=False)  # (adaptive rho on these constraint-heavy QPs sits at the fp64 noise floor)
 
 
 @pytest.mark.parametrize("make,n,m", [(make_generic, 6, 9), (make_wg, 8, 12), (make_wg, 50, 100), (make_g16, 8, 12), (make_wg, 20, 40)],

@@ -6,7 +6,9 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "t
 import numpy as np
 import cases
 from test_gpu_parity import make_gpu
-rng = np.random.default_rng(12345)
+import lds_poison
+print("LDS poison before every call:", lds_poison.install())
+rng = np.random.default_rng(12345 + int(os.environ.get("SQPH_SOAK_SEED", "0")))
 seen = {}
 fails = []
 for t in range(120):
@@ -16,7 +18,7 @@ for t in range(120):
         log, kernels = cases.api_sequence_fuzz(make_gpu, n, m, 2, seed=5000 + t, steps=7, adaptive_ok=(n > 4 and n <= m <= 2.5 * n + 20))
         for k in kernels: seen[k] = seen.get(k, 0) + 1
     except AssertionError as e:
-        fails.append((n, m, str(e)[:300]))
+        fails.append((n, m, t, str(e)[:1500]))
     except Exception as e:
         fails.append((n, m, "EXC " + repr(e)[:300]))
 print("kernels exercised:", sorted(seen.items()))

@@ -4,8 +4,10 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "t
 import numpy as np
 import cases
 from test_gpu_parity import make_gpu, _CsrFacade
+import lds_poison
+print("LDS poison before every call:", lds_poison.install())
 from sqp_solver_amd.problems import random_csr_qp_batch
-rng = np.random.default_rng(777)
+rng = np.random.default_rng(777 + int(os.environ.get("SQPH_SOAK_SEED", "0")))
 seen = {}; fails = []
 for t in range(50):
     n = int(rng.integers(2, 240)); m = int(rng.integers(1, 530)); dens = float(rng.choice([0.03, 0.08, 0.3]))

@@ -6,8 +6,10 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "t
 import numpy as np
 import oracle, cases
 from test_gpu_parity import make_gpu
+import lds_poison
+print("LDS poison before every call:", lds_poison.install())
 from sqp_solver_amd.problems import random_csr_qp_batch
-rng = np.random.default_rng(90210)
+rng = np.random.default_rng(90210 + int(os.environ.get("SQPH_SOAK_SEED", "0")))
 tot = differ = orc_bad = 0; kern = {}; notes = []
 for t in range(48):
     n = int(rng.integers(5, 225)); m = int(rng.integers(8, 513)); dens = float(rng.choice([0.03, 0.06, 0.15]))

@@ -5,8 +5,10 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "t
 import numpy as np
 import oracle, cases
 from test_gpu_parity import make_gpu
+import lds_poison
+print("LDS poison before every call:", lds_poison.install())
 from sqp_solver_amd.problems import random_csr_qp_batch
-rng = np.random.default_rng(4242)
+rng = np.random.default_rng(4242 + int(os.environ.get("SQPH_SOAK_SEED", "0")))
 tot = bad = 0; kern = {}; worst = 0.0; notes = []
 for t in range(36):
     n = int(rng.integers(17, 225)); m = int(rng.integers(129, 513)); dens = float(rng.choice([0.03, 0.06, 0.15]))

@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, oracle
 from sqp_solver_amd import QPSolverBatch
 from sqp_solver_amd.problems import random_qp_batch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+import lds_poison
+print("LDS poison before every call:", lds_poison.install())
 lo, hi, st = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 ms = [int(v) for v in sys.argv[4].split(",")]
 bad = 0
