@@ -184,6 +184,25 @@ __global__ void csr_check(int batch, int n, int m, long long nnz_cap, const int 
 
 }  // namespace
 
+// every device allocation of the library.  Experiment builds with SQPH_POISON_WS set fill it with 0xFF (NaN as doubles, -1 as ints) so
+// that a kernel reading workspace it never wrote fails instead of depending on what the allocator handed out (tools/xp/poison_ws.sh)
+static inline int ws_poison_byte() {
+#ifdef SQPH_EXPERIMENTS
+    static const int v = getenv("SQPH_POISON_WS") ? 0xFF : 0;
+    return v;
+#else
+    return 0;
+#endif
+}
+template <typename P>
+static inline hipError_t ws_malloc(P **p, size_t bytes) {
+    hipError_t e = hipMalloc((void **)p, bytes);
+#ifdef SQPH_EXPERIMENTS
+    if (e == hipSuccess && ws_poison_byte()) e = hipMemset(*p, 0xFF, bytes);
+#endif
+    return e;
+}
+
 struct sqph_solver {
     int device = 0, n = 0, m = 0, cap = 0, dtype = SQPH_F64, flags = 0;
     int num_simds = 1024;  // 4 per CU
@@ -313,17 +332,22 @@ int sqph_create(sqph_solver **out, int device, int n, int m, int batch_capacity,
     const size_t e = sizeof(double), B = (size_t)batch_capacity;  // state/workspace: always fp64
     const size_t mm = (size_t)(m > 0 ? m : 1);
     hipError_t err = hipSuccess;
+    int fill = ws_poison_byte();  // (0 outside the experiment builds)
     auto alloc = [&](void **p, size_t bytes) {
-        if (err == hipSuccess) err = hipMalloc(p, bytes);
-        if (err == hipSuccess) err = hipMemset(*p, 0, bytes);
+        if (err == hipSuccess) err = ws_malloc(p, bytes);
+        if (err == hipSuccess) err = hipMemset(*p, fill, bytes);
     };
+    fill = 0;  // the iterates of a new instance are zero (qp.hpp:74); everything else is written before it is read
     alloc(&s->x, B * n * e);
     alloc(&s->z, B * mm * e);
     alloc(&s->y, B * mm * e);
+    fill = ws_poison_byte();
     alloc(&s->rho_vec, B * mm * e);
     alloc(&s->rho, B * e);
     alloc((void **)&s->ctype, B * mm * sizeof(int));
+    fill = 0;
     alloc((void **)&s->info, B * sizeof(sqph_info));
+    fill = ws_poison_byte();
     alloc(&s->Sinv, B * 2 * (size_t)n * n * e);
     if (err == hipSuccess) {
         // every instance starts UNINITIALIZED (qp.hpp:74): status field = 4, rest 0
@@ -512,7 +536,7 @@ int sqph_get_solution(sqph_solver *s, int batch, int memspace, void *x, void *y,
                 s->hout_cap = 0;
                 const size_t cap = words * 8 < 65536 ? 65536 : words * 8;
                 SQPH_HIP(s, hipHostMalloc(&s->hout, cap, hipHostMallocMapped | hipHostMallocCoherent));
-                SQPH_HIP(s, hipMalloc(&s->dout, cap));
+                SQPH_HIP(s, ws_malloc(&s->dout, cap));
                 if (hipHostGetDevicePointer(&s->hout_dev, s->hout, 0) != hipSuccess) s->hout_dev = nullptr;
                 s->hout_cap = cap;
             }
@@ -663,7 +687,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
             static size_t dbg_cap = 0;
             if ((size_t)qp->batch > dbg_cap) {
                 if (dbg) (void)hipFree(dbg);
-                SQPH_HIP(s, hipMalloc((void **)&dbg, (size_t)qp->batch * 8 * sizeof(unsigned long long)));
+                SQPH_HIP(s, ws_malloc((void **)&dbg, (size_t)qp->batch * 8 * sizeof(unsigned long long)));
                 dbg_cap = qp->batch;
             }
             SQPH_HIP(s, hipMemsetAsync(dbg, 0, (size_t)qp->batch * 8 * sizeof(unsigned long long), s->stream));
@@ -678,7 +702,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
             if (s->trace) (void)hipFree(s->trace);
             s->trace = nullptr;
             s->trace_cap = 0;
-            SQPH_HIP(s, hipMalloc((void **)&s->trace, (1 + 4 * (size_t)cap) * sizeof(double)));
+            SQPH_HIP(s, ws_malloc((void **)&s->trace, (1 + 4 * (size_t)cap) * sizeof(double)));
             s->trace_cap = cap;
         }
         SQPH_HIP(s, hipMemsetAsync(s->trace, 0, sizeof(double), s->stream));
@@ -776,7 +800,7 @@ int launch_typed(sqph_solver *s, const sqph_qp_batch *qp, int mode, const void *
     if (!launched) {
         if (!s->At) {
             const size_t bytes = (size_t)s->cap * (size_t)(s->m > 0 ? s->m : 1) * s->n * sizeof(T);
-            SQPH_HIP(s, hipMalloc(&s->At, bytes));
+            SQPH_HIP(s, ws_malloc(&s->At, bytes));
         }
         a.At = (T *)s->At;
         a.mode = for_family('g');
@@ -853,7 +877,7 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
                 s->hpin_cap = 0;
                 const size_t cap = total < 65536 ? 65536 : total;
                 SQPH_HIP(s, hipHostMalloc(&s->hpin, cap, hipHostMallocMapped | hipHostMallocCoherent));
-                SQPH_HIP(s, hipMalloc(&s->dpin, cap));
+                SQPH_HIP(s, ws_malloc(&s->dpin, cap));
                 if (hipHostGetDevicePointer(&s->hpin_dev, s->hpin, 0) != hipSuccess) s->hpin_dev = nullptr;
                 s->hpin_cap = cap;
             }
@@ -889,7 +913,7 @@ int run(sqph_solver *s, const sqph_qp_batch *qp, int mode, const char *what, con
                          {qp->l, &s->sl, m, &sl}, {qp->u, &s->su, m, &su}};
         for (auto &it : items) {
             if (it.elems == 0) continue;
-            if (!*it.dst) SQPH_HIP(s, hipMalloc(it.dst, (size_t)s->cap * it.elems * e));
+            if (!*it.dst) SQPH_HIP(s, ws_malloc(it.dst, (size_t)s->cap * it.elems * e));
             if (*it.stride == 0) {
                 SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, it.elems * e, hipMemcpyHostToDevice, s->stream));
             } else if ((size_t)*it.stride == it.elems) {
@@ -944,7 +968,7 @@ static int stage_sparse_P(sqph_solver *s, const sqph_csr_batch *c, const sqph_cs
     if (c->memspace == SQPH_HOST) {
         const size_t nind = s_ind ? B * (size_t)s_ind : (size_t)sp->nnz_max;
         const size_t nval = s_val ? B * (size_t)s_val : (size_t)sp->nnz_max;
-        if (!s->pPtr) SQPH_HIP(s, hipMalloc(&s->pPtr, (size_t)s->cap * (n + 1) * sizeof(int)));
+        if (!s->pPtr) SQPH_HIP(s, ws_malloc(&s->pPtr, (size_t)s->cap * (n + 1) * sizeof(int)));
         if (s_ptr && (size_t)s_ptr != n + 1) {
             SQPH_HIP(s, hipMemcpy2DAsync(s->pPtr, (n + 1) * sizeof(int), colptr, (size_t)s_ptr * sizeof(int), (n + 1) * sizeof(int), B,
                                          hipMemcpyHostToDevice, s->stream));
@@ -956,14 +980,14 @@ static int stage_sparse_P(sqph_solver *s, const sqph_csr_batch *c, const sqph_cs
             if (s->pInd) (void)hipFree(s->pInd);
             s->pInd = nullptr;
             s->pInd_cap = 0;
-            SQPH_HIP(s, hipMalloc(&s->pInd, (nind ? nind : 1) * sizeof(int)));
+            SQPH_HIP(s, ws_malloc(&s->pInd, (nind ? nind : 1) * sizeof(int)));
             s->pInd_cap = nind;
         }
         if (nval > s->pVal_cap) {
             if (s->pVal) (void)hipFree(s->pVal);
             s->pVal = nullptr;
             s->pVal_cap = 0;
-            SQPH_HIP(s, hipMalloc(&s->pVal, (nval ? nval : 1) * e));
+            SQPH_HIP(s, ws_malloc(&s->pVal, (nval ? nval : 1) * e));
             s->pVal_cap = nval;
         }
         if (nind) SQPH_HIP(s, hipMemcpyAsync(s->pInd, rowind, nind * sizeof(int), hipMemcpyHostToDevice, s->stream));
@@ -975,7 +999,7 @@ static int stage_sparse_P(sqph_solver *s, const sqph_csr_batch *c, const sqph_cs
                          {c->u, &s->su, m, c->stride_u, &d->u, &d->stride_u}};
         for (auto &it : items) {
             if (it.elems == 0) continue;
-            if (!*it.dst) SQPH_HIP(s, hipMalloc(it.dst, (size_t)s->cap * it.elems * e));
+            if (!*it.dst) SQPH_HIP(s, ws_malloc(it.dst, (size_t)s->cap * it.elems * e));
             if (it.stride == 0) {
                 SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, it.elems * e, hipMemcpyHostToDevice, s->stream));
             } else if ((size_t)it.stride == it.elems) {
@@ -996,8 +1020,8 @@ static int place_sparse_P(sqph_solver *s, int batch, const SparsePDev &dv, bool 
     DeviceGuard g(s->device);
     const bool shared = dv.s_val == 0;
     const size_t nexp = shared ? 1 : B, ncheck = dv.s_ptr == 0 ? 1 : B;  // (a shared pattern is checked once)
-    if (expand && !s->cP) SQPH_HIP(s, hipMalloc(&s->cP, (size_t)s->cap * n * n * e));
-    if (!s->cBad) SQPH_HIP(s, hipMalloc((void **)&s->cBad, sizeof(int)));
+    if (expand && !s->cP) SQPH_HIP(s, ws_malloc(&s->cP, (size_t)s->cap * n * n * e));
+    if (!s->cBad) SQPH_HIP(s, ws_malloc((void **)&s->cBad, sizeof(int)));
     if (expand) SQPH_HIP(s, hipMemsetAsync(s->cP, 0, nexp * n * n * e, s->stream));
     SQPH_HIP(s, hipMemsetAsync(s->cBad, 0, sizeof(int), s->stream));
     const size_t nk = expand ? nexp : ncheck;
@@ -1084,7 +1108,7 @@ static int run_csr_impl(sqph_solver *s, const sqph_csr_batch *c, int mode, const
         const size_t nrow = s_row ? B * (size_t)s_row : m + 1;
         const size_t ncol = s_col ? B * (size_t)s_col : (size_t)c->nnz_max;
         const size_t nval = s_val ? B * (size_t)s_val : (size_t)c->nnz_max;
-        if (!s->cRow) SQPH_HIP(s, hipMalloc(&s->cRow, (size_t)s->cap * (m + 1) * sizeof(int)));
+        if (!s->cRow) SQPH_HIP(s, ws_malloc(&s->cRow, (size_t)s->cap * (m + 1) * sizeof(int)));
         if (s_row && (size_t)s_row != m + 1) {
             SQPH_HIP(s, hipMemcpy2DAsync(s->cRow, (m + 1) * sizeof(int), rowptr, (size_t)s_row * sizeof(int), (m + 1) * sizeof(int), B,
                                          hipMemcpyHostToDevice, s->stream));
@@ -1096,13 +1120,13 @@ static int run_csr_impl(sqph_solver *s, const sqph_csr_batch *c, int mode, const
         if (ncol > s->cCol_cap) {
             if (s->cCol) (void)hipFree(s->cCol);
             s->cCol = nullptr;
-            SQPH_HIP(s, hipMalloc(&s->cCol, (ncol ? ncol : 1) * sizeof(int)));
+            SQPH_HIP(s, ws_malloc(&s->cCol, (ncol ? ncol : 1) * sizeof(int)));
             s->cCol_cap = ncol;
         }
         if (nval > s->cVal_cap) {
             if (s->cVal) (void)hipFree(s->cVal);
             s->cVal = nullptr;
-            SQPH_HIP(s, hipMalloc(&s->cVal, (nval ? nval : 1) * e));
+            SQPH_HIP(s, ws_malloc(&s->cVal, (nval ? nval : 1) * e));
             s->cVal_cap = nval;
         }
         if (ncol) SQPH_HIP(s, hipMemcpyAsync(s->cCol, colind, ncol * sizeof(int), hipMemcpyHostToDevice, s->stream));
@@ -1133,7 +1157,7 @@ static int run_csr_impl(sqph_solver *s, const sqph_csr_batch *c, int mode, const
 #undef SQPH_CSB_PICK
         }
         if (NB || (TT && lds_bytes <= 160 * 1024)) {
-            if (!s->cBad) SQPH_HIP(s, hipMalloc((void **)&s->cBad, sizeof(int)));
+            if (!s->cBad) SQPH_HIP(s, ws_malloc((void **)&s->cBad, sizeof(int)));
             SQPH_HIP(s, hipMemsetAsync(s->cBad, 0, sizeof(int), s->stream));
             const size_t npat = s_row ? B : 1;
             hipLaunchKernelGGL(csr_check, dim3((unsigned)((npat * m + 255) / 256)), dim3(256), 0, s->stream, (int)npat, (int)n, (int)m,
@@ -1164,8 +1188,8 @@ static int run_csr_impl(sqph_solver *s, const sqph_csr_batch *c, int mode, const
     }
     const bool shared = s_val == 0;
     const size_t nexp = shared ? 1 : B;
-    if (!s->cA) SQPH_HIP(s, hipMalloc(&s->cA, (size_t)s->cap * m * n * e));
-    if (!s->cBad) SQPH_HIP(s, hipMalloc((void **)&s->cBad, sizeof(int)));
+    if (!s->cA) SQPH_HIP(s, ws_malloc(&s->cA, (size_t)s->cap * m * n * e));
+    if (!s->cBad) SQPH_HIP(s, ws_malloc((void **)&s->cBad, sizeof(int)));
     SQPH_HIP(s, hipMemsetAsync(s->cA, 0, nexp * m * n * e, s->stream));
     SQPH_HIP(s, hipMemsetAsync(s->cBad, 0, sizeof(int), s->stream));
     const unsigned blocks = (unsigned)((nexp * m + 255) / 256);
@@ -1191,7 +1215,7 @@ static int run_csr_impl(sqph_solver *s, const sqph_csr_batch *c, int mode, const
         if (!d.P || !d.q || !d.l || !d.u) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: null problem pointer", what);
         if (sP < 0 || sq < 0 || sl < 0 || su < 0) SQPH_FAIL(s, SQPH_ERR_INVALID, "%s: negative stride", what);
         for (auto &it : items) {
-            if (!*it.dst) SQPH_HIP(s, hipMalloc(it.dst, (size_t)s->cap * it.elems * e));
+            if (!*it.dst) SQPH_HIP(s, ws_malloc(it.dst, (size_t)s->cap * it.elems * e));
             if (*it.stride == 0) {
                 SQPH_HIP(s, hipMemcpyAsync(*it.dst, it.src, it.elems * e, hipMemcpyHostToDevice, s->stream));
             } else if ((size_t)*it.stride == it.elems) {
@@ -1300,9 +1324,9 @@ int sqph_gather_create_ex(sqph_gather **out, int device, int n, int m, long long
     g->device = device; g->n = n; g->m = m; g->total = total; g->flags = flags;
     DeviceGuard dg(device);
     const size_t mm = (size_t)(m > 0 ? m : 1);
-    hipError_t e = hipMalloc((void **)&g->x, (size_t)total * n * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&g->y, (size_t)total * mm * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&g->info, (size_t)total * sizeof(sqph_info));
+    hipError_t e = ws_malloc((void **)&g->x, (size_t)total * n * sizeof(double));
+    if (e == hipSuccess) e = ws_malloc((void **)&g->y, (size_t)total * mm * sizeof(double));
+    if (e == hipSuccess) e = ws_malloc((void **)&g->info, (size_t)total * sizeof(sqph_info));
     if (e == hipSuccess) {
         e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     }
