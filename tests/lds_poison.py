@@ -14,8 +14,19 @@ def install():
         return False
     src, so = os.path.join(HERE, "lds_poison.hip"), os.path.join(HERE, "_lds_poison.so")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, src])
-    lib = ctypes.CDLL(so)
+        try:
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so + ".tmp", src],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            os.replace(so + ".tmp", so)
+        except Exception as e:  # a test tool must not take the suite down: keep an older build, or run unpoisoned and say so
+            print("lds_poison: build failed (%r); %s" % (e, "using the existing build" if os.path.exists(so) else "LDS poison OFF"))
+            if not os.path.exists(so):
+                return False
+    try:
+        lib = ctypes.CDLL(so)
+    except OSError as e:
+        print("lds_poison: cannot load %s (%r); LDS poison OFF" % (so, e))
+        return False
     lib.lds_poison.argtypes = [ctypes.c_uint, ctypes.c_int]
     from sqp_solver_amd import qp as _qp
 
