@@ -30,12 +30,16 @@ for t in range(36):
         tot += 1
         same = info.status[b] == io["status"][b] and info.iter[b] == io["iter"][b] and info.rho_updates[b] == io["rho_updates"][b]
         ex = cases.relerr(x[b:b + 1], xo[b:b + 1]); ey = cases.relerr(y[b:b + 1], yo[b:b + 1])
-        rd = abs(info.res_dual[b] - io["res_dual"][b]) / max(abs(io["res_dual"][b]), 1e-12)
+        # the reported dual residual against the oracle's: 1e-5 relative plus the rounding level of its terms (P x + q + A'y with |q| ~ 1:
+        # iterates that agree to 1e-11 leave residuals that agree to ~1e-11 absolute, whatever the residual's own size — a converged
+        # iterate's residual of 1e-12 is pure noise)
+        scale = max(1.0, float(np.max(np.abs(q[b]))))
+        rd = abs(info.res_dual[b] - io["res_dual"][b]) / (abs(io["res_dual"][b]) + 1e-5 * scale)
         if same: worst = max(worst, ex, ey)
         if not same or ex > 1e-6 or ey > 1e-6 or rd > 1e-5:
             bad += 1
-            notes.append((n, m, round(dens, 3), mode, b, int(info.status[b]), int(io["status"][b]), int(info.iter[b]), int(io["iter"][b]), int(info.rho_updates[b]), int(io["rho_updates"][b]), "%.1e %.1e rd %.1e" % (ex, ey, rd)))
+            notes.append((n, m, round(dens, 3), mode, b, int(info.status[b]), int(io["status"][b]), int(info.iter[b]), int(io["iter"][b]), int(info.rho_updates[b]), int(io["rho_updates"][b]), "%.1e %.1e rd %.1e (res_dual %.2e, oracle %.2e)" % (ex, ey, rd, info.res_dual[b], io["res_dual"][b])))
     s.close()
 print("kernels:", sorted(kern.items()))
-print("QPs %d, differing in status / iterations / rho updates or beyond 1e-6 (res_dual 1e-5): %d; worst x / y error among the equal ones %.2e" % (tot, bad, worst))
+print("QPs %d, differing in status / iterations / rho updates or beyond 1e-6 (res_dual: 1e-5 relative + 1e-10 absolute): %d; worst x / y error among the equal ones %.2e" % (tot, bad, worst))
 for r in notes[:12]: print(r)
