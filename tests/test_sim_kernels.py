@@ -554,3 +554,14 @@ def test_csrb_kernel_sparse_P_is_bit_identical_to_dense_P(n, m, density, pdens, 
             s.setup_csr(Parg, q, rp, ci, v, l, u)
             s.solve_csr(Parg, q, rp, ci, v, l, u)
         assert np.array_equal(a.solution()[0], b.solution()[0]) and np.array_equal(a.solution()[1], b.solution()[1])
+
+
+@pytest.mark.parametrize("n,m", [(4, 4), (8, 12), (16, 24), (32, 64), (32, 128), (50, 100), (56, 112), (64, 128), (16, 224), (32, 224), (56, 224),
+                                 (112, 32), (112, 208), (32, 448), (56, 448)])
+def test_wg_loaded_factor_at_every_shape_limit(n, m):
+    """solve() and setup_solve_reuse() on a factor LOADED from the workspace, at the largest (n, m) of every compiled register-tiled shape,
+    under the emulator's NaN-poisoned LDS: the path on which round 6's stale-LDS read lived (tile width 56 of the 64 columns of the MFMA
+    set-up's blocks) — a factorisation leaves finite numbers where a loaded factor leaves whatever was there"""
+    mk = lambda n_, m_, b, **kw: simlib.SimSolverBatch(n_, m_, b, variant=simlib.WG, keep_factor=kw.get("keep_factor", False))  # noqa: E731
+    cases.fused_then_solve(mk, n, m, 2, adaptive=False)
+    cases.soc_factor_reuse(mk, n, m, 2)
