@@ -432,9 +432,9 @@ def make_csr_dense(n, m, batch, dtype=np.float64, legacy_cold_start=False, **kw)
 def test_cu_wide_kernel_dense_mode():
     """CsrKernel::run<CHECKS, DENSE = true> (csr_dense.hip): the factor in the workgroup's registers, A streamed from global memory —
     fixed iterations, termination (plain / adaptive rho / SQP settings), float interface, state paths; tile edges 1, 2 and 4"""
-    for (n, m, b) in ((20, 40, 3), (40, 70, 2), (70, 30, 2), (100, 3, 1)):
-        cases.parity_fixed_iters(make_csr_dense, n, m, b, iters=60)
-    cases.parity_fixed_iters(make_csr_dense, 24, 50, 2, iters=60, dtype=np.float32)
+    for (n, m, b) in ((20, 40, 2), (40, 70, 2), (70, 30, 1), (100, 3, 1)):
+        cases.parity_fixed_iters(make_csr_dense, n, m, b, iters=30)
+    cases.parity_fixed_iters(make_csr_dense, 24, 50, 2, iters=30, dtype=np.float32)
     for kw in (dict(), dict(adaptive=True), dict(sqp_settings=True)):
         cases.parity_termination(make_csr_dense, 30, 61, 3, **kw)
     cases.fused_then_solve(make_csr_dense, n=33, m=40, batch=2)

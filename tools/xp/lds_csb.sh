@@ -3,7 +3,7 @@
 export PYTHONPATH=$PWD TMPDIR=/tmp
 for L in "$@"; do
   rm -rf /tmp/pmc_lds
-  SQPH_LIB=$L timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES -d /tmp/pmc_lds -o pmc -- python tools/bench_csr.py --steps 2 --check 0 > /dev/null 2>&1
+  SQPH_LIB=$L timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES -d /tmp/pmc_lds -o pmc -- python tools/bench_csr.py --steps 2 --check 0 --iters ${ITERS:-200} > /dev/null 2>&1
   f=$(find /tmp/pmc_lds -name "*counter_collection.csv" | head -1)
   python - "$f" "$L" <<'PY'
 import csv,sys,collections
