@@ -6,6 +6,9 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# every 32-bit word of LDS: 0xFFFFFFFF = NaN as doubles, -1 as ints; SQPH_TEST_POISON_PAT=7FF00000 = NaN as doubles, a huge positive int
+# SQPH_TEST_POISON_PAT=RANDOM = a different pseudo-random word everywhere, re-seeded per call
+PATTERN = 1 if os.environ.get("SQPH_TEST_POISON_PAT", "").upper() == "RANDOM" else int(os.environ.get("SQPH_TEST_POISON_PAT", "FFFFFFFF"), 16)
 STATE = {"lib": None, "calls": 0}
 
 
@@ -39,7 +42,7 @@ def install():
             if torch.cuda.is_initialized() and torch.cuda.is_current_stream_capturing():  # (a device-wide synchronisation would invalidate the capture)
                 return inner(self, *a, **k)
             self.synchronize()
-            rc = lib.lds_poison(0xFFFFFFFF, 160 * 1024)
+            rc = lib.lds_poison(PATTERN, 160 * 1024)
             assert rc == 0, "lds_poison: hip error %d" % rc
             STATE["calls"] += 1
             return inner(self, *a, **k)
