@@ -564,4 +564,5 @@ def test_wg_loaded_factor_at_every_shape_limit(n, m):
     set-up's blocks) — a factorisation leaves finite numbers where a loaded factor leaves whatever was there"""
     mk = lambda n_, m_, b, **kw: simlib.SimSolverBatch(n_, m_, b, variant=simlib.WG, keep_factor=kw.get("keep_factor", False))  # noqa: E731
     cases.fused_then_solve(mk, n, m, 2, adaptive=False)
-    cases.soc_factor_reuse(mk, n, m, 2)
+    if (n, m) in ((50, 100), (56, 224), (56, 448), (112, 208)):  # (the SOC re-solve: the widest shape of each set-up variant; the GPU suite runs it everywhere)
+        cases.soc_factor_reuse(mk, n, m, 2)
